@@ -1,0 +1,364 @@
+/*
+ * clover4_oracle.c -- scalar CPU restatement of Clover's 4-bit hot path.  TEST INFRASTRUCTURE ONLY.
+ * See clover4_oracle.h for scope, pinning status and the reference file:line each function follows.
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -mfma (see oracle/Makefile).  -ffp-contract=off matters:
+ * the reference's arithmetic is a fixed sequence of separately rounded fp32 operations plus explicit
+ * fused multiply-adds; the compiler must not fuse or split anything.
+ */
+#include "clover4_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+/* 1.0f/49.0f, correctly rounded = 0x3CA72F05 (CloverBase.h:88). */
+static const float RCP49 = 1.0f / 49.0f;
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* signed value of the high / low nibble of a byte */
+static inline int nib_hi(uint8_t b) { return (int)(int8_t)b >> 4; }
+static inline int nib_lo(uint8_t b) { return (int)(int8_t)(uint8_t)(b << 4) >> 4; }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* XORShift128+ as the reference runs it                                                              */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* canonical xorshift128+ state step, used only while deriving lanes 1..3 (simdxorshift128plus.h:38-44) */
+static void canon_step(uint64_t *a, uint64_t *b)
+{
+    uint64_t s1 = *a;
+    const uint64_t s0 = *b;
+    *a = s0;
+    s1 ^= s1 << 23;
+    *b = s1 ^ s0 ^ (s1 >> 18) ^ (s0 >> 5);
+}
+
+/* 2^64-step jump polynomial (simdxorshift128plus.h:47-62) */
+static void canon_jump(uint64_t in0, uint64_t in1, uint64_t *out0, uint64_t *out1)
+{
+    static const uint64_t poly[2] = { 0x8a5cd789635d2dffULL, 0x121fd2155c472f96ULL };
+    uint64_t a = 0, b = 0;
+    for (int i = 0; i < 2; i++) {
+        for (int bit = 0; bit < 64; bit++) {
+            if (poly[i] & (1ULL << bit)) { a ^= in0; b ^= in1; }
+            canon_step(&in0, &in1);
+        }
+    }
+    *out0 = a; *out1 = b;
+}
+
+void orc_rng_init(orc_rng *r, uint64_t key1, uint64_t key2)
+{
+    r->s0[0] = key1; r->s1[0] = key2;
+    for (int l = 1; l < 4; l++) canon_jump(r->s0[l - 1], r->s1[l - 1], &r->s0[l], &r->s1[l]);
+}
+
+/*
+ * One draw.  As written in the reference (simdxorshift128plus.h:97-109) `part1 = part2` runs first and
+ * both temporaries derive from part2, so the effective per-lane state is the 64-bit s1 alone.
+ */
+void orc_rng_draw(orc_rng *r, uint32_t W[8])
+{
+    for (int l = 0; l < 4; l++) {
+        const uint64_t a = r->s1[l];
+        const uint64_t t = a ^ (a << 23);
+        const uint64_t n = t ^ a ^ (t >> 18) ^ (a >> 5);
+        const uint64_t out = n + a;
+        r->s0[l] = a;
+        r->s1[l] = n;
+        W[2 * l]     = (uint32_t)out;
+        W[2 * l + 1] = (uint32_t)(out >> 32);
+    }
+}
+
+/* CloverVector4.h:690-734: mask 0x7F7F7F7F, four byte-shifts per draw, int->float, times 2^-31. */
+void orc_rng_block_noise(orc_rng *r, float noise[8][8])
+{
+    const float rcp_2pow31 = 1.0f / 2147483648.0f;
+    for (int d = 0; d < 2; d++) {
+        uint32_t W[8];
+        orc_rng_draw(r, W);
+        for (int sh = 0; sh < 4; sh++)
+            for (int j = 0; j < 8; j++) {
+                const uint32_t v = (W[j] & 0x7F7F7F7Fu) << (8 * sh);
+                noise[4 * d + sh][j] = (float)(int32_t)v * rcp_2pow31;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* quantisation core                                                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* 0 -> 1.0 fix-up on the bit pattern (CloverVector4.h:661-663) */
+static inline float fix_zero_max(float m) { return f2u(m) == 0u ? m + 1.0f : m; }
+
+/* one element: trunc(fma(|x|, k, noise)) with x's sign re-applied the way _mm256_sign_epi32 does
+ * (CloverVector4.h:741-772): pattern > 0 keeps, pattern == 0 zeroes, sign bit negates. */
+static inline int quant1(float x, float k, float noise)
+{
+    const float ax = u2f(f2u(x) & 0x7FFFFFFFu);
+    const float p = fmaf(ax, k, noise);
+    /* cvttps semantics; out-of-range (never reached for finite in-contract data) gives INT_MIN */
+    int32_t t = (p >= 2147483648.0f || p < -2147483648.0f || p != p) ? INT32_MIN : (int32_t)p;
+    const int32_t xb = (int32_t)f2u(x);
+    if (xb == 0) return 0;
+    return xb < 0 ? (int)(0u - (uint32_t)t) : t;
+}
+
+static inline uint8_t pack2(int q_even, int q_odd)
+{
+    return (uint8_t)(((q_even & 0xF) << 4) | (q_odd & 0xF));
+}
+
+/* quantise 64 consecutive values with a given scale multiplier; noise_of(e) supplies the noise */
+static void quant_block64(const float *x, float k, const float *noise64 /* per element or NULL */, uint8_t *q)
+{
+    for (int i = 0; i < 64; i += 2) {
+        const int a = quant1(x[i],     k, noise64 ? noise64[i]     : 0.0f);
+        const int b = quant1(x[i + 1], k, noise64 ? noise64[i + 1] : 0.0f);
+        q[i >> 1] = pack2(a, b);
+    }
+}
+
+void orc_v4_quantize(const float *x, uint64_t n_pad, uint8_t *q, float *s, orc_rng *rng)
+{
+    const uint64_t nb = n_pad / 64;
+    for (uint64_t b = 0; b < nb; b++) {
+        const float *xb = x + 64 * b;
+        float m = 0.0f;
+        for (int i = 0; i < 64; i++) { const float a = fabsf(xb[i]); if (a > m) m = a; }
+        m = fix_zero_max(m);
+        s[b] = m;
+        const float k = 7.0f / m;
+        if (rng) {
+            /* noise group g, lane j is added to element 8g + j (before the register transpose) */
+            float nz[8][8], flat[64];
+            orc_rng_block_noise(rng, nz);
+            for (int g = 0; g < 8; g++) for (int j = 0; j < 8; j++) flat[8 * g + j] = nz[g][j];
+            quant_block64(xb, k, flat, q + 32 * b);
+        } else {
+            quant_block64(xb, k, 0, q + 32 * b);
+        }
+    }
+}
+
+void orc_v4_restore(const uint8_t *q, const float *s, uint64_t n_pad, float *x)
+{
+    const uint64_t nb = n_pad / 64;
+    for (uint64_t b = 0; b < nb; b++) {
+        const float sc = s[b] / 7.0f;                         /* division first (CloverVector4.h:1050) */
+        for (int i = 0; i < 32; i++) {
+            const uint8_t v = q[32 * b + i];
+            x[64 * b + 2 * i]     = (float)nib_hi(v) * sc;
+            x[64 * b + 2 * i + 1] = (float)nib_lo(v) * sc;
+        }
+    }
+}
+
+float orc_v4_get(const uint8_t *q, const float *s, uint64_t pos)
+{
+    const float sc = s[pos >> 6] / 7.0f;
+    const uint8_t v = q[pos >> 1];
+    return sc * (float)((pos & 1) ? nib_lo(v) : nib_hi(v));
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* dot                                                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* exact integer sum of the 8 nibble products of one little-endian 32-bit word (4 bytes) */
+static inline int32_t word_isum(const uint8_t *u, const uint8_t *v)
+{
+    int32_t acc = 0;
+    for (int i = 0; i < 4; i++)
+        acc += nib_hi(u[i]) * nib_hi(v[i]) + nib_lo(u[i]) * nib_lo(v[i]);
+    return acc;
+}
+
+void orc_v4_word_isums(const uint8_t *qu, const uint8_t *qv, uint64_t n_pad, int32_t *I)
+{
+    const uint64_t nw = n_pad / 8;
+    for (uint64_t w = 0; w < nw; w++) I[w] = word_isum(qu + 4 * w, qv + 4 * w);
+}
+
+/* the final reduction of the 2 x 8 lane accumulators (CloverVector4.h:1190-1191, CloverBase.h:149-157) */
+static inline float reduce16(const float acc[2][8])
+{
+    float v[8], x[4];
+    for (int w = 0; w < 8; w++) v[w] = acc[0][w] + acc[1][w];
+    for (int j = 0; j < 4; j++) x[j] = v[j + 4] + v[j];
+    const float y0 = x[0] + x[2];
+    const float y1 = x[1] + x[3];
+    return y0 + y1;
+}
+
+/* one row/vector dot in the reference's SIMD order; su may be a tile-scale row of a matrix */
+static float dot_simd_order(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t nb)
+{
+    float acc[2][8];
+    memset(acc, 0, sizeof acc);
+    for (uint64_t b = 0; b < nb; b++) {
+        const float c = (su[b] * RCP49) * sv[b];              /* two separately rounded multiplies */
+        float *a = acc[b & 1];
+        for (int w = 0; w < 8; w++) {
+            const int32_t I = word_isum(qu + 32 * b + 4 * w, qv + 32 * b + 4 * w);
+            a[w] = fmaf(c, (float)I, a[w]);
+        }
+    }
+    return reduce16(acc);
+}
+
+float orc_v4_dot(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad)
+{
+    return dot_simd_order(qu, su, qv, sv, n_pad / 64);
+}
+
+float orc_v4_dot_scalar(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad)
+{
+    const uint64_t nb = n_pad / 64;
+    float result = 0.0f;
+    for (uint64_t b = 0; b < nb; b++) {
+        int16_t acc = 0;
+        for (int i = 0; i < 32; i++) {
+            const uint8_t u = qu[32 * b + i], v = qv[32 * b + i];
+            acc = (int16_t)(acc + (int16_t)(nib_hi(u) * nib_hi(v)) + (int16_t)(nib_lo(u) * nib_lo(v)));
+        }
+        const float sc = (su[b] / 7.0f) * (sv[b] / 7.0f);
+        const float term = sc * (float)acc;                   /* separate multiply, then add */
+        result = result + term;
+    }
+    return result;
+}
+
+double orc_v4_dot_f64(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad)
+{
+    const uint64_t nb = n_pad / 64;
+    double r = 0.0;
+    for (uint64_t b = 0; b < nb; b++) {
+        int32_t I = 0;
+        for (int w = 0; w < 8; w++) I += word_isum(qu + 32 * b + 4 * w, qv + 32 * b + 4 * w);
+        r += (double)su[b] * (double)sv[b] * (double)I / 49.0;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* matrix                                                                                            */
+/* ------------------------------------------------------------------------------------------------ */
+
+void orc_m4_quantize(const float *A, uint64_t rows, uint64_t cols, uint8_t *q, float *s, orc_rng *rng)
+{
+    const uint64_t hb = cols >> 6, vb = rows >> 6;
+    for (uint64_t bj = 0; bj < hb; bj++) {                    /* column-block outer (CloverMatrix4.h:524) */
+        for (uint64_t bi = 0; bi < vb; bi++) {
+            const float *t = A + (bi << 6) * cols + (bj << 6);
+            float m = 0.0f;
+            for (int i = 0; i < 64; i++)
+                for (int j = 0; j < 64; j++) { const float a = fabsf(t[(uint64_t)i * cols + j]); if (a > m) m = a; }
+            m = fix_zero_max(m);
+            s[bi * hb + bj] = m;
+            const float k = 7.0f / m;
+            for (int i = 0; i < 64; i++) {
+                uint8_t *dst = q + (((bi << 6) + i) * cols + (bj << 6)) / 2;
+                if (rng) {
+                    float nz[8][8], flat[64];
+                    orc_rng_block_noise(rng, nz);             /* two draws per tile row (:650-700) */
+                    for (int g = 0; g < 8; g++) for (int j = 0; j < 8; j++) flat[8 * g + j] = nz[g][j];
+                    quant_block64(t + (uint64_t)i * cols, k, flat, dst);
+                } else {
+                    quant_block64(t + (uint64_t)i * cols, k, 0, dst);
+                }
+            }
+        }
+    }
+}
+
+float orc_m4_get(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, uint64_t i, uint64_t j)
+{
+    (void)rows;
+    const float sc = s[(i >> 6) * (cols >> 6) + (j >> 6)] / 7.0f;
+    const uint64_t pos = i * cols + j;
+    const uint8_t v = q[pos >> 1];
+    return sc * (float)((pos & 1) ? nib_lo(v) : nib_hi(v));
+}
+
+void orc_m4_rowdots(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,
+                    const uint8_t *x, const float *sx, float *d)
+{
+    const uint64_t hb = cols >> 6;
+    for (uint64_t r = 0; r < rows; r++)
+        d[r] = dot_simd_order(A + r * (cols / 2), sA + (r >> 6) * hb, x, sx, hb);
+}
+
+void orc_m4_requantize64(const float d[64], uint8_t r[32], float *sr, orc_rng *rng)
+{
+    float m = 0.0f;
+    for (int i = 0; i < 64; i++) { const float a = fabsf(d[i]); if (a > m) m = a; }
+    m = fix_zero_max(m);
+    *sr = m;
+    const float k = 7.0f / m;
+    if (rng) {
+        /* results sit pre-transposed in block_values (CloverMatrix4.h:806-808, 909): noise group g,
+         * lane j lands on output row 8j + g */
+        float nz[8][8], flat[64];
+        orc_rng_block_noise(rng, nz);
+        for (int g = 0; g < 8; g++) for (int j = 0; j < 8; j++) flat[8 * j + g] = nz[g][j];
+        quant_block64(d, k, flat, r);
+    } else {
+        quant_block64(d, k, 0, r);
+    }
+}
+
+void orc_m4_mvm(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,
+                const uint8_t *x, const float *sx, uint8_t *r, float *sr, orc_rng *rng)
+{
+    const uint64_t hb = cols >> 6;
+    for (uint64_t i = 0; i < rows; i += 64) {
+        float d[64];
+        for (int k = 0; k < 64; k++)
+            d[k] = dot_simd_order(A + (i + k) * (cols / 2), sA + (i >> 6) * hb, x, sx, hb);
+        orc_m4_requantize64(d, r + i / 2, sr + (i >> 6), rng);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* GEMM (build-defined; see header)                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+static inline int32_t block_isum(const uint8_t *u, const uint8_t *v)
+{
+    int32_t acc = 0;
+    for (int w = 0; w < 8; w++) acc += word_isum(u + 4 * w, v + 4 * w);
+    return acc;
+}
+
+void orc_m4_gemm_isums(const uint8_t *A, uint64_t M, uint64_t K, const uint8_t *B, uint64_t N, int32_t *S)
+{
+    const uint64_t kb = K >> 6;
+    for (uint64_t i = 0; i < M; i++)
+        for (uint64_t j = 0; j < N; j++)
+            for (uint64_t b = 0; b < kb; b++)
+                S[(i * N + j) * kb + b] = block_isum(A + i * (K / 2) + 32 * b, B + j * (K / 2) + 32 * b);
+}
+
+void orc_m4_gemm(const uint8_t *A, const float *sA, uint64_t M, uint64_t K,
+                 const uint8_t *B, const float *sB, uint64_t N, float *C)
+{
+    const uint64_t kb = K >> 6;
+    for (uint64_t i = 0; i < M; i++) {
+        const float *sa = sA + (i >> 6) * kb;
+        for (uint64_t j = 0; j < N; j++) {
+            const float *sb = sB + (j >> 6) * kb;
+            float acc = 0.0f;
+            for (uint64_t b = 0; b < kb; b++) {
+                const float c = (sa[b] * RCP49) * sb[b];
+                const int32_t S = block_isum(A + i * (K / 2) + 32 * b, B + j * (K / 2) + 32 * b);
+                acc = fmaf(c, (float)S, acc);
+            }
+            C[i * N + j] = acc;
+        }
+    }
+}

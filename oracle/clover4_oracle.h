@@ -1,0 +1,86 @@
+/*
+ * clover4_oracle.h -- CPU restatement of Clover's 4-bit hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for the MI355X backend: a plain-C, scalar restatement of the arithmetic that
+ * the reference's AVX2 path performs for CloverVector4 / CloverMatrix4 (quantize, restore, dot, mvm) plus
+ * the build-defined GEMM.  It is NOT part of the product: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product path (libclover_hip.so) never links or calls it.
+ *
+ * Pinning status: the reference cannot be built in this image (include/CloverBase.h:35-36 include ipp.h
+ * and mkl.h unconditionally; neither exists here and stand-ins are not allowed), so the oracle is pinned
+ * against the known-answer vectors captured from the reference's SIMD path that SURVEY.md Appendix D
+ * records (KAT1..KAT3: quantize bytes + scales, dot bit patterns, restore bit patterns, matrix quantize +
+ * mvm bytes + scales) -- see tests/test_oracle_kat.py.  The stochastic (XORShift) stream has no captured
+ * vector: it is restated from include/simdxorshift128plus.h:97-109 and is "parity unpinned".
+ *
+ * All sizes are PADDED sizes (vector: multiple of 128 elements; matrix: rows, cols multiples of 128),
+ * exactly as the reference's containers hold them (include/CloverVector.h:86-92, CloverMatrix.h:48-53).
+ * Packing: element 2i is the HIGH nibble of byte i, element 2i+1 the LOW nibble, two's complement
+ * (include/CloverVector4.h:511-514).  Scales are the block absolute maximum (0 -> 1.0), one per 64
+ * elements (vector) or per 64x64 tile (matrix, row-major tile grid) (CloverVector4.h:661-673,
+ * CloverMatrix4.h:598-603).  Quantized nibbles are always in [-7,7]; -8 is outside the contract.
+ */
+#ifndef CLOVER4_ORACLE_H
+#define CLOVER4_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* XORShift state as the reference keeps it: 4 lanes of (s0,s1) (simdxorshift128plus.h:73-92). */
+typedef struct { uint64_t s0[4]; uint64_t s1[4]; } orc_rng;
+
+/* avx_xorshift128plus_init (simdxorshift128plus.h:47-92): lane0=(k1,k2), lanes 1..3 = 2^64-step jumps. */
+void     orc_rng_init(orc_rng *r, uint64_t key1, uint64_t key2);
+/* One avx_xorshift128plus draw (simdxorshift128plus.h:97-109): 8 x uint32, W[2k]=lo32(lane k). */
+void     orc_rng_draw(orc_rng *r, uint32_t W[8]);
+/* The 64 noises of one block (two draws), indexed [group g=0..7][lane j=0..7] (CloverVector4.h:690-734). */
+void     orc_rng_block_noise(orc_rng *r, float noise[8][8]);
+
+/* CloverVector4::quantize (CloverVector4.h:605-807). rng==NULL <=> CLOVER_STOCHASTIC_ROUNDING_DISABLED. */
+void     orc_v4_quantize(const float *x, uint64_t n_pad, uint8_t *q, float *s, orc_rng *rng);
+/* CloverVector4::restore (CloverVector4.h:1027-1093). */
+void     orc_v4_restore(const uint8_t *q, const float *s, uint64_t n_pad, float *x);
+/* CloverVector4::get (CloverVector4.h:179-188). */
+float    orc_v4_get(const uint8_t *q, const float *s, uint64_t pos);
+/* Exact per-(block, 32-bit word) integer sums I[b*8+w] (CloverVector4.h:1140-1180). */
+void     orc_v4_word_isums(const uint8_t *qu, const uint8_t *qv, uint64_t n_pad, int32_t *I);
+/* CloverVector4::dot -- SIMD lane/accumulator order (CloverVector4.h:1095-1192, CloverBase.h:149-157). */
+float    orc_v4_dot(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad);
+/* CloverVector4::dot_scalar (CloverVector4.h:555-595) -- the reference's own tolerance partner. */
+float    orc_v4_dot_scalar(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad);
+/* Order-free fp64 evaluation of the same sum (tolerance anchor for dot_fast / gemm). */
+double   orc_v4_dot_f64(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad);
+
+/* CloverMatrix4::quantize (CloverMatrix4.h:512-766). Tile order for the rng: column-block outer. */
+void     orc_m4_quantize(const float *A, uint64_t rows, uint64_t cols, uint8_t *q, float *s, orc_rng *rng);
+/* CloverMatrix4::get (CloverMatrix4.h:123-139). */
+float    orc_m4_get(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, uint64_t i, uint64_t j);
+/* fp32 row dots of mvm before the re-quantisation (CloverMatrix4.h:804-916): d[r], r=0..rows-1. */
+void     orc_m4_rowdots(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,
+                        const uint8_t *x, const float *sx, float *d);
+/* CloverMatrix4::mvm(CloverVector4, CloverVector4&) (CloverMatrix4.h:777-1083). */
+void     orc_m4_mvm(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,
+                    const uint8_t *x, const float *sx, uint8_t *r, float *sr, orc_rng *rng);
+/* Re-quantisation of 64 row dots (mvm epilogue, CloverMatrix4.h:919-1080); noise lane map 8j+g. */
+void     orc_m4_requantize64(const float d[64], uint8_t r[32], float *sr, orc_rng *rng);
+
+/*
+ * GEMM -- no reference function exists; build-defined semantics:
+ *   A is M x K, B is N x K (both CloverMatrix4 layouts), C = A * B^T, fp32, row-major M x N.
+ *   S[i][j][b] = sum over the 64 nibble products of K-block b   (exact int32)
+ *   c[b]       = f32(f32(sA[(i>>6)*(K/64)+b] * (1/49)) * sB[(j>>6)*(K/64)+b])
+ *   C[i][j]    = fold over b = 0,1,2,... of  C = fmaf(c[b], (float)S[i][j][b], C),  C0 = 0
+ * i.e. ONE sequential fma chain per output element (the MFMA-friendly order), not dot()'s 16 chains.
+ */
+void     orc_m4_gemm(const uint8_t *A, const float *sA, uint64_t M, uint64_t K,
+                     const uint8_t *B, const float *sB, uint64_t N, float *C);
+/* Exact K-block integer sums S[(i*N + j)*(K/64) + b] for small cases. */
+void     orc_m4_gemm_isums(const uint8_t *A, uint64_t M, uint64_t K, const uint8_t *B, uint64_t N, int32_t *S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
