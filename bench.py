@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: CloverMatrix4::mvm (int4 GEMV + re-quantise) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one mvm of a (N * rows_per_gpu) x cols 4-bit matrix with a 4-bit vector.  Each rank owns a
+contiguous row shard (a multiple of 64 rows) resident in HBM; N > 1 adds one RCCL all-gather of the packed
+result (nibbles + scales) per step -- the only exchange the path has.  Weak scaling: the
+per-GPU shard is fixed (default 65536 x 65536 = BASELINE.json configs[2], "C3"); --rows-per-gpu 131072
+at N=8 is exactly configs[4] ("C5", 2^20 x 2^16).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic bytes /
+HIP-event kernel time) and `cpu_baseline` (the AVX2+OpenMP restatement of the reference on the host cores,
+bounded sample, N=1 only).  Inputs are synthetic and generated on the device before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def mvm_bytes(rows: int, cols: int) -> int:
+    """Algorithmic bytes of one mvm: every operand incl. scales counted once."""
+    return rows * cols // 2 + 4 * (rows // 64) * (cols // 64) + (cols // 2 + cols // 16) + (rows // 2 + rows // 16)
+
+
+# ----------------------------------------------------------------------------------------------------
+# CPU baseline leg (runs in a child process so OpenMP binding env vars take effect)
+# ----------------------------------------------------------------------------------------------------
+def cpu_baseline_child(path: str) -> None:
+    import numpy as np
+
+    from oracle.binding import FastOracle          # test/bench infrastructure: the timed CPU port
+    d = np.load(path)
+    rows, cols = int(d["rows"]), int(d["cols"])
+    F = FastOracle()
+    best = None
+    cores = os.cpu_count() or 1
+    out = (np.zeros(rows // 2, np.uint8), np.zeros(rows // 64, np.float32))
+    for threads in sorted({1, cores}):
+        F.set_threads(threads)
+        F.m4_mvm(d["qA"], d["sA"], rows, cols, d["qx"], d["sx"], out=out)     # warm-up
+        ts = []
+        t_end = time.perf_counter() + 6.0
+        while len(ts) < 15 and (time.perf_counter() < t_end or len(ts) < 3):
+            t0 = time.perf_counter()
+            F.m4_mvm(d["qA"], d["sA"], rows, cols, d["qx"], d["sx"], out=out)
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[len(ts) // 2]
+        if best is None or med < best[0]:
+            best = (med, threads)
+    match = bool(np.array_equal(out[0], d["r"]) and np.array_equal(out[1].view(np.uint32), d["sr"].view(np.uint32)))
+    print(json.dumps({"seconds": best[0], "threads": best[1], "gpu_result_matches_cpu": match}))
+
+
+def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sample_rows: int) -> dict:
+    import numpy as np
+    sample_rows = min(sample_rows, rows_total)
+    hb = cols // 64
+    data = {
+        "rows": sample_rows, "cols": cols,
+        "qA": A[: sample_rows * cols // 2].cpu().numpy(), "sA": sA[: (sample_rows // 64) * hb].cpu().numpy(),
+        "qx": x.cpu().numpy(), "sx": sx.cpu().numpy(),
+        "r": r[: sample_rows // 2].cpu().numpy(), "sr": sr[: sample_rows // 64].cpu().numpy(),
+    }
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "sample.npz")
+        np.savez(path, **data)
+        env = dict(os.environ, OMP_PROC_BIND="true", OMP_WAIT_POLICY="active")
+        env.pop("OMP_NUM_THREADS", None)
+        out = subprocess.run([sys.executable, __file__, "--cpu-baseline-child", path], env=env, check=True,
+                             capture_output=True, text=True, timeout=600).stdout
+    res = json.loads(out.strip().splitlines()[-1])
+    nbytes = mvm_bytes(sample_rows, cols)
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": round(nbytes / res["seconds"] / 1e9, 3), "unit": "GB/s", "cores": res["threads"], "kind": "port",
+        "sample": f"mvm of the first {sample_rows} rows x {cols} cols of the same matrix ({nbytes} B), median of <=15 runs, "
+                  f"AVX2+OpenMP restatement (oracle/clover4_fast.c) on {cpu_model}, host has {os.cpu_count()} cpus",
+        "ms": round(res["seconds"] * 1e3, 3), "gpu_result_matches_cpu": res["gpu_result_matches_cpu"],
+    }
+
+
+# ----------------------------------------------------------------------------------------------------
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows-per-gpu", type=int, default=65536)
+    ap.add_argument("--cols", type=int, default=65536)
+    ap.add_argument("--cpu-sample-rows", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args.cpu_baseline_child)
+        return
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST, CloverHip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    hip = CloverHip(device=local_rank)               # raises if libclover_hip.so is missing: no fallback
+    lib = hip.lib
+    stream = torch.cuda.current_stream().cuda_stream
+
+    rows, cols = args.rows_per_gpu, args.cols
+    assert rows % 128 == 0 and cols % 128 == 0
+    rows_total = rows * world
+    hb = cols // 64
+    seed = 0xC10FE4
+
+    # ---- synthetic operands, resident in HBM (quantised domain: nibbles U[-7,7], scales U[0.5,2)) ----
+    A = torch.empty(rows * cols // 2, dtype=torch.uint8, device=dev)
+    sA = torch.empty((rows // 64) * hb, dtype=torch.float32, device=dev)
+    x = torch.empty(cols // 2, dtype=torch.uint8, device=dev)
+    sx = torch.empty(hb, dtype=torch.float32, device=dev)
+    hip.check(lib.clv_fill_random_nibbles(A.data_ptr(), A.numel(), seed, rank * rows * cols // 2, stream))
+    hip.check(lib.clv_fill_random_scales(sA.data_ptr(), sA.numel(), seed + 1, rank * (rows // 64) * hb, stream))
+    hip.check(lib.clv_fill_random_nibbles(x.data_ptr(), x.numel(), seed + 2, 0, stream))
+    hip.check(lib.clv_fill_random_scales(sx.data_ptr(), sx.numel(), seed + 3, 0, stream))
+
+    # packed result of this rank: [rows/2 nibble bytes | rows/64 fp32 scales]; gathered as one buffer
+    shard_bytes = rows // 2 + 4 * (rows // 64)
+    res = torch.empty(shard_bytes, dtype=torch.uint8, device=dev)
+    r_ptr, sr_ptr = res.data_ptr(), res.data_ptr() + rows // 2
+    gathered = torch.empty(shard_bytes * world, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i: int | None) -> None:
+        if i is not None:
+            ev[i][0].record()
+        hip.check(lib.clm4_mvm(A.data_ptr(), sA.data_ptr(), rows, cols, x.data_ptr(), sx.data_ptr(), r_ptr, sr_ptr, None, stream))
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, res)
+
+    for _ in range(args.warmup):
+        step(None)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    kt = torch.tensor([kern_avg_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+    kern_avg_ms = float(kt.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    bytes_total = mvm_bytes(rows_total, cols)
+    bytes_gpu = mvm_bytes(rows, cols)
+    value = bytes_total / (ms_per_step * 1e-3) / 1e9
+    achieved = bytes_gpu / (kern_avg_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "int4 GEMV (CloverMatrix4::mvm) effective GB/s, algorithmic operand bytes / time",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int4 x int4 -> int32 word sums, fp32 scale/accumulate (reference order)", "data": "synthetic",
+        "config": {
+            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 (BASELINE configs[2] per GPU), x and result CloverVector4, "
+                        f"STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
+            "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of packed result" if world > 1 else ""),
+            "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
+            "algorithmic_bytes_per_step": bytes_total,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "k_m4_mvm64", "kernel_avg_ms": round(kern_avg_ms, 5), "algorithmic_bytes_per_launch": bytes_gpu,
+        },
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = run_cpu_baseline(hip, A, sA, x, sx, res[: rows // 2], res[rows // 2:].view(torch.float32),
+                                                   rows_total, cols, args.cpu_sample_rows)
+        except Exception as e:                                   # the baseline must never kill the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    if world == 1 and not args.no_extras:
+        out["extras"] = extras(hip, torch, dev, stream)
+
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(hip, torch, dev, stream) -> dict:
+    """Secondary numbers of the same path (configs[1]): vector quantize + dot at n = 2^24.
+    These footprints fit the 256 MiB Infinity Cache, so they are NOT HBM-roofline claims."""
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST
+    lib = hip.lib
+    n = 1 << 24
+    xs = torch.empty(n, dtype=torch.float32, device=dev)
+    ys = torch.empty(n, dtype=torch.float32, device=dev)
+    hip.check(lib.clv_fill_random_ints_f32(xs.data_ptr(), n, 10, 11, 0, stream))
+    hip.check(lib.clv_fill_random_ints_f32(ys.data_ptr(), n, 10, 12, 0, stream))
+    qa = torch.empty(n // 2, dtype=torch.uint8, device=dev)
+    qb = torch.empty(n // 2, dtype=torch.uint8, device=dev)
+    sa = torch.empty(n // 64, dtype=torch.float32, device=dev)
+    sb = torch.empty(n // 64, dtype=torch.float32, device=dev)
+    o = torch.empty(2, dtype=torch.float32, device=dev)
+
+    def timeit(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    q_ms = timeit(lambda: hip.check(lib.clv4_quantize(xs.data_ptr(), n, qa.data_ptr(), sa.data_ptr(), None, stream)), 50)
+    hip.check(lib.clv4_quantize(ys.data_ptr(), n, qb.data_ptr(), sb.data_ptr(), None, stream))
+    f_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_FAST, o.data_ptr(), None, stream)), 50)
+    e_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_EXACT, o.data_ptr() + 4, None, stream)), 5)
+    vals = o.cpu().numpy()
+    return {
+        "note": "n=2^24 operands (76.5 MB / 18.9 MB) fit the Infinity Cache: cache-resident rates, not HBM-roofline claims",
+        "quantize_n2^24": {"ms": round(q_ms, 5), "GB/s": round(4.5625 * n / q_ms / 1e6, 1)},
+        "dot_fast_n2^24": {"ms": round(f_ms, 5), "GB/s": round(1.125 * n / f_ms / 1e6, 1), "GFLOP/s": round(2 * n / f_ms / 1e6, 1)},
+        "dot_exact_n2^24": {"ms": round(e_ms, 5), "GB/s": round(1.125 * n / e_ms / 1e6, 1),
+                            "note": "reference's 16 sequential fma chains: latency-bound by definition"},
+        "dot_fast_minus_exact_rel": float(abs(vals[0] - vals[1]) / max(abs(vals[1]), 1e-30)),
+    }
+
+
+if __name__ == "__main__":
+    main()

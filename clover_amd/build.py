@@ -1,0 +1,75 @@
+"""Build driver: compiles the HIP library (gfx950) and the CPU oracle in-tree.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only builder container; the
+resulting .so files travel to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+HIP_SOURCES = ["runtime.hip", "vector4.hip", "matrix4.hip", "rng4.hip", "gemm4.hip", "multi.hip"]
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # the reference's arithmetic is a fixed sequence of separately rounded fp32 ops + explicit fmas:
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+]
+
+
+def repo_root() -> Path:
+    return Path(__file__).resolve().parent.parent
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build libclover_hip.so)")
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps if d.exists())
+
+
+def hip_library_path() -> Path:
+    return repo_root() / "clover_amd" / "lib" / "libclover_hip.so"
+
+
+def build_hip_library(force: bool = False, verbose: bool = False) -> Path:
+    root = repo_root()
+    src_dir = root / "clover_amd" / "csrc"
+    srcs = [src_dir / s for s in HIP_SOURCES if (src_dir / s).exists()]
+    deps = srcs + list(src_dir.glob("*.h")) + [root / "include" / "clover_hip.h"]
+    out = hip_library_path()
+    out.parent.mkdir(parents=True, exist_ok=True)
+    if force or _stale(out, deps):
+        cmd = [_hipcc(), *HIP_FLAGS, f"-I{root / 'include'}", f"-I{src_dir}", "-o", str(out), *map(str, srcs)]
+        if any(s.name == "multi.hip" for s in srcs):
+            cmd += ["-L/opt/rocm/lib", "-lrccl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return out
+
+
+def build_oracle(force: bool = False) -> Path:
+    """Builds oracle/liboracle.so (+ liboracle_fast.so): test infrastructure, never loaded by the product."""
+    odir = repo_root() / "oracle"
+    if force:
+        subprocess.run(["make", "-C", str(odir), "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", str(odir), "all"], check=True, stdout=subprocess.DEVNULL)
+    return odir / "liboracle.so"
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip_library(force=force, verbose=verbose)
+    build_oracle(force=force)
+
+
+if __name__ == "__main__":
+    build_all(force=True, verbose=True)

@@ -1,0 +1,115 @@
+// common.h -- shared host/device helpers of libclover_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "clover_hip.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void clv_set_error(const char *fmt, ...);
+
+#define CLV_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            clv_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                        \
+            return CLV_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+#define CLV_REQUIRE(cond, ...)           \
+    do {                                 \
+        if (!(cond)) {                   \
+            clv_set_error(__VA_ARGS__);  \
+            return CLV_ERR_INVALID;      \
+        }                                \
+    } while (0)
+
+#define CLV_LAUNCH_CHECK()                                                             \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            clv_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__),  \
+                          __FILE__, __LINE__);                                         \
+            return CLV_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// number of compute units of the current device (cached per device)
+int clv_cu_count();
+// grow-only per-device scratch buffer used when the caller passes workspace == NULL
+int clv_internal_workspace(void **ptr, uint64_t bytes);
+
+// ---- device helpers ---------------------------------------------------------------------------
+#define CLV_RCP49 (1.0f / 49.0f)   // 0x3CA72F05, the reference's clover_mm256_rcp_49_ps (CloverBase.h:88)
+
+// v_dot8_i32_i4: sum of the 8 signed-nibble products of two dwords, plus c.  Both operands use the
+// same nibble order inside the word, so this IS the reference's per-32-bit-word integer.
+__device__ __forceinline__ int sdot8(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot8((int)a, (int)b, c, false);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int dot32(const u32x4 &a, const u32x4 &b)
+{
+    int s = sdot8(a.x, b.x, 0);
+    s = sdot8(a.y, b.y, s);
+    s = sdot8(a.z, b.z, s);
+    return sdot8(a.w, b.w, s);
+}
+
+// 0 -> 1.0 on the bit pattern (CloverVector4.h:661-663)
+__device__ __forceinline__ float fix_zero_max(float m)
+{
+    return __float_as_uint(m) == 0u ? m + 1.0f : m;
+}
+
+// one element of the quantiser: trunc(fma(|x|, k, noise)), sign of x re-applied the way
+// _mm256_sign_epi32 does (CloverVector4.h:741-772).  Returns the value in [-7,7].
+__device__ __forceinline__ int quant1(float x, float k, float noise)
+{
+    const float p = __builtin_fmaf(__builtin_fabsf(x), k, noise);
+    const int t = (int)p;                       // v_cvt_i32_f32: truncation, like cvttps
+    return __float_as_int(x) < 0 ? -t : t;      // +0.0 -> t == 0 already
+}
+
+// bit position of element e (0..7) of a little-endian 32-bit word: even elements sit in the HIGH nibble
+__device__ __forceinline__ int nib_shift(int e) { return 8 * (e >> 1) + ((e & 1) ? 0 : 4); }
+
+__device__ __forceinline__ uint32_t pack8(const int q[8])
+{
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) w |= ((uint32_t)q[e] & 0xFu) << nib_shift(e);
+    return w;
+}
+
+// signed nibble e of word w
+__device__ __forceinline__ int unpack1(uint32_t w, int e)
+{
+    return ((int)(w << (28 - nib_shift(e)))) >> 28;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// splitmix64 finaliser: counter-based generator for synthetic data
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}

@@ -1,0 +1,263 @@
+// matrix4.hip -- CloverMatrix4 hot path on gfx950: quantize (64x64 tiles) and mvm (GEMV + re-quantise).
+//
+// HBM layout = the reference's (CloverMatrix4.h:77-93, 123-139): row-major nibbles (rows*cols/2 bytes),
+// then one fp32 scale per 64x64 tile in a row-major (rows/64) x (cols/64) grid.
+#include "common.h"
+
+// ================================================================================================
+// mvm  (CloverMatrix4.h:777-1083)
+// ================================================================================================
+//
+// Bit-exactness fixes the arithmetic: every output row owns 16 sequential fp32 fma chains, chain
+// j = (32-bit word index within the row) mod 16 -- the reference's 2 accumulators x 8 AVX lanes -- and
+// a fixed add tree at the end.  Mapping used here ("chain per lane"):
+//   workgroup  = one 64-row output block (256 threads), so the re-quantise epilogue is fused;
+//   lane       = (row rho = tid>>2, quarter q = tid&3): it owns chains 4q..4q+3 of its row and walks
+//                the row 64 B (one block pair) per step, loading its 16 B with one dwordx4;
+//   x          = staged once per 65536-column chunk in LDS (32 KiB) together with the per-block factor
+//                c[b] = f32(f32(sA[b] * 1/49) * sx[b]) (4 KiB), which is identical for all 64 rows;
+//   v_dot8_i32_i4 yields the exact integer of each word, v_cvt + v_fma continue the chain.
+// Algorithmic bytes per call: rows*cols/2 + 4*(rows/64)*(cols/64) + 0.5625*(rows + cols)  (SURVEY 8(d)).
+
+#define MVM_CHUNK 65536u   // columns staged in LDS per pass
+
+template <int U>
+__device__ __forceinline__ void mvm_steps(const u32x4 *__restrict__ Ap, const u32x4 *xs, const float *cs, int q,
+                                          uint32_t t0, float &a0, float &a1, float &a2, float &a3)
+{
+    u32x4 a[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) a[u] = __builtin_nontemporal_load(&Ap[4 * (t0 + u) + q]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const u32x4 xv = xs[4 * (t0 + u) + q];
+        const float c = cs[2 * (t0 + u) + (q >> 1)];
+        a0 = __builtin_fmaf(c, (float)sdot8(a[u].x, xv.x, 0), a0);
+        a1 = __builtin_fmaf(c, (float)sdot8(a[u].y, xv.y, 0), a1);
+        a2 = __builtin_fmaf(c, (float)sdot8(a[u].z, xv.z, 0), a2);
+        a3 = __builtin_fmaf(c, (float)sdot8(a[u].w, xv.w, 0), a3);
+    }
+}
+
+// re-quantise 64 row dots held one per lane of a full wave (CloverMatrix4.h:919-1080, rounding disabled)
+__device__ __forceinline__ void requantize_wave(float d, float noise, uint32_t *r_words, float *sr)
+{
+    const int lane = threadIdx.x & 63;
+    float m = wave_max(__builtin_fabsf(d));
+    m = fix_zero_max(m);
+    const float k = 7.0f / m;
+    const int qv = quant1(d, k, noise);
+    uint32_t w = ((uint32_t)qv & 0xFu) << nib_shift(lane & 7);
+    w |= __shfl_xor(w, 1);
+    w |= __shfl_xor(w, 2);
+    w |= __shfl_xor(w, 4);
+    if ((lane & 7) == 0) r_words[lane >> 3] = w;
+    if (lane == 0) *sr = m;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A, const float *__restrict__ sA,
+                                                  uint64_t cols, const uint8_t *__restrict__ x, const float *__restrict__ sx,
+                                                  float *__restrict__ d_out, uint32_t *__restrict__ r, float *__restrict__ sr)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 *xs = reinterpret_cast<u32x4 *>(smem);                        // MVM_CHUNK/2 bytes
+    float *cs = reinterpret_cast<float *>(smem + MVM_CHUNK / 2);        // MVM_CHUNK/64 floats
+    float *dsh = cs + MVM_CHUNK / 64;                                   // 64 floats
+
+    const uint64_t rb = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int q = tid & 3;
+    const int rho = tid >> 2;
+    const uint64_t row = rb * 64 + rho;
+    const u32x4 *Arow = reinterpret_cast<const u32x4 *>(A + row * (cols / 2));
+    const float *sArow = sA + rb * (cols / 64);
+
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+
+    for (uint64_t c0 = 0; c0 < cols; c0 += MVM_CHUNK) {
+        const uint32_t cw = (uint32_t)((cols - c0) < MVM_CHUNK ? (cols - c0) : MVM_CHUNK);
+        if (c0) __syncthreads();
+        const u32x4 *xg = reinterpret_cast<const u32x4 *>(x + c0 / 2);
+        for (uint32_t i = tid; i < cw / 32; i += 256) xs[i] = xg[i];
+        for (uint32_t i = tid; i < cw / 64; i += 256) cs[i] = (sArow[c0 / 64 + i] * CLV_RCP49) * sx[c0 / 64 + i];
+        __syncthreads();
+
+        const u32x4 *Ap = Arow + c0 / 32;
+        const uint32_t npairs = cw / 128;
+        uint32_t t = 0;
+        for (; t + U <= npairs; t += U) mvm_steps<U>(Ap, xs, cs, q, t, a0, a1, a2, a3);
+        for (; t < npairs; t++) mvm_steps<1>(Ap, xs, cs, q, t, a0, a1, a2, a3);
+    }
+
+    // chain (4q+i): accumulator a = q>>1, AVX lane w = 4(q&1)+i.  Fixed tree of CloverBase.h:149-157:
+    const float v0 = a0 + __shfl_xor(a0, 2);     // acc[0][w] + acc[1][w]
+    const float v1 = a1 + __shfl_xor(a1, 2);
+    const float v2 = a2 + __shfl_xor(a2, 2);
+    const float v3 = a3 + __shfl_xor(a3, 2);
+    const float x0 = v0 + __shfl_xor(v0, 1);     // v[i+4] + v[i]
+    const float x1 = v1 + __shfl_xor(v1, 1);
+    const float x2 = v2 + __shfl_xor(v2, 1);
+    const float x3 = v3 + __shfl_xor(v3, 1);
+    const float dot = (x0 + x2) + (x1 + x3);
+
+    if (q == 0) {
+        dsh[rho] = dot;
+        if (d_out) d_out[row] = dot;
+    }
+    __syncthreads();
+    if (r && tid < 64) requantize_wave(dsh[tid], 0.0f, r + rb * 8, sr + rb);
+}
+
+// ================================================================================================
+// quantize  (CloverMatrix4.h:512-766, rounding disabled)
+// ================================================================================================
+// workgroup = one 64x64 tile (256 threads); thread = (row r = tid>>3 [+32 on the second pass],
+// octet o = tid&7) holds 8 consecutive values = one output dword.  Pass 1 reduces the tile maximum
+// (registers -> wave shuffle -> LDS); pass 2 quantises from the registers, nothing is re-read.
+__global__ __launch_bounds__(256) void k_m4_quantize(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
+                                                     float *__restrict__ s, uint32_t tiles_x)
+{
+    __shared__ float sh[4];
+    const uint32_t bj = blockIdx.x % tiles_x;
+    const uint64_t bi = blockIdx.x / tiles_x;
+    const int tid = threadIdx.x;
+    const int o = tid & 7;
+    const int r0 = tid >> 3;
+
+    float v[2][8];
+    float m = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const uint64_t row = bi * 64 + r0 + 32 * p;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(A + row * cols + bj * 64 + o * 8);
+        const f32x4 lo = __builtin_nontemporal_load(&src[0]);
+        const f32x4 hi = __builtin_nontemporal_load(&src[1]);
+        v[p][0] = lo.x; v[p][1] = lo.y; v[p][2] = lo.z; v[p][3] = lo.w;
+        v[p][4] = hi.x; v[p][5] = hi.y; v[p][6] = hi.z; v[p][7] = hi.w;
+#pragma unroll
+        for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[p][e]));
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) sh[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    m = fix_zero_max(m);
+    const float k = 7.0f / m;
+    if (tid == 0) s[bi * tiles_x + bj] = m;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        int qv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) qv[e] = quant1(v[p][e], k, 0.0f);
+        const uint64_t row = bi * 64 + r0 + 32 * p;
+        q[(row * cols + bj * 64) / 8 + o] = pack8(qv);
+    }
+}
+
+// ================================================================================================
+// GEMM, first (VALU) version: one thread per C element, exact K-block integer via 8 x v_dot8, one fma
+// chain over K-blocks.  Semantics in oracle/clover4_oracle.h; the MFMA kernel replaces this for big shapes.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_m4_gemm_simple(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t M,
+                                                        uint64_t K, const uint8_t *__restrict__ B, const float *__restrict__ sB,
+                                                        uint64_t N, float *__restrict__ C)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const uint64_t i = (uint64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= M || j >= N) return;
+    const uint64_t kb = K / 64;
+    const u32x4 *a = reinterpret_cast<const u32x4 *>(A + i * (K / 2));
+    const u32x4 *b = reinterpret_cast<const u32x4 *>(B + j * (K / 2));
+    const float *sa = sA + (i >> 6) * kb;
+    const float *sb = sB + (j >> 6) * kb;
+    float acc = 0.0f;
+    for (uint64_t blk = 0; blk < kb; blk++) {
+        const int S = dot32(a[2 * blk], b[2 * blk]) + dot32(a[2 * blk + 1], b[2 * blk + 1]);
+        const float c = (sa[blk] * CLV_RCP49) * sb[blk];
+        acc = __builtin_fmaf(c, (float)S, acc);
+    }
+    C[i * N + j] = acc;
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng, hipStream_t st);
+int clm4_requantize_stochastic(const float *d, uint64_t rows, int8_t *r, float *sr, uint64_t *rng, hipStream_t st);
+
+static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                      float *d, int8_t *r, float *sr, hipStream_t st)
+{
+    const size_t lds = MVM_CHUNK / 2 + (MVM_CHUNK / 64) * sizeof(float) + 64 * sizeof(float);
+    hipLaunchKernelGGL(k_m4_mvm64<8>, dim3((unsigned)(rows / 64)), dim3(256), lds, st, (const uint8_t *)A, sA, cols,
+                       (const uint8_t *)x, sx, d, (uint32_t *)r, sr);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+static int check_mvm_args(const char *fn, const void *A, const void *sA, uint64_t rows, uint64_t cols, const void *x, const void *sx)
+{
+    CLV_REQUIRE(A && sA && x && sx, "%s: null pointer", fn);
+    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "%s: rows=%llu cols=%llu must be multiples of 128", fn,
+                (unsigned long long)rows, (unsigned long long)cols);
+    CLV_REQUIRE(rows / 64 <= 0x7FFFFFFFull, "%s: too many rows", fn);
+    return CLV_OK;
+}
+
+extern "C" int clm4_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                        int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream)
+{
+    int rc = check_mvm_args("clm4_mvm", A, sA, rows, cols, x, sx);
+    if (rc) return rc;
+    CLV_REQUIRE(r && sr, "clm4_mvm: null result pointer");
+    if (!rows) return CLV_OK;
+    hipStream_t st = as_stream(stream);
+    if (!rng_state_dev) return launch_mvm(A, sA, rows, cols, x, sx, nullptr, r, sr, st);
+    // stochastic: fp32 row dots to scratch, then the re-quantiser that walks the XORShift stream
+    void *ws = nullptr;
+    // row dots at the front, the XORShift prefix data (see rng4.hip) behind them
+    rc = clv_internal_workspace(&ws, ((rows * sizeof(float) + 255) & ~255ull) + ((rows / 64) * 4 + 8) * sizeof(uint64_t));
+    if (rc) return rc;
+    rc = launch_mvm(A, sA, rows, cols, x, sx, (float *)ws, nullptr, nullptr, st);
+    if (rc) return rc;
+    return clm4_requantize_stochastic((const float *)ws, rows, r, sr, rng_state_dev, st);
+}
+
+extern "C" int clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                            float *d, void *stream)
+{
+    int rc = check_mvm_args("clm4_rowdots", A, sA, rows, cols, x, sx);
+    if (rc) return rc;
+    CLV_REQUIRE(d, "clm4_rowdots: null result pointer");
+    if (!rows) return CLV_OK;
+    return launch_mvm(A, sA, rows, cols, x, sx, d, nullptr, nullptr, as_stream(stream));
+}
+
+extern "C" int clm4_quantize(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream)
+{
+    CLV_REQUIRE(A && q && s, "clm4_quantize: null pointer");
+    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "clm4_quantize: rows=%llu cols=%llu must be multiples of 128",
+                (unsigned long long)rows, (unsigned long long)cols);
+    if (!rows || !cols) return CLV_OK;
+    const uint64_t tiles = (rows / 64) * (cols / 64);
+    CLV_REQUIRE(tiles <= 0x7FFFFFFFull, "clm4_quantize: too many tiles");
+    if (rng_state_dev) return clm4_quantize_stochastic(A, rows, cols, q, s, rng_state_dev, as_stream(stream));
+    hipLaunchKernelGGL(k_m4_quantize, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), A, cols, (uint32_t *)q, s,
+                       (uint32_t)(cols / 64));
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K, const int8_t *B, const float *sB, uint64_t N,
+                         float *C, void *stream)
+{
+    CLV_REQUIRE(A && sA && B && sB && C, "clm4_gemm: null pointer");
+    CLV_REQUIRE(M % 128 == 0 && N % 128 == 0 && K % 128 == 0, "clm4_gemm: M=%llu N=%llu K=%llu must be multiples of 128",
+                (unsigned long long)M, (unsigned long long)N, (unsigned long long)K);
+    if (!M || !N) return CLV_OK;
+    hipLaunchKernelGGL(k_m4_gemm_simple, dim3((unsigned)(N / 16), (unsigned)(M / 16)), dim3(256), 0, as_stream(stream),
+                       (const uint8_t *)A, sA, M, K, (const uint8_t *)B, sB, N, C);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}

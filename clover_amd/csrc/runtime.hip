@@ -1,0 +1,292 @@
+// runtime.hip -- device/stream/memory plumbing, XORShift key handling and synthetic-data fills.
+#include "common.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+
+// ---- errors -----------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void clv_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *clv_last_error(void) { return g_err; }
+extern "C" const char *clv_version(void) { return "clover_hip 0.1 (gfx950)"; }
+
+// ---- devices ----------------------------------------------------------------------------------
+extern "C" int clv_device_count(int *count)
+{
+    CLV_REQUIRE(count, "clv_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *count = n;
+    return CLV_OK;
+}
+
+extern "C" int clv_set_device(int device) { CLV_HIP(hipSetDevice(device)); return CLV_OK; }
+extern "C" int clv_get_device(int *device)
+{
+    CLV_REQUIRE(device, "clv_get_device: null argument");
+    CLV_HIP(hipGetDevice(device));
+    return CLV_OK;
+}
+
+extern "C" int clv_device_info(char *name, int name_len, int *compute_units, uint64_t *hbm_bytes)
+{
+    int dev = 0;
+    CLV_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    CLV_HIP(hipGetDeviceProperties(&p, dev));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    return CLV_OK;
+}
+
+#define CLV_MAX_DEVICES 64
+static int g_cu[CLV_MAX_DEVICES];
+
+int clv_cu_count()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CLV_MAX_DEVICES) return 256;
+    if (g_cu[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cu[dev] = n;
+    }
+    return g_cu[dev];
+}
+
+// grow-only scratch per device; used only when a caller passes workspace == NULL
+static std::mutex g_ws_mutex;
+static void *g_ws_ptr[CLV_MAX_DEVICES];
+static uint64_t g_ws_bytes[CLV_MAX_DEVICES];
+
+int clv_internal_workspace(void **ptr, uint64_t bytes)
+{
+    int dev = 0;
+    CLV_HIP(hipGetDevice(&dev));
+    CLV_REQUIRE(dev >= 0 && dev < CLV_MAX_DEVICES, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (g_ws_bytes[dev] < bytes) {
+        if (g_ws_ptr[dev]) {
+            CLV_HIP(hipDeviceSynchronize());
+            CLV_HIP(hipFree(g_ws_ptr[dev]));
+            g_ws_ptr[dev] = nullptr;
+            g_ws_bytes[dev] = 0;
+        }
+        uint64_t want = bytes < (1ull << 20) ? (1ull << 20) : bytes;
+        CLV_HIP(hipMalloc(&g_ws_ptr[dev], want));
+        g_ws_bytes[dev] = want;
+    }
+    *ptr = g_ws_ptr[dev];
+    return CLV_OK;
+}
+
+// ---- memory / streams / events ------------------------------------------------------------------
+extern "C" int clv_malloc(void **ptr, uint64_t bytes)
+{
+    CLV_REQUIRE(ptr, "clv_malloc: null argument");
+    CLV_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    return CLV_OK;
+}
+extern "C" int clv_free(void *ptr) { if (ptr) CLV_HIP(hipFree(ptr)); return CLV_OK; }
+extern "C" int clv_memset(void *ptr, int value, uint64_t bytes, void *stream)
+{
+    CLV_HIP(hipMemsetAsync(ptr, value, bytes, as_stream(stream)));
+    return CLV_OK;
+}
+extern "C" int clv_memcpy_h2d(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    CLV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return CLV_OK;
+}
+extern "C" int clv_memcpy_d2h(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    CLV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    CLV_HIP(hipStreamSynchronize(as_stream(stream)));
+    return CLV_OK;
+}
+extern "C" int clv_memcpy_d2d(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    CLV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return CLV_OK;
+}
+extern "C" int clv_host_alloc(void **ptr, uint64_t bytes)
+{
+    CLV_REQUIRE(ptr, "clv_host_alloc: null argument");
+    CLV_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return CLV_OK;
+}
+extern "C" int clv_host_free(void *ptr) { if (ptr) CLV_HIP(hipHostFree(ptr)); return CLV_OK; }
+
+extern "C" int clv_stream_create(void **stream)
+{
+    CLV_REQUIRE(stream, "clv_stream_create: null argument");
+    hipStream_t s;
+    CLV_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return CLV_OK;
+}
+extern "C" int clv_stream_destroy(void *stream) { CLV_HIP(hipStreamDestroy(as_stream(stream))); return CLV_OK; }
+extern "C" int clv_stream_sync(void *stream) { CLV_HIP(hipStreamSynchronize(as_stream(stream))); return CLV_OK; }
+extern "C" int clv_device_sync(void) { CLV_HIP(hipDeviceSynchronize()); return CLV_OK; }
+
+extern "C" int clv_event_create(void **event)
+{
+    CLV_REQUIRE(event, "clv_event_create: null argument");
+    hipEvent_t e;
+    CLV_HIP(hipEventCreate(&e));
+    *event = e;
+    return CLV_OK;
+}
+extern "C" int clv_event_destroy(void *event) { CLV_HIP(hipEventDestroy((hipEvent_t)event)); return CLV_OK; }
+extern "C" int clv_event_record(void *event, void *stream)
+{
+    CLV_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+    return CLV_OK;
+}
+extern "C" int clv_event_sync(void *event) { CLV_HIP(hipEventSynchronize((hipEvent_t)event)); return CLV_OK; }
+extern "C" int clv_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    CLV_REQUIRE(ms, "clv_event_elapsed_ms: null argument");
+    CLV_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return CLV_OK;
+}
+
+// ---- XORShift keys ------------------------------------------------------------------------------
+// Lane 0 is the seed pair; lanes 1..3 are successive 2^64-step jumps of the canonical xorshift128+
+// (reference include/simdxorshift128plus.h:38-92).
+static void canon_step(uint64_t &a, uint64_t &b)
+{
+    uint64_t s1 = a;
+    const uint64_t s0 = b;
+    a = s0;
+    s1 ^= s1 << 23;
+    b = s1 ^ s0 ^ (s1 >> 18) ^ (s0 >> 5);
+}
+
+static void canon_jump(uint64_t in0, uint64_t in1, uint64_t &out0, uint64_t &out1)
+{
+    static const uint64_t poly[2] = {0x8a5cd789635d2dffull, 0x121fd2155c472f96ull};
+    uint64_t a = 0, b = 0;
+    for (int i = 0; i < 2; i++)
+        for (int bit = 0; bit < 64; bit++) {
+            if (poly[i] & (1ull << bit)) { a ^= in0; b ^= in1; }
+            canon_step(in0, in1);
+        }
+    out0 = a;
+    out1 = b;
+}
+
+extern "C" int clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const uint64_t key2[4], void *stream)
+{
+    CLV_REQUIRE(state_dev && key1 && key2, "clv_rng_set: null argument");
+    uint64_t st[8];
+    memcpy(st, key1, 32);
+    memcpy(st + 4, key2, 32);
+    CLV_HIP(hipMemcpyAsync(state_dev, st, sizeof st, hipMemcpyHostToDevice, as_stream(stream)));
+    CLV_HIP(hipStreamSynchronize(as_stream(stream)));   // st is a stack buffer
+    return CLV_OK;
+}
+
+extern "C" int clv_rng_seed(uint64_t *state_dev, uint64_t key1, uint64_t key2, void *stream)
+{
+    uint64_t s0[4], s1[4];
+    s0[0] = key1;
+    s1[0] = key2;
+    for (int l = 1; l < 4; l++) canon_jump(s0[l - 1], s1[l - 1], s0[l], s1[l]);
+    return clv_rng_set(state_dev, s0, s1, stream);
+}
+
+extern "C" int clv_rng_get(const uint64_t *state_dev, uint64_t key1[4], uint64_t key2[4], void *stream)
+{
+    CLV_REQUIRE(state_dev && key1 && key2, "clv_rng_get: null argument");
+    uint64_t st[8];
+    CLV_HIP(hipMemcpyAsync(st, state_dev, sizeof st, hipMemcpyDeviceToHost, as_stream(stream)));
+    CLV_HIP(hipStreamSynchronize(as_stream(stream)));
+    memcpy(key1, st, 32);
+    memcpy(key2, st + 4, 32);
+    return CLV_OK;
+}
+
+// ---- synthetic data -----------------------------------------------------------------------------
+// one dword (8 nibbles) per splitmix64 draw; nibble = (byte * 15 >> 8) - 7, uniform on [-7,7]
+__global__ void k_fill_nibbles(uint32_t *q, uint64_t nwords, uint64_t seed, uint64_t word_offset)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint64_t r = splitmix64(seed ^ ((i + word_offset) * 0xD6E8FEB86659FD93ull));
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int v = (int)((((r >> (8 * e)) & 0xFF) * 15) >> 8) - 7;
+            w |= ((uint32_t)v & 0xFu) << (4 * e);
+        }
+        q[i] = w;
+    }
+}
+
+__global__ void k_fill_scales(float *s, uint64_t n, uint64_t seed, uint64_t offset)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = splitmix64(seed ^ ((i + offset) * 0xA24BAED4963EE407ull));
+        // [0.5, 2): 0.5 + 1.5 * u, u a 24-bit fraction
+        s[i] = 0.5f + 1.5f * ((float)(r >> 40) * (1.0f / 16777216.0f));
+    }
+}
+
+__global__ void k_fill_ints_f32(float *x, uint64_t n, int range, uint64_t seed, uint64_t offset)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t span = 2ull * (uint64_t)range + 1ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = splitmix64(seed ^ ((i + offset) * 0x9FB21C651E98DF25ull));
+        x[i] = (float)((int)(((r >> 32) * span) >> 32) - range);
+    }
+}
+
+static inline int fill_grid(uint64_t n)
+{
+    const uint64_t want = (n + 255) / 256;
+    const uint64_t cap = (uint64_t)clv_cu_count() * 16;
+    return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+extern "C" int clv_fill_random_nibbles(int8_t *q, uint64_t bytes, uint64_t seed, uint64_t byte_offset, void *stream)
+{
+    CLV_REQUIRE(q && (bytes % 4 == 0) && (byte_offset % 4 == 0), "clv_fill_random_nibbles: size/offset must be multiples of 4");
+    if (!bytes) return CLV_OK;
+    hipLaunchKernelGGL(k_fill_nibbles, dim3(fill_grid(bytes / 4)), dim3(256), 0, as_stream(stream),
+                       (uint32_t *)q, bytes / 4, seed, byte_offset / 4);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clv_fill_random_scales(float *s, uint64_t count, uint64_t seed, uint64_t index_offset, void *stream)
+{
+    CLV_REQUIRE(s, "clv_fill_random_scales: null argument");
+    if (!count) return CLV_OK;
+    hipLaunchKernelGGL(k_fill_scales, dim3(fill_grid(count)), dim3(256), 0, as_stream(stream), s, count, seed, index_offset);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clv_fill_random_ints_f32(float *x, uint64_t count, int range, uint64_t seed, uint64_t index_offset, void *stream)
+{
+    CLV_REQUIRE(x && range >= 0, "clv_fill_random_ints_f32: bad argument");
+    if (!count) return CLV_OK;
+    hipLaunchKernelGGL(k_fill_ints_f32, dim3(fill_grid(count)), dim3(256), 0, as_stream(stream), x, count, range, seed, index_offset);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}

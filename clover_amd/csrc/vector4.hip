@@ -1,0 +1,246 @@
+// vector4.hip -- CloverVector4 hot path on gfx950: quantize, restore, dot (exact order / fast), word sums.
+//
+// Data layout in HBM = the reference's (CloverVector4.h:68-103): n_pad/2 value bytes (element 2i in the
+// high nibble of byte i), one fp32 scale per 64 elements.  One output dword = 8 consecutive elements,
+// so the natural unit of work is "lane = 8 elements": 8 lanes form a 64-element block and the block
+// maximum is a 3-step xor-shuffle inside that 8-lane group; nothing goes through LDS.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// quantize (rounding disabled): CloverVector4.h:605-807 with rnd_* == 0
+//   per lane: 32 B in (2 x dwordx4), 4 B out; per wave: 2 KiB in, 256 B + 8 scales out.
+//   algorithmic bytes: 4.5625 per element.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x, uint32_t *__restrict__ q,
+                                                     float *__restrict__ s, uint64_t nwords)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const f32x4 a = __builtin_nontemporal_load(&x[2 * i]);
+        const f32x4 b = __builtin_nontemporal_load(&x[2 * i + 1]);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float m = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        m = fmaxf(m, __shfl_xor(m, 4));
+        m = fix_zero_max(m);
+        const float k = 7.0f / m;                 // IEEE-correct fp32 division (CloverVector4.h:668)
+        int qv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) qv[e] = quant1(v[e], k, 0.0f);
+        q[i] = pack8(qv);
+        if ((i & 7) == 0) s[i >> 3] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// restore: CloverVector4.h:1027-1093.  x = (scale / 7.0f) * q  (division first, then one multiply)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_v4_restore(const uint32_t *__restrict__ q, const float *__restrict__ s,
+                                                    f32x4 *__restrict__ x, uint64_t nwords)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint32_t w = q[i];
+        const float sc = s[i >> 3] / 7.0f;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (float)unpack1(w, e) * sc;
+        x[2 * i]     = f32x4{v[0], v[1], v[2], v[3]};
+        x[2 * i + 1] = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact integer word sums: I[w] = sum of the 8 nibble products of word w
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_v4_word_isums(const uint32_t *__restrict__ qu, const uint32_t *__restrict__ qv,
+                                                       int32_t *__restrict__ I, uint64_t nwords)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride)
+        I[i] = sdot8(qu[i], qv[i], 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dot, reference order (CloverVector4.h:1095-1192): 16 sequential fp32 fma chains -- chain
+// j = word index mod 16 (accumulator = bit 3, AVX lane = bits 0..2) -- then the fixed add tree of
+// CloverBase.h:149-157.  The chains are sequential by definition, so this is ONE wave and
+// latency-bound (~4 cycles per block pair); it exists for parity and for short vectors.
+//   lane = (sub, j): sub = lane>>4 prepares block pair 4g+sub; chain lanes (sub==0) fold 4 pairs per step.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_v4_dot_exact(const uint32_t *__restrict__ qu, const float *__restrict__ su,
+                                                     const uint32_t *__restrict__ qv, const float *__restrict__ sv,
+                                                     uint64_t npairs, float *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int j = lane & 15;
+    const int sub = lane >> 4;
+    float acc = 0.0f;
+    const uint64_t full = npairs & ~(uint64_t)3;
+#pragma unroll 4
+    for (uint64_t g = 0; g < full; g += 4) {
+        const uint64_t p = g + sub;
+        const uint64_t blk = 2 * p + (j >> 3);
+        const float c = (su[blk] * CLV_RCP49) * sv[blk];
+        const float f = (float)sdot8(qu[16 * p + j], qv[16 * p + j], 0);
+        const float c1 = __shfl(c, j + 16), f1 = __shfl(f, j + 16);
+        const float c2 = __shfl(c, j + 32), f2 = __shfl(f, j + 32);
+        const float c3 = __shfl(c, j + 48), f3 = __shfl(f, j + 48);
+        acc = __builtin_fmaf(c, f, acc);      // meaningful on sub == 0 lanes only
+        acc = __builtin_fmaf(c1, f1, acc);
+        acc = __builtin_fmaf(c2, f2, acc);
+        acc = __builtin_fmaf(c3, f3, acc);
+    }
+    for (uint64_t p = full; p < npairs; p++) {   // 0..3 leftover pairs, every lane walks them
+        const uint64_t blk = 2 * p + (j >> 3);
+        const float c = (su[blk] * CLV_RCP49) * sv[blk];
+        const float f = (float)sdot8(qu[16 * p + j], qv[16 * p + j], 0);
+        acc = __builtin_fmaf(c, f, acc);
+    }
+    // lanes 0..15 hold chain j: accumulator a = j>>3, AVX lane w = j&7
+    const float v = acc + __shfl(acc, (j + 8) & 15);   // acc[0][w] + acc[1][w]          (:1190)
+    const float x = __shfl(v, (j + 4) & 15) + v;       // x[w] = v[w+4] + v[w], w = 0..3  (CloverBase.h:153)
+    const float x2 = __shfl(x, (j + 2) & 15);
+    const float y = x + x2;                            // y0 = x0 + x2 (lane 0), y1 = x1 + x3 (lane 1)
+    const float y1 = __shfl(y, 1);
+    if (lane == 0) *out = y + y1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dot, fast order: exact integer block sums, per-block scale, fp32 partials reduced by a fixed tree.
+//   lane = 16 B of each operand (half a block); lane pairs combine their integer sums first, so each
+//   block contributes exactly c[b] * I[b] like the reference; only the fp32 summation ORDER differs.
+//   algorithmic bytes: 1.125 per element.
+// ------------------------------------------------------------------------------------------------
+#define DOT_FAST_THREADS 256
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(DOT_FAST_THREADS) void k_v4_dot_partial(const u32x4 *__restrict__ qu, const float *__restrict__ su,
+                                                                     const u32x4 *__restrict__ qv, const float *__restrict__ sv,
+                                                                     uint64_t nvec, float *__restrict__ partial)
+{
+    __shared__ float sh[4];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    float acc = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const u32x4 a = __builtin_nontemporal_load(&qu[i]);
+        const u32x4 b = __builtin_nontemporal_load(&qv[i]);
+        int I = dot32(a, b);
+        I += __shfl_xor(I, 1);
+        if ((i & 1) == 0) {
+            const uint64_t blk = i >> 1;
+            const float c = (su[blk] * CLV_RCP49) * sv[blk];
+            acc = __builtin_fmaf(c, (float)I, acc);
+        }
+    }
+    const float t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(DOT_FAST_THREADS) void k_v4_dot_final(const float *__restrict__ partial, int count, float *__restrict__ out)
+{
+    __shared__ float sh[4];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < count; i += DOT_FAST_THREADS) acc += partial[i];
+    const float t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) *out = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static inline int stream_grid(uint64_t items, int threads, int per_cu)
+{
+    const uint64_t want = (items + threads - 1) / threads;
+    const uint64_t cap = (uint64_t)clv_cu_count() * per_cu;
+    return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, hipStream_t st);
+
+extern "C" int clv4_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream)
+{
+    CLV_REQUIRE(x && q && s, "clv4_quantize: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv4_quantize: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    if (!n_pad) return CLV_OK;
+    if (rng_state_dev) return clv4_quantize_stochastic(x, n_pad, q, s, rng_state_dev, as_stream(stream));
+    const uint64_t nwords = n_pad / 8;
+    hipLaunchKernelGGL(k_v4_quantize, dim3(stream_grid(nwords, 256, 8)), dim3(256), 0, as_stream(stream),
+                       (const f32x4 *)x, (uint32_t *)q, s, nwords);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clv4_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, void *stream)
+{
+    CLV_REQUIRE(x && q && s, "clv4_restore: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv4_restore: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    if (!n_pad) return CLV_OK;
+    const uint64_t nwords = n_pad / 8;
+    hipLaunchKernelGGL(k_v4_restore, dim3(stream_grid(nwords, 256, 8)), dim3(256), 0, as_stream(stream),
+                       (const uint32_t *)q, s, (f32x4 *)x, nwords);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clv4_word_isums(const int8_t *qu, const int8_t *qv, uint64_t n_pad, int32_t *isums, void *stream)
+{
+    CLV_REQUIRE(qu && qv && isums, "clv4_word_isums: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv4_word_isums: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    if (!n_pad) return CLV_OK;
+    const uint64_t nwords = n_pad / 8;
+    hipLaunchKernelGGL(k_v4_word_isums, dim3(stream_grid(nwords, 256, 8)), dim3(256), 0, as_stream(stream),
+                       (const uint32_t *)qu, (const uint32_t *)qv, isums, nwords);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+static inline int dot_fast_grid(uint64_t n_pad)
+{
+    return stream_grid(n_pad / 32, DOT_FAST_THREADS, 4);
+}
+
+extern "C" uint64_t clv4_dot_workspace_bytes(uint64_t n_pad)
+{
+    (void)n_pad;
+    return (uint64_t)clv_cu_count() * 4 * sizeof(float) + 256;
+}
+
+extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad,
+                        int mode, float *out_dev, void *workspace, void *stream)
+{
+    CLV_REQUIRE(qu && su && qv && sv && out_dev, "clv4_dot: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv4_dot: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    CLV_REQUIRE(mode == CLV_DOT_EXACT || mode == CLV_DOT_FAST, "clv4_dot: unknown mode %d", mode);
+    hipStream_t st = as_stream(stream);
+    if (!n_pad) { CLV_HIP(hipMemsetAsync(out_dev, 0, sizeof(float), st)); return CLV_OK; }
+    if (mode == CLV_DOT_EXACT) {
+        hipLaunchKernelGGL(k_v4_dot_exact, dim3(1), dim3(64), 0, st, (const uint32_t *)qu, su, (const uint32_t *)qv, sv,
+                           n_pad / 128, out_dev);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
+    if (!workspace) {
+        int rc = clv_internal_workspace(&workspace, clv4_dot_workspace_bytes(n_pad));
+        if (rc) return rc;
+    }
+    const int grid = dot_fast_grid(n_pad);
+    hipLaunchKernelGGL(k_v4_dot_partial, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv,
+                       n_pad / 32, (float *)workspace);
+    CLV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_v4_dot_final, dim3(1), dim3(DOT_FAST_THREADS), 0, st, (const float *)workspace, grid, out_dev);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}

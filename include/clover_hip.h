@@ -1,0 +1,129 @@
+/*
+ * clover_hip.h -- C ABI of libclover_hip.so: the MI355X (gfx950) backend for Clover's 4-bit hot path.
+ *
+ * This is the drop-in boundary.  Clover itself has no FFI/plugin interface: its API is the public method
+ * surface of the header-only classes CloverVector4 / CloverMatrix4 (reference README.md:68, 117-128).
+ * Each entry point below replaces the BODY of one of those methods; the reference-side binding a
+ * maintainer would add is shown in INTEGRATION.md, and include/CloverVector4.h / include/CloverMatrix4.h
+ * in this repository are C++ containers with the reference's class and method names built on this ABI.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types.  Every data pointer is a DEVICE pointer (HBM) unless the name says
+ *    `host`; `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - sizes are the PADDED sizes the reference containers hold: vector length_pad (multiple of 128,
+ *    CloverVector.h:86-92), matrix rows/cols (multiples of 128, CloverMatrix.h:48-53).
+ *  - data format = the reference's: byte i holds element 2i in its HIGH nibble and 2i+1 in its LOW nibble,
+ *    two's complement, values in [-7,7] (CloverVector4.h:511-514); one fp32 scale (the block's absolute
+ *    maximum, 0 -> 1.0) per 64 elements (CloverVector4.h:661-673) / per 64x64 tile, row-major tile grid
+ *    (CloverMatrix4.h:123-139, 598-603).  Matrices are row-major nibbles, exactly as the reference
+ *    stores them.
+ *  - every function returns CLV_OK (0) or a negative CLV_ERR_* code and never calls exit(); the C++
+ *    container layer turns a non-zero status into the reference's behaviour (message + exit(1)).
+ *    clv_last_error() returns a thread-local description of the last failure.
+ *  - results: bit-identical to the reference's AVX2 path when stochastic rounding is disabled
+ *    (rng == NULL); with an rng state the same XORShift stream as the reference's sequential methods is
+ *    consumed (bit-identical nibbles for identical keys).  Exceptions are spelled out per function.
+ */
+#ifndef CLOVER_HIP_H
+#define CLOVER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLV_OK                 0
+#define CLV_ERR_INVALID       -1   /* bad size / null pointer / unsupported mode */
+#define CLV_ERR_HIP           -2   /* a HIP runtime call failed (see clv_last_error) */
+#define CLV_ERR_NO_DEVICE     -3   /* no gfx950 device visible */
+#define CLV_ERR_UNSUPPORTED   -4
+
+/* dot() evaluation order */
+#define CLV_DOT_EXACT          0   /* the reference's 16 sequential fma chains: bit-identical, latency-bound */
+#define CLV_DOT_FAST           1   /* exact integer block sums, fp32 tree reduction: bandwidth-bound */
+
+/* ---- runtime ---------------------------------------------------------------------------------- */
+const char *clv_version(void);
+const char *clv_last_error(void);
+int  clv_device_count(int *count);
+int  clv_set_device(int device);
+int  clv_get_device(int *device);
+/* name, compute units, HBM bytes of the current device (any pointer may be NULL) */
+int  clv_device_info(char *name, int name_len, int *compute_units, uint64_t *hbm_bytes);
+
+int  clv_malloc(void **ptr, uint64_t bytes);
+int  clv_free(void *ptr);
+int  clv_memset(void *ptr, int value, uint64_t bytes, void *stream);
+int  clv_memcpy_h2d(void *dst_dev, const void *src_host, uint64_t bytes, void *stream);
+int  clv_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t bytes, void *stream);
+int  clv_memcpy_d2d(void *dst_dev, const void *src_dev, uint64_t bytes, void *stream);
+int  clv_host_alloc(void **ptr, uint64_t bytes);          /* pinned, page-aligned host memory */
+int  clv_host_free(void *ptr);
+int  clv_stream_create(void **stream);
+int  clv_stream_destroy(void *stream);
+int  clv_stream_sync(void *stream);
+int  clv_device_sync(void);
+int  clv_event_create(void **event);
+int  clv_event_destroy(void *event);
+int  clv_event_record(void *event, void *stream);
+int  clv_event_sync(void *event);
+int  clv_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ---- XORShift state (CloverRandom.h:90-114, simdxorshift128plus.h:47-109) ------------------------ */
+/* The generator state lives in device memory: 8 x uint64 = s0[4], s1[4] (random_key1, random_key2).
+ * clv_rng_seed() reproduces avx_xorshift128plus_init(key1, key2) on the host and uploads it;
+ * clv_rng_set() uploads explicit keys (CloverRandom::setRandomKeys). */
+#define CLV_RNG_STATE_BYTES 64
+int  clv_rng_seed(uint64_t *state_dev, uint64_t key1, uint64_t key2, void *stream);
+int  clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const uint64_t key2[4], void *stream);
+int  clv_rng_get(const uint64_t *state_dev, uint64_t key1[4], uint64_t key2[4], void *stream); /* syncs */
+
+/* ---- CloverVector4 ---------------------------------------------------------------------------- */
+/* CloverVector4::quantize (CloverVector4.h:605-807).  x: n_pad floats; q: n_pad/2 bytes; s: n_pad/64
+ * floats.  rng_state_dev == NULL <=> CLOVER_STOCHASTIC_ROUNDING_DISABLED; otherwise two draws per block
+ * are consumed in block order and the state is advanced in place, as the sequential method does. */
+int  clv4_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream);
+/* CloverVector4::restore (CloverVector4.h:1027-1093). */
+int  clv4_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, void *stream);
+/* CloverVector4::dot (CloverVector4.h:1095-1192).  *out_dev receives one float.  CLV_DOT_EXACT is
+ * bit-identical to the reference; CLV_DOT_FAST differs only in fp32 summation order (the per-block
+ * integer sums are exact either way).  workspace: clv4_dot_workspace_bytes() bytes or NULL (internal). */
+uint64_t clv4_dot_workspace_bytes(uint64_t n_pad);
+int  clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad,
+              int mode, float *out_dev, void *workspace, void *stream);
+/* exact int32 sum of the 8 nibble products of every 32-bit word: I[n_pad/8] */
+int  clv4_word_isums(const int8_t *qu, const int8_t *qv, uint64_t n_pad, int32_t *isums, void *stream);
+
+/* ---- CloverMatrix4 ---------------------------------------------------------------------------- */
+/* CloverMatrix4::quantize (CloverMatrix4.h:512-766).  A: rows*cols floats row-major; q: rows*cols/2
+ * bytes; s: (rows/64)*(cols/64) floats.  With an rng the tiles consume the stream in the reference's
+ * order (column-block outer, row-block inner, two draws per tile row). */
+int  clm4_quantize(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s,
+                   uint64_t *rng_state_dev, void *stream);
+/* CloverMatrix4::mvm(const CloverVector4&, CloverVector4&) (CloverMatrix4.h:777-1083) and mvm_parallel
+ * (:1681-2006; same results).  x: cols/2 bytes + cols/64 scales; r: rows/2 bytes + rows/64 scales
+ * (the re-quantised result).  Bit-identical to the reference when rng_state_dev == NULL. */
+int  clm4_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols,
+              const int8_t *x, const float *sx, int8_t *r, float *sr,
+              uint64_t *rng_state_dev, void *stream);
+/* the fp32 row dots of mvm before re-quantisation: d[rows] (CloverMatrix4.h:804-916) */
+int  clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols,
+                  const int8_t *x, const float *sx, float *d, void *stream);
+/* GEMM, build-defined (the reference has none; semantics in oracle/clover4_oracle.h and DESIGN.md):
+ * A is M x K, B is N x K, C = A * B^T as fp32 M x N row-major, one fma chain over K-blocks per element. */
+int  clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K,
+               const int8_t *B, const float *sB, uint64_t N, float *C, void *stream);
+
+/* ---- synthetic data (bench / tests): fills device buffers without an fp32 source ------------------ */
+/* nibbles uniform in [-7,7], scales uniform in [0.5,2): counter-based splitmix64 of (seed, index), so any
+ * row range of a sharded matrix regenerates independently. */
+int  clv_fill_random_nibbles(int8_t *q, uint64_t bytes, uint64_t seed, uint64_t byte_offset, void *stream);
+int  clv_fill_random_scales(float *s, uint64_t count, uint64_t seed, uint64_t index_offset, void *stream);
+/* fp32 integers uniform in [-range, range] (the reference's setRandomInteger(10) data, 01_measure.h:797) */
+int  clv_fill_random_ints_f32(float *x, uint64_t count, int range, uint64_t seed, uint64_t index_offset, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

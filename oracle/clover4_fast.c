@@ -1,0 +1,164 @@
+/*
+ * clover4_fast.c -- AVX2 + OpenMP restatement of the 4-bit hot path: the timed CPU baseline ("port").
+ * TEST / BENCH INFRASTRUCTURE ONLY -- never linked into libclover_hip.so.
+ *
+ * Same results, bit for bit, as the scalar oracle (clover4_oracle.c) and therefore as the reference's
+ * AVX2 path (rounding disabled); tests/test_oracle_fast.py asserts that.  It plays the role of
+ * "Clover's own AVX2 path on the host cores" next to the GPU numbers, because the reference sources
+ * can neither be built in this image (IPP/MKL headers) nor travel to the GPU box.
+ *
+ * Parallel decomposition mirrors the reference's OpenMP variants: mvm splits 64-row blocks contiguously
+ * over threads (CloverMatrix4.h:1700-1705), quantize splits 64-element blocks (CloverVector4.h:818-828);
+ * dot stays sequential because its fp32 order is part of the result (dot_parallel is not reproducible).
+ *
+ * The nibble arithmetic is written independently of the reference: nibbles are sign-extended into four
+ * int16 "planes" with shifts and multiplied with vpmaddwd, which yields the exact per-32-bit-word integer
+ * directly (the reference reaches the same integer through vpsignb/vpmaddubsw on 16x-scaled bytes).
+ */
+#include <immintrin.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static const float RCP49 = 1.0f / 49.0f;
+
+int orcf_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orcf_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* exact int32 sums of the 8 nibble products of each of the 8 words of a 32-byte block */
+static inline __m256i block_word_isums(__m256i u, __m256i v)
+{
+    /* a 16-bit lane holds 4 nibbles: bits 12-15, 8-11, 4-7, 0-3; plane k = sign-extended nibble k */
+    const __m256i u3 = _mm256_srai_epi16(u, 12);
+    const __m256i v3 = _mm256_srai_epi16(v, 12);
+    const __m256i u2 = _mm256_srai_epi16(_mm256_slli_epi16(u, 4), 12);
+    const __m256i v2 = _mm256_srai_epi16(_mm256_slli_epi16(v, 4), 12);
+    const __m256i u1 = _mm256_srai_epi16(_mm256_slli_epi16(u, 8), 12);
+    const __m256i v1 = _mm256_srai_epi16(_mm256_slli_epi16(v, 8), 12);
+    const __m256i u0 = _mm256_srai_epi16(_mm256_slli_epi16(u, 12), 12);
+    const __m256i v0 = _mm256_srai_epi16(_mm256_slli_epi16(v, 12), 12);
+    /* vpmaddwd adds the two 16-bit products of every 32-bit word */
+    const __m256i p32 = _mm256_add_epi32(_mm256_madd_epi16(u3, v3), _mm256_madd_epi16(u2, v2));
+    const __m256i p10 = _mm256_add_epi32(_mm256_madd_epi16(u1, v1), _mm256_madd_epi16(u0, v0));
+    return _mm256_add_epi32(p32, p10);
+}
+
+/* the reference's final tree (CloverBase.h:149-157) on acc0 + acc1 */
+static inline float reduce_tree(__m256 acc0, __m256 acc1)
+{
+    float v[8];
+    _mm256_storeu_ps(v, _mm256_add_ps(acc0, acc1));
+    const float x0 = v[4] + v[0], x1 = v[5] + v[1], x2 = v[6] + v[2], x3 = v[7] + v[3];
+    const float y0 = x0 + x2, y1 = x1 + x3;
+    return y0 + y1;
+}
+
+static inline float dot_row(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t nb)
+{
+    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();
+    for (uint64_t b = 0; b < nb; b += 2) {
+        const __m256i ua = _mm256_loadu_si256((const __m256i *)(qu + 32 * b));
+        const __m256i va = _mm256_loadu_si256((const __m256i *)(qv + 32 * b));
+        const __m256i ub = _mm256_loadu_si256((const __m256i *)(qu + 32 * b + 32));
+        const __m256i vb = _mm256_loadu_si256((const __m256i *)(qv + 32 * b + 32));
+        const float ca = (su[b] * RCP49) * sv[b];
+        const float cb = (su[b + 1] * RCP49) * sv[b + 1];
+        const __m256 fa = _mm256_cvtepi32_ps(block_word_isums(ua, va));
+        const __m256 fb = _mm256_cvtepi32_ps(block_word_isums(ub, vb));
+        acc0 = _mm256_fmadd_ps(_mm256_set1_ps(ca), fa, acc0);
+        acc1 = _mm256_fmadd_ps(_mm256_set1_ps(cb), fb, acc1);
+    }
+    return reduce_tree(acc0, acc1);
+}
+
+float orcf_v4_dot(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad)
+{
+    return dot_row(qu, su, qv, sv, n_pad / 64);
+}
+
+/* quantise 64 floats with multiplier k (rounding disabled) into 32 bytes */
+static inline void quant64(const float *x, float k, uint8_t *dst)
+{
+    const __m256 vk = _mm256_set1_ps(k);
+    const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7FFFFFFF));
+    /* element e of a word goes to bit 8*(e/2) + (e even ? 4 : 0) */
+    const __m256i sh = _mm256_setr_epi32(4, 0, 12, 8, 20, 16, 28, 24);
+    uint32_t words[8];
+    for (int g = 0; g < 8; g++) {
+        const __m256 xv = _mm256_loadu_ps(x + 8 * g);
+        const __m256 p = _mm256_fmadd_ps(_mm256_and_ps(xv, absmask), vk, _mm256_setzero_ps());
+        const __m256i t = _mm256_cvttps_epi32(p);
+        const __m256i q = _mm256_sign_epi32(t, _mm256_castps_si256(xv));
+        __m256i n = _mm256_sllv_epi32(_mm256_and_si256(q, _mm256_set1_epi32(0xF)), sh);
+        /* OR-reduce the 8 lanes into one dword */
+        __m128i r = _mm_or_si128(_mm256_castsi256_si128(n), _mm256_extracti128_si256(n, 1));
+        r = _mm_or_si128(r, _mm_shuffle_epi32(r, 0x4E));
+        r = _mm_or_si128(r, _mm_shuffle_epi32(r, 0xB1));
+        words[g] = (uint32_t)_mm_cvtsi128_si32(r);
+    }
+    memcpy(dst, words, 32);
+}
+
+static inline float absmax64(const float *x)
+{
+    const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7FFFFFFF));
+    __m256 m = _mm256_setzero_ps();
+    for (int g = 0; g < 8; g++) m = _mm256_max_ps(m, _mm256_and_ps(_mm256_loadu_ps(x + 8 * g), absmask));
+    float v[8];
+    _mm256_storeu_ps(v, m);
+    float r = 0.0f;
+    for (int i = 0; i < 8; i++) if (v[i] > r) r = v[i];
+    return r;
+}
+
+static inline float fix_zero(float m)
+{
+    uint32_t u;
+    memcpy(&u, &m, 4);
+    return u == 0 ? m + 1.0f : m;
+}
+
+void orcf_v4_quantize(const float *x, uint64_t n_pad, uint8_t *q, float *s)
+{
+    const int64_t nb = (int64_t)(n_pad / 64);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < nb; b++) {
+        const float m = fix_zero(absmax64(x + 64 * b));
+        s[b] = m;
+        quant64(x + 64 * b, 7.0f / m, q + 32 * b);
+    }
+}
+
+void orcf_m4_mvm(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,
+                 const uint8_t *x, const float *sx, uint8_t *r, float *sr)
+{
+    const uint64_t hb = cols / 64;
+    const int64_t groups = (int64_t)(rows / 64);
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < groups; g++) {
+        float d[64];
+        for (int k = 0; k < 64; k++)
+            d[k] = dot_row(A + ((uint64_t)g * 64 + k) * (cols / 2), sA + (uint64_t)g * hb, x, sx, hb);
+        const float m = fix_zero(absmax64(d));
+        sr[g] = m;
+        quant64(d, 7.0f / m, r + 32 * g);
+    }
+}

@@ -1,0 +1,45 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol include/clover_hip.h declares; the binding's prototype table covers the same set."""
+import ctypes
+import re
+from pathlib import Path
+
+from clover_amd.build import build_hip_library, repo_root
+from clover_amd.lib_binding import SIGNATURES, load_library
+
+
+def declared_symbols():
+    text = (repo_root() / "include" / "clover_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cl[vm]4?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_surface():
+    syms = declared_symbols()
+    for must in ("clv4_quantize", "clv4_restore", "clv4_dot", "clm4_quantize", "clm4_mvm", "clm4_gemm",
+                 "clv_last_error", "clv_malloc", "clv_rng_seed"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    path = build_hip_library()
+    lib = ctypes.CDLL(str(path))                      # loads on a machine without a GPU
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in clover_hip.h but not exported: {missing}"
+
+
+def test_binding_table_matches_header():
+    assert sorted(SIGNATURES) == declared_symbols()
+    lib = load_library()
+    assert lib.clv_version().decode().startswith("clover_hip")
+
+
+def test_error_codes_without_compute():
+    lib = load_library()
+    # argument validation happens before any device work: callable on a CPU-only box
+    assert lib.clv4_quantize(None, 128, None, None, None, None) == -1
+    assert b"null" in lib.clv_last_error()
+    assert lib.clm4_mvm(1, 1, 100, 128, 1, 1, 1, 1, None, None) == -1   # rows not a multiple of 128
+    assert b"multiples of 128" in lib.clv_last_error()
+    n = ctypes.c_int(-1)
+    assert lib.clv_device_count(ctypes.byref(n)) == 0 and n.value >= 0

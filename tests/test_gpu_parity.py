@@ -1,0 +1,212 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar: bit-exact for every byte, scale and fp32 result produced in the reference's order (quantize, restore,
+word sums, dot EXACT, mvm, rowdots, GEMM per-element chain); dot FAST is the only tolerance-based check
+(tolerance written at the assert).  Sizes follow the reference's validation grid plus
+ragged / edge cases; big configurations are covered by properties in test_gpu_large.py.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import bits, kat2_inputs, kat3_inputs, random_packed
+
+pytestmark = pytest.mark.gpu
+KAT = json.loads((Path(__file__).parent / "golden" / "kat_reference.json").read_text())
+
+
+def ints(rng, n, lim):
+    return rng.integers(-lim, lim + 1, size=n).astype(np.float32)
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+
+
+# ---------------------------------------------------------------- known answers straight on the GPU
+def test_gpu_kat1_kat2(hip):
+    from clover_amd.lib_binding import DOT_EXACT
+    a = hip.v4_quantize(np.full(128, 1.0, np.float32))
+    b = hip.v4_quantize(np.full(128, 2.0, np.float32))
+    assert set(a[0].tolist()) == {0x77} and a[1].tolist() == [1.0, 1.0] and b[1].tolist() == [2.0, 2.0]
+    assert hex(bits(hip.v4_dot(*a, *b, mode=DOT_EXACT))) == KAT["KAT1"]["dot_bits"]
+    x, y = kat2_inputs()
+    qx, qy = hip.v4_quantize(x), hip.v4_quantize(y)
+    assert qx[0][:32].tobytes().hex() == KAT["KAT2"]["qx_bytes_0_31"]
+    assert qy[0][:32].tobytes().hex() == KAT["KAT2"]["qy_bytes_0_31"]
+    assert hex(bits(hip.v4_dot(*qx, *qy, mode=DOT_EXACT))) == KAT["KAT2"]["dot_bits"]
+    assert [hex(v) for v in bits(hip.v4_restore(*qx)[:4])] == KAT["KAT2"]["restore_qx_0_3_bits"]
+
+
+def test_gpu_kat3(hip):
+    A, x = kat3_inputs()
+    M, N = A.shape
+    qA, sA = hip.m4_quantize(A)
+    qx = hip.v4_quantize(x)
+    r, sr = hip.m4_mvm(qA, sA, M, N, *qx)
+    assert r.tobytes().hex() == KAT["KAT3"]["r_bytes_0_63"]
+    assert [hex(v) for v in bits(sr)] == KAT["KAT3"]["r_scale_bits"]
+
+
+# ---------------------------------------------------------------- vector ops vs oracle
+@pytest.mark.parametrize("n", [128, 256, 384, 1024, 2048 + 128, 65536, (1 << 20) + 128])
+def test_quantize_restore_bit_exact(hip, oracle, n):
+    rng = np.random.default_rng(n)
+    for x in (ints(rng, n, 10), (rng.normal(size=n) * 4).astype(np.float32), rng.uniform(-1e-3, 1e-3, n).astype(np.float32)):
+        x[n // 3] = 0.0
+        x[n // 2] = -0.0
+        q, s = hip.v4_quantize(x)
+        qo, so = oracle.v4_quantize(x)
+        assert same(q, qo) and same(s, so)
+        assert same(hip.v4_restore(q, s), oracle.v4_restore(q, s))
+
+
+def test_quantize_edge_blocks(hip, oracle):
+    x = np.zeros(512, np.float32)
+    x[64:128] = 1e-30                      # tiny but non-zero block
+    x[128:192] = np.float32(3.4e38)        # huge block
+    x[192:256] = -np.arange(64, dtype=np.float32)
+    x[300] = np.float32(1e-45)             # a denormal max
+    q, s = hip.v4_quantize(x)
+    qo, so = oracle.v4_quantize(x)
+    assert same(q, qo) and same(s, so)
+    assert s[0] == 1.0 and not q[:32].any()
+
+
+@pytest.mark.parametrize("n", [128, 256, 640, 2048, 4096 + 128, 1 << 16])
+def test_word_isums_and_dot_exact(hip, oracle, n):
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST
+    rng = np.random.default_rng(n + 17)
+    (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
+    assert np.array_equal(hip.v4_word_isums(qu, qv), oracle.v4_word_isums(qu, qv))
+    d = hip.v4_dot(qu, su, qv, sv, mode=DOT_EXACT)
+    assert bits(d) == bits(oracle.v4_dot(qu, su, qv, sv))
+    # FAST: same exact block integers, different fp32 summation order.  Tolerance: 2e-6 * sum|terms|
+    # (the reference's own SIMD-vs-scalar check allows 0.02 absolute, 02_vector.cpp:284)
+    f = hip.v4_dot(qu, su, qv, sv, mode=DOT_FAST)
+    I = oracle.v4_word_isums(qu, qv).reshape(-1, 8).sum(1)
+    mag = float(np.sum(np.abs(I) * su.astype(np.float64) * sv.astype(np.float64) / 49.0))
+    assert abs(float(f) - oracle.v4_dot_f64(qu, su, qv, sv)) <= 2e-6 * mag + 1e-6
+
+
+def test_dot_on_quantized_ints(hip, oracle):
+    # the reference's dot test data: ints in [-7,7] (02_vector.cpp:258-295)
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST
+    rng = np.random.default_rng(99)
+    for n in (128, 1152, 2048):
+        a, b = hip.v4_quantize(ints(rng, n, 7)), hip.v4_quantize(ints(rng, n, 7))
+        d = hip.v4_dot(*a, *b, mode=DOT_EXACT)
+        assert bits(d) == bits(oracle.v4_dot(*a, *b))
+        assert abs(float(d) - float(oracle.v4_dot_scalar(*a, *b))) <= 0.02
+        assert abs(float(hip.v4_dot(*a, *b, mode=DOT_FAST)) - float(d)) <= 0.02
+
+
+# ---------------------------------------------------------------- matrix ops vs oracle
+GRID = [(128, 128), (128, 384), (256, 256), (384, 128), (512, 1280), (1280, 640)]
+
+
+@pytest.mark.parametrize("shape", GRID)
+def test_matrix_quantize_bit_exact(hip, oracle, shape):
+    M, N = shape
+    rng = np.random.default_rng(M * 31 + N)
+    for A in (ints(rng, M * N, 10).reshape(M, N), rng.normal(size=(M, N)).astype(np.float32)):
+        A[0, 0] = -0.0
+        q, s = hip.m4_quantize(A)
+        qo, so = oracle.m4_quantize(A)
+        assert same(q, qo) and same(s, so)
+
+
+def test_matrix_quantize_zero_tile(hip, oracle):
+    A = np.zeros((128, 256), np.float32)
+    A[64:, 128:] = 5.0
+    q, s = hip.m4_quantize(A)
+    qo, so = oracle.m4_quantize(A)
+    assert same(q, qo) and same(s, so) and s[0] == 1.0
+
+
+@pytest.mark.parametrize("shape", GRID + [(128, 65536 + 128), (256, 131072)])
+def test_mvm_bit_exact(hip, oracle, shape):
+    M, N = shape
+    rng = np.random.default_rng(M * 13 + N)
+    qA, _ = random_packed(rng, M * N)
+    sA = rng.uniform(0.5, 2.0, size=(M // 64) * (N // 64)).astype(np.float32)
+    qx, sx = random_packed(rng, N)
+    d = hip.m4_rowdots(qA, sA, M, N, qx, sx)
+    assert same(d, oracle.m4_rowdots(qA, sA, M, N, qx, sx))
+    r, sr = hip.m4_mvm(qA, sA, M, N, qx, sx)
+    ro, sro = oracle.m4_mvm(qA, sA, M, N, qx, sx)
+    assert same(r, ro) and same(sr, sro)
+
+
+def test_mvm_on_quantized_floats(hip, oracle):
+    # end to end like the reference's mvm test (03_matrix.cpp:248-326): quantize both on the device, multiply
+    rng = np.random.default_rng(4)
+    M, N = 384, 512
+    A, x = ints(rng, M * N, 10).reshape(M, N), ints(rng, N, 10)
+    qA, sA = hip.m4_quantize(A)
+    qx = hip.v4_quantize(x)
+    r, sr = hip.m4_mvm(qA, sA, M, N, *qx)
+    ro, sro = oracle.m4_mvm(*oracle.m4_quantize(A), M, N, *oracle.v4_quantize(x))
+    assert same(r, ro) and same(sr, sro)
+
+
+def test_mvm_zero_matrix(hip, oracle):
+    M, N = 128, 256
+    qA, sA = np.zeros(M * N // 2, np.uint8), np.ones((M // 64) * (N // 64), np.float32)
+    qx, sx = random_packed(np.random.default_rng(1), N)
+    r, sr = hip.m4_mvm(qA, sA, M, N, qx, sx)
+    assert not r.any() and sr.tolist() == [1.0, 1.0]
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 128), (128, 256, 384), (256, 128, 1024)])
+def test_gemm_bit_exact(hip, oracle, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    qA, _ = random_packed(rng, M * K)
+    qB, _ = random_packed(rng, N * K)
+    sA = rng.uniform(0.5, 2.0, size=(M // 64) * (K // 64)).astype(np.float32)
+    sB = rng.uniform(0.5, 2.0, size=(N // 64) * (K // 64)).astype(np.float32)
+    C = hip.m4_gemm(qA, sA, M, K, qB, sB, N)
+    assert same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N))
+
+
+# ---------------------------------------------------------------- stochastic rounding: same XORShift stream
+@pytest.mark.parametrize("n", [128, 1024, 8192 + 128, (1 << 17) + 384])
+def test_stochastic_vector_quantize_same_stream(hip, oracle, n):
+    rng = np.random.default_rng(n)
+    x = (rng.normal(size=n) * 2).astype(np.float32)
+    st = hip.new_rng(12345, 67890)
+    o = oracle.rng(12345, 67890)
+    for _ in range(2):                       # second call continues the stream
+        q, s = hip.v4_quantize(x, rng=st)
+        qo, so = oracle.v4_quantize(x, o)
+        assert same(q, qo) and same(s, so)
+    k1, k2 = hip.rng_get(st)
+    o1, o2 = oracle.rng_keys(o)
+    assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
+
+
+def test_stochastic_matrix_quantize_and_mvm_same_stream(hip, oracle):
+    rng = np.random.default_rng(8)
+    M, N = 256, 384
+    A = rng.normal(size=(M, N)).astype(np.float32)
+    st, o = hip.new_rng(445560390295639063, 2935984234003016713), oracle.rng(445560390295639063, 2935984234003016713)
+    qA, sA = hip.m4_quantize(A, rng=st)
+    qAo, sAo = oracle.m4_quantize(A, o)
+    assert same(qA, qAo) and same(sA, sAo)
+    qx = oracle.v4_quantize(rng.normal(size=N).astype(np.float32))
+    r, sr = hip.m4_mvm(qA, sA, M, N, *qx, rng=st)
+    ro, sro = oracle.m4_mvm(qA, sA, M, N, *qx, o)
+    assert same(r, ro) and same(sr, sro)
+    assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
+
+
+# ---------------------------------------------------------------- error behaviour of the boundary
+def test_bad_sizes_are_rejected(hip):
+    from clover_amd.lib_binding import CloverHipError
+    with pytest.raises(CloverHipError):
+        hip.v4_quantize(np.zeros(100, np.float32))
+    buf = hip.alloc(1024)
+    assert hip.lib.clm4_mvm(buf.ptr, buf.ptr, 192, 128, buf.ptr, buf.ptr, buf.ptr, buf.ptr, None, None) == -1
