@@ -77,8 +77,11 @@ __device__ __forceinline__ float fix_zero_max(float m)
 __device__ __forceinline__ int quant1(float x, float k, float noise)
 {
     const float p = __builtin_fmaf(__builtin_fabsf(x), k, noise);
-    const int t = (int)p;                       // v_cvt_i32_f32: truncation, like cvttps
-    return __float_as_int(x) < 0 ? -t : t;      // +0.0 -> t == 0 already
+    // v_cvt_i32_f32 truncates like cvttps but saturates; cvttps returns 0x80000000 for anything outside
+    // int32 (only reachable when 7/max overflows, i.e. a block maximum below 2.06e-38): mirror that.
+    const int t = (p < 2147483648.0f) ? (int)p : (int)0x80000000;   // p >= 0 or NaN here
+    const int xb = __float_as_int(x);
+    return xb < 0 ? (int)(0u - (unsigned)t) : (xb == 0 ? 0 : t);
 }
 
 // bit position of element e (0..7) of a little-endian 32-bit word: even elements sit in the HIGH nibble

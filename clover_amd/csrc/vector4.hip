@@ -67,46 +67,119 @@ __global__ __launch_bounds__(256) void k_v4_word_isums(const uint32_t *__restric
 // ------------------------------------------------------------------------------------------------
 // dot, reference order (CloverVector4.h:1095-1192): 16 sequential fp32 fma chains -- chain
 // j = word index mod 16 (accumulator = bit 3, AVX lane = bits 0..2) -- then the fixed add tree of
-// CloverBase.h:149-157.  The chains are sequential by definition, so this is ONE wave and
-// latency-bound (~4 cycles per block pair); it exists for parity and for short vectors.
-//   lane = (sub, j): sub = lane>>4 prepares block pair 4g+sub; chain lanes (sub==0) fold 4 pairs per step.
+// CloverBase.h:149-157.  The chains are sequential by definition (n/128 dependent fmas each), so the
+// floor is one fma latency per block pair on ONE wave.  Everything that is not the chain is moved out:
+//   k_v4_dot_prep   (all CUs)  : per word f = (float)sdot8(u,v), per block c = f32(f32(su/49)*sv), written
+//                                "chain-major": F[g][j][i] = f of word 16(4g+i)+j, C[g][a][i] = c of
+//                                block 2(4g+i)+a  (g = group of 4 block pairs), so a chain lane fetches
+//                                4 steps with one 16-byte read;
+//   k_v4_dot_chain  (one WG)   : 256 threads copy tile t+1 (512 pairs = 36 KiB) HBM->LDS while lanes 0..15
+//                                of wave 0 run the fma chains over tile t out of LDS.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_v4_dot_exact(const uint32_t *__restrict__ qu, const float *__restrict__ su,
+#define DX_TILE_PAIRS 512
+#define DX_TILE_GROUPS (DX_TILE_PAIRS / 4)
+#define DX_TILE_F4 (DX_TILE_GROUPS * 16)            // float4 per tile of F
+#define DX_TILE_C4 (DX_TILE_GROUPS * 2)             // float4 per tile of C
+#define DX_BUF_F4 (DX_TILE_F4 + DX_TILE_C4)
+
+__global__ __launch_bounds__(256) void k_v4_dot_prep(const uint32_t *__restrict__ qu, const float *__restrict__ su,
                                                      const uint32_t *__restrict__ qv, const float *__restrict__ sv,
-                                                     uint64_t npairs, float *__restrict__ out)
+                                                     uint64_t npairs, uint64_t ngroups, f32x4 *__restrict__ F, f32x4 *__restrict__ Cc)
 {
-    const int lane = threadIdx.x;
-    const int j = lane & 15;
-    const int sub = lane >> 4;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ngroups * 16; t += stride) {
+        const uint64_t g = t >> 4;
+        const int j = (int)(t & 15);
+        float f[4], c[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t p = 4 * g + i;
+            if (p < npairs) {
+                f[i] = (float)sdot8(qu[16 * p + j], qv[16 * p + j], 0);
+                const uint64_t blk = 2 * p + (j & 1);                  // lanes j = 0,1 also produce the c's
+                c[i] = j < 2 ? (su[blk] * CLV_RCP49) * sv[blk] : 0.0f;
+            } else {
+                f[i] = 0.0f;
+                c[i] = 0.0f;
+            }
+        }
+        F[t] = f32x4{f[0], f[1], f[2], f[3]};
+        if (j < 2) Cc[2 * g + j] = f32x4{c[0], c[1], c[2], c[3]};
+    }
+}
+
+__global__ __launch_bounds__(256) void k_v4_dot_chain(const f32x4 *__restrict__ F, const f32x4 *__restrict__ Cc,
+                                                      uint64_t npairs, uint64_t ngroups, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = reinterpret_cast<f32x4 *>(smem);          // 2 x DX_BUF_F4
+    const int tid = threadIdx.x;
+    const int j = tid & 15;
+    const uint64_t ntiles = (ngroups + DX_TILE_GROUPS - 1) / DX_TILE_GROUPS;
+    constexpr int NF = DX_TILE_F4 / 256;                   // 8 float4 of F per thread per tile
+
+    f32x4 rf[NF], rc;
+    auto fetch = [&](uint64_t tile) {
+        const uint64_t g0 = tile * DX_TILE_GROUPS;
+#pragma unroll
+        for (int k = 0; k < NF; k++) {
+            const uint64_t idx = g0 * 16 + tid + 256 * k;
+            rf[k] = idx < ngroups * 16 ? F[idx] : f32x4{0, 0, 0, 0};
+        }
+        const uint64_t cidx = g0 * 2 + tid;
+        rc = (tid < DX_TILE_C4 && cidx < ngroups * 2) ? Cc[cidx] : f32x4{0, 0, 0, 0};
+    };
+    auto stash = [&](int buf) {
+        f32x4 *b = lds + buf * DX_BUF_F4;
+#pragma unroll
+        for (int k = 0; k < NF; k++) b[tid + 256 * k] = rf[k];
+        if (tid < DX_TILE_C4) b[DX_TILE_F4 + tid] = rc;
+    };
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
     float acc = 0.0f;
-    const uint64_t full = npairs & ~(uint64_t)3;
+    for (uint64_t tile = 0; tile < ntiles; tile++) {
+        const int buf = (int)(tile & 1);
+        if (tile + 1 < ntiles) fetch(tile + 1);            // in flight while the chains run
+        if (tid < 16) {
+            const f32x4 *bf = lds + buf * DX_BUF_F4;
+            const f32x4 *bc = bf + DX_TILE_F4;
+            const uint64_t g0 = tile * DX_TILE_GROUPS;
+            const uint64_t gend = (ngroups - g0) < DX_TILE_GROUPS ? (ngroups - g0) : DX_TILE_GROUPS;
+            const uint64_t full = (npairs / 4 > g0) ? ((npairs / 4 - g0) < gend ? (npairs / 4 - g0) : gend) : 0;
+            uint64_t g = 0;
 #pragma unroll 4
-    for (uint64_t g = 0; g < full; g += 4) {
-        const uint64_t p = g + sub;
-        const uint64_t blk = 2 * p + (j >> 3);
-        const float c = (su[blk] * CLV_RCP49) * sv[blk];
-        const float f = (float)sdot8(qu[16 * p + j], qv[16 * p + j], 0);
-        const float c1 = __shfl(c, j + 16), f1 = __shfl(f, j + 16);
-        const float c2 = __shfl(c, j + 32), f2 = __shfl(f, j + 32);
-        const float c3 = __shfl(c, j + 48), f3 = __shfl(f, j + 48);
-        acc = __builtin_fmaf(c, f, acc);      // meaningful on sub == 0 lanes only
-        acc = __builtin_fmaf(c1, f1, acc);
-        acc = __builtin_fmaf(c2, f2, acc);
-        acc = __builtin_fmaf(c3, f3, acc);
+            for (; g < full; g++) {
+                const f32x4 f = bf[g * 16 + j];
+                const f32x4 c = bc[g * 2 + (j >> 3)];
+                acc = __builtin_fmaf(c.x, f.x, acc);
+                acc = __builtin_fmaf(c.y, f.y, acc);
+                acc = __builtin_fmaf(c.z, f.z, acc);
+                acc = __builtin_fmaf(c.w, f.w, acc);
+            }
+            if (g < gend) {                                // the last, partial group of the vector
+                const f32x4 f = bf[g * 16 + j];
+                const f32x4 c = bc[g * 2 + (j >> 3)];
+                const uint64_t rem = npairs - 4 * (g0 + g);
+                acc = __builtin_fmaf(c.x, f.x, acc);
+                if (rem > 1) acc = __builtin_fmaf(c.y, f.y, acc);
+                if (rem > 2) acc = __builtin_fmaf(c.z, f.z, acc);
+            }
+        }
+        if (tile + 1 < ntiles) stash(buf ^ 1);
+        __syncthreads();
     }
-    for (uint64_t p = full; p < npairs; p++) {   // 0..3 leftover pairs, every lane walks them
-        const uint64_t blk = 2 * p + (j >> 3);
-        const float c = (su[blk] * CLV_RCP49) * sv[blk];
-        const float f = (float)sdot8(qu[16 * p + j], qv[16 * p + j], 0);
-        acc = __builtin_fmaf(c, f, acc);
+    if (tid < 64) {
+        // lanes 0..15 hold chain j: accumulator a = j>>3, AVX lane w = j&7
+        const float v = acc + __shfl(acc, (j + 8) & 15);   // acc[0][w] + acc[1][w]          (:1190)
+        const float x = __shfl(v, (j + 4) & 15) + v;       // x[w] = v[w+4] + v[w], w = 0..3  (CloverBase.h:153)
+        const float x2 = __shfl(x, (j + 2) & 15);
+        const float y = x + x2;                            // y0 = x0 + x2 (lane 0), y1 = x1 + x3 (lane 1)
+        const float y1 = __shfl(y, 1);
+        if (tid == 0) *out = y + y1;
     }
-    // lanes 0..15 hold chain j: accumulator a = j>>3, AVX lane w = j&7
-    const float v = acc + __shfl(acc, (j + 8) & 15);   // acc[0][w] + acc[1][w]          (:1190)
-    const float x = __shfl(v, (j + 4) & 15) + v;       // x[w] = v[w+4] + v[w], w = 0..3  (CloverBase.h:153)
-    const float x2 = __shfl(x, (j + 2) & 15);
-    const float y = x + x2;                            // y0 = x0 + x2 (lane 0), y1 = x1 + x3 (lane 1)
-    const float y1 = __shfl(y, 1);
-    if (lane == 0) *out = y + y1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,10 +285,13 @@ static inline int dot_fast_grid(uint64_t n_pad)
     return stream_grid(n_pad / 32, DOT_FAST_THREADS, 4);
 }
 
+static inline uint64_t dot_exact_groups(uint64_t n_pad) { return (n_pad / 128 + 3) / 4; }
+
 extern "C" uint64_t clv4_dot_workspace_bytes(uint64_t n_pad)
 {
-    (void)n_pad;
-    return (uint64_t)clv_cu_count() * 4 * sizeof(float) + 256;
+    const uint64_t fast = (uint64_t)clv_cu_count() * 4 * sizeof(float) + 256;
+    const uint64_t exact = dot_exact_groups(n_pad) * (16 + 2) * sizeof(f32x4) + 256;
+    return fast > exact ? fast : exact;
 }
 
 extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad,
@@ -226,15 +302,28 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
     CLV_REQUIRE(mode == CLV_DOT_EXACT || mode == CLV_DOT_FAST, "clv4_dot: unknown mode %d", mode);
     hipStream_t st = as_stream(stream);
     if (!n_pad) { CLV_HIP(hipMemsetAsync(out_dev, 0, sizeof(float), st)); return CLV_OK; }
-    if (mode == CLV_DOT_EXACT) {
-        hipLaunchKernelGGL(k_v4_dot_exact, dim3(1), dim3(64), 0, st, (const uint32_t *)qu, su, (const uint32_t *)qv, sv,
-                           n_pad / 128, out_dev);
-        CLV_LAUNCH_CHECK();
-        return CLV_OK;
-    }
     if (!workspace) {
         int rc = clv_internal_workspace(&workspace, clv4_dot_workspace_bytes(n_pad));
         if (rc) return rc;
+    }
+    if (mode == CLV_DOT_EXACT) {
+        const uint64_t npairs = n_pad / 128, ngroups = dot_exact_groups(n_pad);
+        f32x4 *F = (f32x4 *)workspace;
+        f32x4 *Cc = F + ngroups * 16;
+        hipLaunchKernelGGL(k_v4_dot_prep, dim3(stream_grid(ngroups * 16, 256, 8)), dim3(256), 0, st, (const uint32_t *)qu, su,
+                           (const uint32_t *)qv, sv, npairs, ngroups, F, Cc);
+        CLV_LAUNCH_CHECK();
+        static const size_t lds = 2 * DX_BUF_F4 * sizeof(f32x4);      // 72 KiB: above the 64 KiB default
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        CLV_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            CLV_HIP(hipFuncSetAttribute((const void *)k_v4_dot_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(k_v4_dot_chain, dim3(1), dim3(256), lds, st, (const f32x4 *)F, (const f32x4 *)Cc, npairs, ngroups, out_dev);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
     }
     const int grid = dot_fast_grid(n_pad);
     hipLaunchKernelGGL(k_v4_dot_partial, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv,
