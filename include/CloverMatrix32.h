@@ -1,0 +1,60 @@
+/*
+ * CloverMatrix32.h -- fp32 row-major matrix container: the input of CloverMatrix4::quantize and the
+ * output of CloverMatrix4::gemm.  Mirrors the storage part of the reference's include/CloverMatrix32.h
+ * (:43-73; rows and cols padded to multiples of 128 by CloverMatrix.h:48-53, contents uninitialised).
+ * The reference's fp32 mvm (MKL sgemv) and transpose (IPP) are out of scope.
+ */
+#ifndef CLOVER_MATRIX32_H
+#define CLOVER_MATRIX32_H
+
+#include <iomanip>
+#include <sstream>
+#include <string>
+
+#include "CloverVector32.h"
+
+class CloverMatrix32 {
+protected:
+    const uint64_t rows;
+    const uint64_t cols;
+    mutable clover_hip::Mirror mem;
+
+public:
+    CloverMatrix32(uint64_t h, uint64_t w)
+        : rows(clover_hip::round_up(h, CLOVER_VECTOR_SIZE_PAD)), cols(clover_hip::round_up(w, CLOVER_VECTOR_SIZE_PAD))
+    {
+        mem.allocate(rows * cols * sizeof(float));
+    }
+
+    uint64_t getRows() const { return rows; }
+    uint64_t getCols() const { return cols; }
+    uint64_t size() const { return rows * cols; }
+    uint64_t getBitsLength() const { return 32; }
+    uint64_t getBytes() const { return rows * cols * sizeof(float); }
+
+    float *getData() const { return reinterpret_cast<float *>(mem.host_rw()); }
+    float get(uint64_t i, uint64_t j) const { return reinterpret_cast<const float *>(mem.host_ro())[i * cols + j]; }
+    void set(uint64_t i, uint64_t j, float v) { reinterpret_cast<float *>(mem.host_rw())[i * cols + j] = v; }
+    void clear() { memset(mem.host_rw(), 0, rows * cols * sizeof(float)); }
+
+    void setRandomInteger(float max_value, uint64_t seed = 0x9E3779B97F4A7C15ull)
+    {
+        CloverVector32 view(rows * cols, getData());      /* non-owning view over the same buffer */
+        view.setRandomInteger(max_value, seed);
+    }
+
+    std::string toString() const
+    {
+        std::stringstream sout;
+        for (uint64_t i = 0; i < rows; i++) {
+            for (uint64_t j = 0; j < cols; j++) sout << std::setw(7) << std::setprecision(2) << get(i, j) << " ";
+            sout << ";" << std::endl;
+        }
+        return sout.str();
+    }
+
+    const float *device_ro() const { return reinterpret_cast<const float *>(mem.dev_ro()); }
+    float *device_wo() { return reinterpret_cast<float *>(mem.dev_wo()); }
+};
+
+#endif

@@ -1,0 +1,103 @@
+/*
+ * CloverMatrix4.h -- 4-bit quantized matrix, MI355X-backed.
+ *
+ * Drop-in for the reference's include/CloverMatrix4.h: same class name, constructor, method names and
+ * data format (row-major nibbles followed by a row-major grid of fp32 scales, one per 64x64 tile;
+ * rows/cols padded to multiples of 128; :77-139).  Hot methods call libclover_hip.so:
+ *
+ *   quantize                         -> clm4_quantize (CloverMatrix4.h:512-766)
+ *   mvm / mvm_parallel / mvm_scalar  -> clm4_mvm      (:777-1083, :1681-2006, :311-392 -- all three give
+ *                                                      the same result in the reference, bit for bit)
+ *   gemm (new)                       -> clm4_gemm     (the reference has no GEMM; semantics in DESIGN.md)
+ *
+ * As in the reference, values/scales are not exposed (they are `protected` there, :73-75); the matrix
+ * lives in HBM once quantized.  Out of scope: transpose, mixed-precision mvm.
+ */
+#ifndef CLOVER_MATRIX4_H
+#define CLOVER_MATRIX4_H
+
+#include "CloverMatrix32.h"
+#include "CloverVector4.h"
+
+class CloverMatrix4 {
+protected:
+    const uint64_t rows;
+    const uint64_t cols;
+    mutable clover_hip::Mirror mem;            /* [rows*cols/2 value bytes][(rows/64)*(cols/64) scales] */
+    mutable clover_hip::RandomState random;
+    uint64_t value_bytes;
+
+    const int8_t *dev_values() const { return reinterpret_cast<const int8_t *>(mem.dev_ro()); }
+    const float *dev_scales() const { return reinterpret_cast<const float *>(mem.dev_ro() + value_bytes); }
+
+public:
+    CloverMatrix4(uint64_t h, uint64_t w)
+        : rows(clover_hip::round_up(h, CLOVER_VECTOR_SIZE_PAD)), cols(clover_hip::round_up(w, CLOVER_VECTOR_SIZE_PAD))
+    {
+        value_bytes = rows * cols / 2;
+        mem.allocate(value_bytes + (rows >> 6) * (cols >> 6) * sizeof(float));
+    }
+
+    uint64_t getRows() const { return rows; }
+    uint64_t getCols() const { return cols; }
+    uint64_t size() const { return rows * cols; }
+    uint64_t getBitsLength() const { return 4; }
+    uint64_t getBytes() const { return value_bytes + (rows >> 6) * (cols >> 6) * sizeof(float); }
+
+    float get(uint64_t i, uint64_t j) const
+    {
+        const uint8_t *h = mem.host_ro();
+        const float *s = reinterpret_cast<const float *>(h + value_bytes);
+        const float scale = s[(i >> 6) * (cols >> 6) + (j >> 6)] / 7.0f;
+        const uint64_t pos = i * cols + j;
+        const int8_t b = (int8_t)h[pos >> 1];
+        return scale * (float)(int8_t)((int8_t)(b << ((pos % 2) * 4)) >> 4);
+    }
+
+    void setRandomKeys(const uint64_t key1[4], const uint64_t key2[4]) { random.set(key1, key2); }
+    void seedRandomKeys(uint64_t key1, uint64_t key2) { random.seed(key1, key2); }
+
+    void quantize(const CloverMatrix32 &m)
+    {
+        if (m.getRows() != rows || m.getCols() != cols) {
+            std::cout << "Matrices do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        const float *A = m.device_ro();
+        uint8_t *d = mem.dev_wo();
+        clover_hip::check(clm4_quantize(A, rows, cols, reinterpret_cast<int8_t *>(d), reinterpret_cast<float *>(d + value_bytes),
+                                        clover_hip::rng_or_null(random), nullptr), "CloverMatrix4::quantize");
+    }
+    void quantize_scalar(const CloverMatrix32 &m) { quantize(m); }
+
+    void mvm(const CloverVector4 &productVector, CloverVector4 &resultVector)
+    {
+        if (productVector.size() != getCols()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        if (resultVector.size_pad() != getRows()) {                 /* checked by mvm_scalar in the reference (:313) */
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        const int8_t *x = productVector.dev_values_ro();
+        const float *sx = productVector.dev_scales_ro();
+        clover_hip::check(clm4_mvm(dev_values(), dev_scales(), rows, cols, x, sx, resultVector.dev_values_wo(),
+                                   resultVector.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr), "CloverMatrix4::mvm");
+    }
+    void mvm_parallel(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
+    void mvm_scalar(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
+
+    /* C = this * B^T, fp32: this is M x K, B is N x K, C is M x N (build-defined) */
+    void gemm(const CloverMatrix4 &B, CloverMatrix32 &C) const
+    {
+        if (B.cols != cols || C.getRows() != rows || C.getCols() != B.rows) {
+            std::cout << "GEMM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        clover_hip::check(clm4_gemm(dev_values(), dev_scales(), rows, cols, B.dev_values(), B.dev_scales(), B.rows, C.device_wo(), nullptr),
+                          "CloverMatrix4::gemm");
+    }
+};
+
+#endif

@@ -1,0 +1,88 @@
+/*
+ * CloverVector32.h -- fp32 vector container: the INPUT of quantize and the OUTPUT of restore.
+ *
+ * Same class name, constructors, padding and accessors as the reference's include/CloverVector32.h
+ * (:47-70 constructors, :93-148 accessors; padding to a multiple of 128 with zeroed tail from
+ * CloverVector.h:86-92), written from scratch on top of clover_device.h.  Only the part of the class
+ * that the 4-bit hot path touches is provided; the reference's fp32 math (dot/scaleAndAdd/threshold via
+ * AVX2, mvm via MKL) is out of scope.
+ */
+#ifndef CLOVER_VECTOR32_H
+#define CLOVER_VECTOR32_H
+
+#include <iomanip>
+#include <sstream>
+#include <string>
+
+#include "clover_device.h"
+
+#define CLOVER_VECTOR_BLOCK 64
+#define CLOVER_VECTOR_SIZE_PAD (CLOVER_VECTOR_BLOCK * 2)
+
+class CloverVector32 {
+protected:
+    const uint64_t length;
+    const uint64_t length_pad;
+    mutable clover_hip::Mirror mem;
+
+public:
+    explicit CloverVector32(uint64_t s) : length(s), length_pad(clover_hip::round_up(s, CLOVER_VECTOR_SIZE_PAD))
+    {
+        mem.allocate(length_pad * sizeof(float));
+        float *v = reinterpret_cast<float *>(mem.host_rw());
+        for (uint64_t i = length; i < length_pad; i++) v[i] = 0;      /* zeroed padding (CloverVector32.h:61-63) */
+    }
+    /* non-owning view over caller memory holding size_pad() floats (CloverVector32.h:47-51) */
+    CloverVector32(uint64_t s, float *data) : length(s), length_pad(clover_hip::round_up(s, CLOVER_VECTOR_SIZE_PAD))
+    {
+        mem.adopt(data, length_pad * sizeof(float));
+    }
+    CloverVector32(const CloverVector32 &other) : length(other.length), length_pad(other.length_pad)
+    {
+        mem.allocate(length_pad * sizeof(float));
+        memcpy(mem.host_rw(), other.mem.host_ro(), length_pad * sizeof(float));
+    }
+
+    uint64_t size() const { return length; }
+    uint64_t size_pad() const { return length_pad; }
+    uint64_t getBitsLength() const { return 32; }
+    uint64_t getBytes() const { return length_pad * sizeof(float); }
+
+    float get(uint64_t i) const { return reinterpret_cast<const float *>(mem.host_ro())[i]; }
+    float getAbs(uint64_t i) const { float v = get(i); return v < 0 ? -v : v; }
+    void set(uint64_t i, float v) { reinterpret_cast<float *>(mem.host_rw())[i] = v; }
+    float *getData() const { return reinterpret_cast<float *>(mem.host_rw()); }
+
+    void clear() { memset(mem.host_rw(), 0, length_pad * sizeof(float)); }
+
+    /* test data like the reference's setRandomInteger (CloverVector32.h:697-744): integers uniform in
+     * [-max, max].  Uses a splitmix64 stream, not the reference's XORShift keys. */
+    void setRandomInteger(float max_value, uint64_t seed = 0x2545F4914F6CDD1Dull)
+    {
+        float *v = getData();
+        const int64_t range = (int64_t)max_value;
+        uint64_t z = seed;
+        for (uint64_t i = 0; i < length; i++) {
+            z += 0x9E3779B97F4A7C15ull;
+            uint64_t r = z;
+            r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ull;
+            r = (r ^ (r >> 27)) * 0x94D049BB133111EBull;
+            r ^= r >> 31;
+            v[i] = (float)((int64_t)(r % (uint64_t)(2 * range + 1)) - range);
+        }
+    }
+
+    std::string toString() const
+    {
+        std::stringstream sout;
+        for (uint64_t i = 0; i < length; i++)
+            sout << std::setw(10) << i << " | " << std::setw(20) << std::fixed << std::setprecision(7) << get(i) << std::endl;
+        return sout.str();
+    }
+
+    /* device access for the 4-bit containers */
+    const float *device_ro() const { return reinterpret_cast<const float *>(mem.dev_ro()); }
+    float *device_wo() { return reinterpret_cast<float *>(mem.dev_wo()); }
+};
+
+#endif

@@ -1,0 +1,211 @@
+/*
+ * CloverVector4.h -- 4-bit quantized vector, MI355X-backed.
+ *
+ * Drop-in for the reference's include/CloverVector4.h: same class name, constructors, method names,
+ * padding and data format (64-element blocks with one fp32 absolute-max scale, element 2i in the high
+ * nibble of byte i, values immediately followed by the scales in ONE allocation, :68-103), but every
+ * hot method is a call into libclover_hip.so (include/clover_hip.h) instead of an AVX2 loop:
+ *
+ *   quantize / quantize_parallel   -> clv4_quantize   (CloverVector4.h:605-807, :809-1024)
+ *   restore                        -> clv4_restore    (:1027-1093)
+ *   dot                            -> clv4_dot EXACT  (:1095-1192; bit-identical fp32 order)
+ *   dot_parallel                   -> clv4_dot FAST   (:1793-1907; the reference's OpenMP reduction order is
+ *                                                      unspecified, FAST is deterministic and tolerance-equal)
+ *   dot_scalar                     -> host loop       (:555-595; the reference's own validation partner)
+ *
+ * Results are bit-identical to the reference when built with -DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1; the
+ * default build rounds stochastically from the same XORShift stream (setRandomKeys for determinism).
+ * Element accessors (get/set/getBits/setBits/getData/...) work on the host copy and synchronise lazily.
+ * Out of scope here: scaleAndAdd, threshold.
+ */
+#ifndef CLOVER_VECTOR4_H
+#define CLOVER_VECTOR4_H
+
+#include <bitset>
+
+#include "CloverVector32.h"
+
+class CloverVector4 {
+protected:
+    const uint64_t length;
+    const uint64_t length_pad;
+    mutable clover_hip::Mirror mem;            /* [length_pad/2 value bytes][scales] */
+    mutable clover_hip::RandomState random;
+    uint64_t value_bytes;
+    /* a view built from two unrelated pointers cannot be one block: keep separate mirrors for it */
+    mutable clover_hip::Mirror view_scales;
+    bool split_view;
+
+    void allocate()
+    {
+        const uint64_t blocks = length_pad / CLOVER_VECTOR_BLOCK;
+        const uint64_t blocks_pad = clover_hip::round_up(blocks, CLOVER_VECTOR_BLOCK);
+        value_bytes = length_pad / 2;
+        mem.allocate(value_bytes + blocks_pad * sizeof(float));
+        split_view = false;
+        int8_t *v = reinterpret_cast<int8_t *>(mem.host_rw());
+        float *s = reinterpret_cast<float *>(v + value_bytes);
+        for (uint64_t i = length >> 1; i < value_bytes; i++) v[i] = 0;          /* zeroed value padding  */
+        for (uint64_t i = length / 64; i < blocks; i++) s[i] = 1;               /* padding scales = 1.0  */
+    }
+
+    static inline int8_t nibble(int8_t byte, uint64_t pos) { return (int8_t)((int8_t)(byte << ((pos % 2) * 4)) >> 4); }
+
+public:
+    explicit CloverVector4(uint64_t s) : length(s), length_pad(clover_hip::round_up(s, CLOVER_VECTOR_SIZE_PAD)) { allocate(); }
+
+    /* non-owning view (CloverVector4.h:114-119) */
+    CloverVector4(uint64_t s, int8_t *data, float *data_scales)
+        : length(s), length_pad(clover_hip::round_up(s, CLOVER_VECTOR_SIZE_PAD))
+    {
+        value_bytes = length_pad / 2;
+        mem.adopt(data, value_bytes);
+        view_scales.adopt(data_scales, (length_pad / 64) * sizeof(float));
+        split_view = true;
+    }
+
+    explicit CloverVector4(const CloverVector32 &other) : length(other.size()), length_pad(other.size_pad())
+    {
+        allocate();
+        quantize(other);
+    }
+
+    CloverVector4(const CloverVector4 &other) : length(other.length), length_pad(other.length_pad)
+    {
+        allocate();
+        memcpy(getData(), other.values_ro(), value_bytes);
+        memcpy(getScales(), other.scales_ro(), (length_pad / 64) * sizeof(float));
+    }
+
+    /* ---- support methods (CloverVector4.h:150-326) ------------------------------------------- */
+    uint64_t size() const { return length; }
+    uint64_t size_pad() const { return length_pad; }
+    uint64_t getBitsLength() const { return 4; }
+    uint64_t getBytes() const { return length_pad / 2 + (length_pad / 64) * sizeof(float); }
+
+    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
+    float *getScales() const
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.host_rw());
+        return reinterpret_cast<float *>(mem.host_rw() + value_bytes);
+    }
+
+    int8_t getBits(uint64_t pos) const { return nibble(values_ro()[pos >> 1], pos); }
+    void setBits(uint64_t pos, int8_t bits)
+    {
+        int8_t *v = getData();
+        const int8_t qu = (int8_t)((bits & 0x0F) << ((1 - pos % 2) * 4));
+        v[pos >> 1] = (int8_t)((v[pos >> 1] & (pos % 2 == 0 ? 0x0F : 0xF0)) | qu);
+    }
+    float get(uint64_t pos) const
+    {
+        const float scale = scales_ro()[pos >> 6] / 7.0f;
+        return scale * (float)nibble(values_ro()[pos >> 1], pos);
+    }
+    float getAbs(uint64_t pos) const { const float v = get(pos); return v < 0 ? -v : v; }
+    /* the reference uses the approximate rcpss here (CloverVector4.h:211); an exact division is used instead */
+    void set(uint64_t pos, float value)
+    {
+        const float scale = 7.0f / scales_ro()[pos >> 6];
+        setBits(pos, (int8_t)roundf(value * scale));
+    }
+    void clear()
+    {
+        memset(getData(), 0, value_bytes);
+        float *s = getScales();
+        for (uint64_t b = 0; b < length_pad / 64; b++) s[b] = 1.0f;
+    }
+    std::string toString() const
+    {
+        std::stringstream sout;
+        for (uint64_t i = 0; i < length_pad; i++) {
+            sout << std::setw(10) << i << " | " << std::setw(20) << std::fixed << std::setprecision(7) << get(i) << " | "
+                 << std::setw(20) << scales_ro()[i >> 6] << " | " << std::setw(5) << (int)getBits(i) << " | "
+                 << std::bitset<8>((uint8_t)values_ro()[i >> 1]) << std::endl;
+        }
+        return sout.str();
+    }
+
+    /* CloverRandom::setRandomKeys (CloverRandom.h:90-94): the four 64-bit lanes of each key register */
+    void setRandomKeys(const uint64_t key1[4], const uint64_t key2[4]) { random.set(key1, key2); }
+    /* avx_xorshift128plus_init(key1, key2) + setRandomKeys in one call */
+    void seedRandomKeys(uint64_t key1, uint64_t key2) { random.seed(key1, key2); }
+
+    /* ---- hot path ---------------------------------------------------------------------------- */
+    void quantize(const CloverVector32 &other)
+    {
+        if (other.size_pad() != length_pad) {
+            std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        const float *x = other.device_ro();
+        clover_hip::check(clv4_quantize(x, length_pad, dev_values_wo(), dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
+                          "CloverVector4::quantize");
+    }
+    void quantize_parallel(const CloverVector32 &other) { quantize(other); }
+    /* the reference's scalar variant divides by zero on all-zero blocks (:478-479); the SIMD contract is used */
+    void quantize_scalar(const CloverVector32 &other) { quantize(other); }
+
+    void restore(CloverVector32 &other) const
+    {
+        clover_hip::check(clv4_restore(dev_values_ro(), dev_scales_ro(), length_pad, other.device_wo(), nullptr), "CloverVector4::restore");
+    }
+    void restore_scalar(CloverVector32 &other) const { restore(other); }
+
+    float dot(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_EXACT); }
+    float dot_parallel(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
+    float dot_fast(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
+
+    float dot_scalar(const CloverVector4 &other) const
+    {
+        const int8_t *u = values_ro(), *v = other.values_ro();
+        const float *su = scales_ro(), *sv = other.scales_ro();
+        float result = 0;
+        for (uint64_t b = 0; b < length_pad / 64; b++) {
+            int16_t acc = 0;
+            for (uint64_t i = 32 * b; i < 32 * b + 32; i++)
+                acc = (int16_t)(acc + nibble(u[i], 0) * nibble(v[i], 0) + nibble(u[i], 1) * nibble(v[i], 1));
+            result += (su[b] / 7.0f) * (sv[b] / 7.0f) * (float)acc;
+        }
+        return result;
+    }
+
+    /* ---- device views, used by CloverMatrix4 ------------------------------------------------------ */
+    const int8_t *dev_values_ro() const { return reinterpret_cast<const int8_t *>(mem.dev_ro()); }
+    const float *dev_scales_ro() const
+    {
+        if (split_view) return reinterpret_cast<const float *>(view_scales.dev_ro());
+        return reinterpret_cast<const float *>(mem.dev_ro() + value_bytes);
+    }
+    int8_t *dev_values_wo() { return reinterpret_cast<int8_t *>(mem.dev_wo()); }     /* kernels overwrite every used byte */
+    float *dev_scales_wo()
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.dev_wo());
+        return reinterpret_cast<float *>(mem.dev_wo() + value_bytes);
+    }
+
+private:
+    const int8_t *values_ro() const { return reinterpret_cast<const int8_t *>(mem.host_ro()); }
+    const float *scales_ro() const
+    {
+        if (split_view) return reinterpret_cast<const float *>(view_scales.host_ro());
+        return reinterpret_cast<const float *>(mem.host_ro() + value_bytes);
+    }
+    float dot_mode(const CloverVector4 &other, int mode) const
+    {
+        if (other.length_pad != length_pad) {
+            std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        void *out = nullptr;
+        clover_hip::check(clv_malloc(&out, sizeof(float)), "device allocation");
+        clover_hip::check(clv4_dot(dev_values_ro(), dev_scales_ro(), other.dev_values_ro(), other.dev_scales_ro(), length_pad, mode,
+                                   static_cast<float *>(out), nullptr, nullptr), "CloverVector4::dot");
+        float r = 0;
+        clover_hip::check(clv_memcpy_d2h(&r, out, sizeof(float), nullptr), "device->host copy");
+        clv_free(out);
+        return r;
+    }
+};
+
+#endif

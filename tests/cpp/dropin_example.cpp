@@ -1,0 +1,86 @@
+// dropin_example.cpp -- user code written against the reference's class surface (README.md:70-107 style),
+// compiled against THIS repository's include/ and linked with libclover_hip.so.  Prints key=value lines that
+// tests/test_gpu_cpp_dropin.py compares with the oracle / the reference's known answers.
+#include <CloverMatrix32.h>
+#include <CloverMatrix4.h>
+#include <CloverVector32.h>
+#include <CloverVector4.h>
+
+#include <cstdio>
+#include <cstring>
+
+static unsigned bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+
+static void hexdump(const char *key, const int8_t *p, int n)
+{
+    printf("%s=", key);
+    for (int i = 0; i < n; i++) printf("%02x", (unsigned)(uint8_t)p[i]);
+    printf("\n");
+}
+
+int main()
+{
+    // ---- KAT1: the README example -----------------------------------------------------------
+    {
+        const int n = 128;
+        CloverVector32 a_vector_32bit(n), b_vector_32bit(n);
+        float *a = a_vector_32bit.getData();
+        float *b = b_vector_32bit.getData();
+        for (int i = 0; i < n; i += 1) { a[i] = 1; b[i] = 2; }
+        CloverVector4 a_vector_4bit(128), b_vector_4bit(128);
+        a_vector_4bit.quantize(a_vector_32bit);
+        b_vector_4bit.quantize(b_vector_32bit);
+        const float dot = a_vector_4bit.dot(b_vector_4bit);
+        printf("kat1_dot=0x%08x\n", bits(dot));
+        printf("kat1_dot_scalar=0x%08x\n", bits(a_vector_4bit.dot_scalar(b_vector_4bit)));
+        printf("kat1_dot_parallel=%.9g\n", a_vector_4bit.dot_parallel(b_vector_4bit));
+        hexdump("kat1_bytes", a_vector_4bit.getData(), 8);
+        printf("kat1_scales=%g,%g\n", a_vector_4bit.getScales()[0], b_vector_4bit.getScales()[1]);
+        printf("kat1_get=%g bytes=%llu\n", b_vector_4bit.get(5), (unsigned long long)a_vector_4bit.getBytes());
+    }
+    // ---- KAT2: quantize / dot / restore ------------------------------------------------------------
+    {
+        const int n = 256;
+        CloverVector32 x(n), y(n), back(n);
+        for (int i = 0; i < n; i++) {
+            x.set(i, (float)(((37 * i) % 101) - 50) * 0.125f);
+            y.set(i, (float)(((53 * i) % 89) - 44) * 0.0625f);
+        }
+        CloverVector4 qx(x), qy(n);
+        qy.quantize_parallel(y);
+        hexdump("kat2_qx", qx.getData(), 32);
+        hexdump("kat2_qy", qy.getData(), 32);
+        printf("kat2_dot=0x%08x\n", bits(qx.dot(qy)));
+        printf("kat2_dot_scalar=0x%08x\n", bits(qx.dot_scalar(qy)));
+        qx.restore(back);
+        printf("kat2_restore=0x%08x,0x%08x,0x%08x,0x%08x\n", bits(back.get(0)), bits(back.get(1)), bits(back.get(2)), bits(back.get(3)));
+        CloverVector4 copy(qx);                       // copy constructor keeps bytes and scales
+        printf("kat2_copy_dot=0x%08x\n", bits(copy.dot(qy)));
+        CloverVector4 view(n, qx.getData(), qx.getScales());   // non-owning view
+        printf("kat2_view_dot=0x%08x\n", bits(view.dot(qy)));
+    }
+    // ---- KAT3: matrix quantize + mvm ------------------------------------------------------------------
+    {
+        const int M = 128, N = 256;
+        CloverMatrix32 A(M, N);
+        CloverVector32 x(N);
+        for (int r = 0; r < M; r++)
+            for (int c = 0; c < N; c++) A.set(r, c, (float)(((31 * r + 17 * c) % 23) - 11));
+        for (int c = 0; c < N; c++) x.set(c, (float)(((13 * c) % 19) - 9));
+        CloverMatrix4 qA(M, N);
+        CloverVector4 qx(N), r(M), r2(M);
+        qA.quantize(A);
+        qx.quantize(x);
+        qA.mvm(qx, r);
+        qA.mvm_parallel(qx, r2);
+        hexdump("kat3_r", r.getData(), 64);
+        hexdump("kat3_r_parallel", r2.getData(), 64);
+        printf("kat3_scales=0x%08x,0x%08x\n", bits(r.getScales()[0]), bits(r.getScales()[1]));
+        printf("kat3_get=%.5f,%.5f,%.5f,%.5f\n", qA.get(0, 0), qA.get(0, 1), qA.get(0, 2), qA.get(0, 3));
+        // GEMM (new): C = qA * qA^T, spot values
+        CloverMatrix32 C(M, M);
+        qA.gemm(qA, C);
+        printf("gemm_c00=0x%08x gemm_c_1_77=0x%08x\n", bits(C.get(0, 0)), bits(C.get(1, 77)));
+    }
+    return 0;
+}

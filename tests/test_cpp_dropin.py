@@ -1,0 +1,59 @@
+"""The C++ drop-in surface: user code in the reference's style compiles against include/ (CPU check) and,
+on the GPU box, produces the reference's known answers through libclover_hip.so."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from clover_amd.build import build_hip_library, repo_root
+from conftest import bits, kat3_inputs
+
+ROOT = repo_root()
+SRC = ROOT / "tests" / "cpp" / "dropin_example.cpp"
+KAT = json.loads((Path(__file__).parent / "golden" / "kat_reference.json").read_text())
+
+
+def compile_example(out: Path, extra=()):
+    lib = build_hip_library()
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}",
+           str(SRC), "-o", str(out), f"-L{lib.parent}", "-lclover_hip", f"-Wl,-rpath,{lib.parent}",
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", *extra]
+    subprocess.run(cmd, check=True)
+
+
+def test_dropin_example_compiles_and_links(tmp_path):
+    # host language of the reference is C++11 (CMakeLists.txt:44-76); the headers must build with it
+    compile_example(tmp_path / "dropin")
+    for hdr in ("CloverVector32.h", "CloverVector4.h", "CloverMatrix32.h", "CloverMatrix4.h"):
+        subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", f"-I{ROOT / 'include'}", str(ROOT / "include" / hdr)], check=True)
+
+
+@pytest.mark.gpu
+def test_dropin_example_matches_reference_answers(tmp_path, oracle):
+    exe = tmp_path / "dropin"
+    compile_example(exe)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=300).stdout
+    kv = {}
+    for line in out.splitlines():
+        for tok in line.split():
+            if "=" in tok:
+                k, v = tok.split("=", 1)
+                kv[k] = v
+    assert kv["kat1_dot"] == KAT["KAT1"]["dot_bits"] and kv["kat1_dot_scalar"] == KAT["KAT1"]["dot_scalar_bits"]
+    assert float(kv["kat1_dot_parallel"]) == 256.0 and kv["kat1_bytes"] == "77" * 8 and kv["kat1_scales"] == "1,2"
+    assert kv["kat1_get"] == "2" and kv["bytes"] == "72"
+    assert kv["kat2_qx"] == KAT["KAT2"]["qx_bytes_0_31"] and kv["kat2_qy"] == KAT["KAT2"]["qy_bytes_0_31"]
+    assert kv["kat2_dot"] == KAT["KAT2"]["dot_bits"] and kv["kat2_dot_scalar"] == KAT["KAT2"]["dot_scalar_bits"]
+    assert kv["kat2_copy_dot"] == KAT["KAT2"]["dot_bits"] and kv["kat2_view_dot"] == KAT["KAT2"]["dot_bits"]
+    assert kv["kat2_restore"].split(",") == KAT["KAT2"]["restore_qx_0_3_bits"]
+    assert kv["kat3_r"] == KAT["KAT3"]["r_bytes_0_63"] and kv["kat3_r_parallel"] == KAT["KAT3"]["r_bytes_0_63"]
+    assert kv["kat3_scales"].split(",") == KAT["KAT3"]["r_scale_bits"]
+    np.testing.assert_allclose([float(v) for v in kv["kat3_get"].split(",")], KAT["KAT3"]["qA_get_0_0_3"], atol=1e-5)
+    # GEMM spot values vs the oracle's definition
+    A, _ = kat3_inputs()
+    qA, sA = oracle.m4_quantize(A)
+    C = oracle.m4_gemm(qA, sA, 128, 256, qA, sA, 128)
+    assert kv["gemm_c00"] == hex(bits(C[0, 0])) or int(kv["gemm_c00"], 16) == int(bits(C[0, 0]))
+    assert int(kv["gemm_c_1_77"], 16) == int(bits(C[1, 77]))
