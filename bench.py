@@ -277,7 +277,24 @@ def extras(hip, torch, dev, stream) -> dict:
     f_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_FAST, o.data_ptr(), None, stream)), 50)
     e_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_EXACT, o.data_ptr() + 4, None, stream)), 5)
     vals = o.cpu().numpy()
+    # configs[3]: gemm 8192^3 (int8 MFMA, fp32 per-K-block epilogue)
+    G = 8192
+    gA = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
+    gB = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
+    gsA = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
+    gsB = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
+    gC = torch.empty(G * G, dtype=torch.float32, device=dev)
+    for t, sd in ((gA, 21), (gB, 22)):
+        hip.check(lib.clv_fill_random_nibbles(t.data_ptr(), t.numel(), sd, 0, stream))
+    for t, sd in ((gsA, 23), (gsB, 24)):
+        hip.check(lib.clv_fill_random_scales(t.data_ptr(), t.numel(), sd, 0, stream))
+    g_ms = timeit(lambda: hip.check(lib.clm4_gemm(gA.data_ptr(), gsA.data_ptr(), G, G, gB.data_ptr(), gsB.data_ptr(), G, gC.data_ptr(), stream)), 10)
+    gemm = {"ms": round(g_ms, 4), "TOP/s": round(2.0 * G ** 3 / g_ms / 1e9, 1),
+            "frac_of_int8_mfma_peak": round(2.0 * G ** 3 / g_ms / 1e9 / 5000.0, 4),
+            "note": "int4 x int4 via v_mfma_i32_16x16x64_i8 (nibbles widened to int8 in LDS), peak = 5 POP/s dense int8"}
+    del gA, gB, gC
     return {
+        "gemm_8192^3": gemm,
         "note": "n=2^24 operands (76.5 MB / 18.9 MB) fit the Infinity Cache: cache-resident rates, not HBM-roofline claims",
         "quantize_n2^24": {"ms": round(q_ms, 5), "GB/s": round(4.5625 * n / q_ms / 1e6, 1)},
         "dot_fast_n2^24": {"ms": round(f_ms, 5), "GB/s": round(1.125 * n / f_ms / 1e6, 1), "GFLOP/s": round(2 * n / f_ms / 1e6, 1)},

@@ -4,6 +4,9 @@
 // then one fp32 scale per 64x64 tile in a row-major (rows/64) x (cols/64) grid.
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 // ================================================================================================
 // mvm  (CloverMatrix4.h:777-1083)
 // ================================================================================================
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(256) void k_m4_gemm_simple(const uint8_t *__restric
 // ================================================================================================
 int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng, hipStream_t st);
 int clm4_requantize_stochastic(const float *d, uint64_t rows, int8_t *r, float *sr, uint64_t *rng, hipStream_t st);
+int clm4_gemm_mfma(const int8_t *A, const float *sA, uint64_t M, uint64_t K, const int8_t *B, const float *sB, uint64_t N, float *C, hipStream_t st);
 
 static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
                       float *d, int8_t *r, float *sr, hipStream_t st)
@@ -256,6 +260,8 @@ extern "C" int clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t 
     CLV_REQUIRE(M % 128 == 0 && N % 128 == 0 && K % 128 == 0, "clm4_gemm: M=%llu N=%llu K=%llu must be multiples of 128",
                 (unsigned long long)M, (unsigned long long)N, (unsigned long long)K);
     if (!M || !N) return CLV_OK;
+    static const bool use_simple = [] { const char *e = getenv("CLV_GEMM_KERNEL"); return e && !strcmp(e, "simple"); }();
+    if (!use_simple && K > 0) return clm4_gemm_mfma(A, sA, M, K, B, sB, N, C, as_stream(stream));
     hipLaunchKernelGGL(k_m4_gemm_simple, dim3((unsigned)(N / 16), (unsigned)(M / 16)), dim3(256), 0, as_stream(stream),
                        (const uint8_t *)A, sA, M, K, (const uint8_t *)B, sB, N, C);
     CLV_LAUNCH_CHECK();

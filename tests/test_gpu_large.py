@@ -1,0 +1,113 @@
+"""GPU parity at BASELINE.json's full sizes, through size-independent properties and sampled oracle checks
+(the scalar oracle cannot finish a 65536 x 65536 mvm in seconds; the AVX2 port and sampling can).
+
+  C2  quantize + dot, n = 2^24         : bit-exact vs the AVX2 restatement (itself == scalar oracle)
+  C3  mvm 65536 x 65536                : sampled 64-row output blocks vs the scalar oracle; shard == whole
+  C4  gemm (8192^3 is ~1e12 ops)       : 2048^3 here, sampled elements vs the oracle's definition
+  C5  row sharding                     : concatenated shard results == unsharded result, byte for byte
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+
+
+def test_c2_quantize_dot_2p24(hip, fast_oracle):
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST
+    n = 1 << 24
+    rng = np.random.default_rng(24)
+    x = rng.integers(-10, 11, size=n).astype(np.float32)
+    y = rng.integers(-10, 11, size=n).astype(np.float32)
+    qx, sx = hip.v4_quantize(x)
+    qy, sy = hip.v4_quantize(y)
+    fx, fsx = fast_oracle.v4_quantize(x)
+    assert same(qx, fx) and same(sx, fsx)
+    d_exact = hip.v4_dot(qx, sx, qy, sy, mode=DOT_EXACT)
+    assert bits(d_exact) == bits(fast_oracle.v4_dot(qx, sx, qy, sy))            # reference order, 131072 steps per chain
+    d_fast = hip.v4_dot(qx, sx, qy, sy, mode=DOT_FAST)
+    # only the fp32 summation order differs: relative 1e-5 (the two CPU orders of the reference differ by 372 ulp here)
+    assert abs(float(d_fast) - float(d_exact)) <= 1e-5 * abs(float(d_exact)) + 1e-3
+    # encode -> decode round trip: |x - restore(q)| <= scale / 7 per block (truncation), sign preserved
+    xr = hip.v4_restore(qx, sx)
+    assert np.all(np.abs(x - xr) <= np.repeat(sx, 64) / np.float32(7.0) + 1e-6)
+    assert np.all(np.sign(xr) * np.sign(x) >= 0)
+
+
+def _device_matrix(hip, rows, cols, seed):
+    A = hip.alloc(rows * cols // 2)
+    sA = hip.alloc((rows // 64) * (cols // 64) * 4)
+    x = hip.alloc(cols // 2)
+    sx = hip.alloc(cols // 64 * 4)
+    hip.check(hip.lib.clv_fill_random_nibbles(A.ptr, A.nbytes, seed, 0, None))
+    hip.check(hip.lib.clv_fill_random_scales(sA.ptr, sA.nbytes // 4, seed + 1, 0, None))
+    hip.check(hip.lib.clv_fill_random_nibbles(x.ptr, x.nbytes, seed + 2, 0, None))
+    hip.check(hip.lib.clv_fill_random_scales(sx.ptr, sx.nbytes // 4, seed + 3, 0, None))
+    return A, sA, x, sx
+
+
+def _download(hip, ptr, nbytes, dtype):
+    out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+    hip.check(hip.lib.clv_memcpy_d2h(out.ctypes.data, ptr, nbytes, None))
+    return out
+
+
+def test_c3_mvm_65536_sampled_and_sharded(hip, oracle):
+    rows = cols = 65536
+    hb = cols // 64
+    A, sA, x, sx = _device_matrix(hip, rows, cols, 0xC3)
+    r = hip.alloc(rows // 2)
+    sr = hip.alloc(rows // 64 * 4)
+    hip.check(hip.lib.clm4_mvm(A.ptr, sA.ptr, rows, cols, x.ptr, sx.ptr, r.ptr, sr.ptr, None, None))
+    r_h, sr_h = r.download(np.uint8), sr.download(np.float32)
+    # the synthetic fill really is nibbles in [-7,7] and scales in [0.5,2)
+    qx, sxh = x.download(np.uint8), sx.download(np.float32)
+    assert ((qx >> 4) != 8).all() and ((qx & 0xF) != 8).all() and sxh.min() >= 0.5 and sxh.max() < 2.0
+    # sampled 64-row output blocks against the scalar oracle
+    for g in (0, 1, 511, 777, 1023):
+        blk = _download(hip, A.ptr + g * 64 * cols // 2, 64 * cols // 2, np.uint8)
+        sblk = _download(hip, sA.ptr + g * hb * 4, hb * 4, np.float32)
+        d = oracle.m4_rowdots(blk, sblk, 64, cols, qx, sxh)
+        ro, sro = oracle.v4_quantize(np.concatenate([d, np.zeros(64, np.float32)]))
+        assert same(r_h[g * 32:(g + 1) * 32], ro[:32]) and bits(sr_h[g]) == bits(sro[0])
+    # C5 property: 8 contiguous row shards (as 8 GPUs would hold them) reproduce the whole result byte for byte
+    shard = rows // 8
+    parts_r, parts_s = [], []
+    for k in range(8):
+        rk, srk = hip.alloc(shard // 2), hip.alloc(shard // 64 * 4)
+        hip.check(hip.lib.clm4_mvm(A.ptr + k * shard * cols // 2, sA.ptr + k * (shard // 64) * hb * 4, shard, cols,
+                                   x.ptr, sx.ptr, rk.ptr, srk.ptr, None, None))
+        parts_r.append(rk.download(np.uint8))
+        parts_s.append(srk.download(np.float32))
+    assert same(np.concatenate(parts_r), r_h) and same(np.concatenate(parts_s), sr_h)
+
+
+def test_gemm_2048_sampled(hip, oracle):
+    M = N = K = 2048
+    kb = K // 64
+    A, sA, _, _ = _device_matrix(hip, M, K, 0x6E)
+    B, sB, _, _ = _device_matrix(hip, N, K, 0x6F)
+    Cd = hip.alloc(M * N * 4)
+    hip.check(hip.lib.clm4_gemm(A.ptr, sA.ptr, M, K, B.ptr, sB.ptr, N, Cd.ptr, None))
+    Ch = Cd.download(np.float32).reshape(M, N)
+    qA, qB = A.download(np.uint8), B.download(np.uint8)
+    sAh, sBh = sA.download(np.float32), sB.download(np.float32)
+    rng = np.random.default_rng(1)
+    rows = sorted(set([0, 63, 64, 127, 128, M - 1] + rng.integers(0, M, 6).tolist()))
+    cols = sorted(set([0, 15, 16, 64, 129, N - 1] + rng.integers(0, N, 6).tolist()))
+    # the GEMM definition evaluated element by element (exact product + one rounding = fmaf)
+    for i in rows:
+        for j in cols:
+            acc = np.float32(0)
+            S = oracle.v4_word_isums(qA[i * K // 2:(i + 1) * K // 2], qB[j * K // 2:(j + 1) * K // 2]).reshape(kb, 8).sum(1)
+            for b in range(kb):
+                c = np.float32(np.float32(sAh[(i >> 6) * kb + b] * np.float32(1.0 / 49.0)) * sBh[(j >> 6) * kb + b])
+                acc = np.float32(np.float64(c) * np.float64(S[b]) + np.float64(acc))
+            assert bits(acc) == bits(Ch[i, j]), (i, j)
