@@ -30,6 +30,20 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def pmc_traffic(rows: int, cols: int):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/rNN_mvm_c3_pmc.json); PMC cannot
+    be collected inside a timed run, so the latest committed measurement of the same kernel + shape is reported."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_mvm_c3_pmc.json")):
+        try:
+            d = json.loads(f.read_text())["mvm_c3"]
+            if d["rows"] == rows and d["cols"] == cols:
+                best = (round(d["traffic_bytes_per_launch"]), f.name)
+        except (OSError, KeyError, ValueError):
+            continue
+    return best
+
+
 def mvm_bytes(rows: int, cols: int) -> int:
     """Algorithmic bytes of one mvm: every operand incl. scales counted once."""
     return rows * cols // 2 + 4 * (rows // 64) * (cols // 64) + (cols // 2 + cols // 16) + (rows // 2 + rows // 16)
@@ -228,6 +242,11 @@ def main() -> None:
             "kernel": "k_m4_mvm64", "kernel_avg_ms": round(kern_avg_ms, 5), "algorithmic_bytes_per_launch": bytes_gpu,
         },
     }
+
+    tr = pmc_traffic(rows, cols)
+    if tr:
+        out["roofline"]["traffic"] = tr[0]
+        out["roofline"]["traffic_source"] = f"profiles/{tr[1]} (FETCH_SIZE x1024 x2 gfx950 correction + WRITE_SIZE x1024, per launch)"
 
     if world == 1 and not args.no_cpu_baseline:
         try:

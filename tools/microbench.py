@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Kernel-variant sweep on the GPU box (not part of the product): read-bandwidth ceiling and mvm variants."""
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clover_amd.lib_binding import CloverHip  # noqa: E402
+
+hip = CloverHip()
+lib = hip.lib
+vp, u64 = C.c_void_p, C.c_uint64
+lib.clvx_read_bw.argtypes = [vp, u64, C.c_int, C.c_int, vp, vp]
+lib.clvx_mvm_variant.argtypes = [C.c_int, vp, vp, u64, u64, vp, vp, vp, vp, vp]
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    hip.sync()
+    a, b = vp(), vp()
+    hip.check(lib.clv_event_create(C.byref(a)))
+    hip.check(lib.clv_event_create(C.byref(b)))
+    ts = []
+    for _ in range(5):
+        hip.check(lib.clv_event_record(a, None))
+        for _ in range(reps):
+            fn()
+        hip.check(lib.clv_event_record(b, None))
+        hip.check(lib.clv_event_sync(b))
+        ms = C.c_float()
+        hip.check(lib.clv_event_elapsed_ms(a, b, C.byref(ms)))
+        ts.append(ms.value / reps)
+    return sorted(ts)[len(ts) // 2]
+
+
+res = {}
+big = hip.alloc(2 << 30)
+hip.check(lib.clv_fill_random_nibbles(big.ptr, big.nbytes, 1, 0, None))
+out = hip.alloc(256)
+for nt in (0, 1):
+    for bpc in (4, 8, 16):
+        ms = timeit(lambda: hip.check(lib.clvx_read_bw(big.ptr, big.nbytes, nt, bpc, out.ptr, None)))
+        res[f"read_bw_2GiB_nt{nt}_bpc{bpc}"] = round(big.nbytes / ms / 1e6, 1)
+
+
+def mvm_bytes(rows, cols):
+    return rows * cols // 2 + 4 * (rows // 64) * (cols // 64) + (cols // 2 + cols // 16) + (rows // 2 + rows // 16)
+
+
+for (rows, cols) in ((65536, 65536), (32768, 32768), (16384, 16384), (8192, 8192), (131072, 32768), (16384, 131072)):
+    sA = hip.alloc((rows // 64) * (cols // 64) * 4)
+    x, sx = hip.alloc(cols // 2), hip.alloc(cols // 16)
+    r, sr = hip.alloc(rows // 2), hip.alloc(rows // 16)
+    hip.check(lib.clv_fill_random_scales(sA.ptr, sA.nbytes // 4, 2, 0, None))
+    hip.check(lib.clv_fill_random_nibbles(x.ptr, x.nbytes, 3, 0, None))
+    hip.check(lib.clv_fill_random_scales(sx.ptr, sx.nbytes // 4, 4, 0, None))
+    ref = None
+    for v in range(5):
+        fn = lambda: hip.check(lib.clvx_mvm_variant(v, big.ptr, sA.ptr, rows, cols, x.ptr, sx.ptr, r.ptr, sr.ptr, None))
+        ms = timeit(fn)
+        got = (r.download(np.uint8).tobytes(), sr.download(np.float32).tobytes())
+        if ref is None:
+            ref = got
+        res[f"mvm_{rows}x{cols}_v{v}"] = {"us": round(ms * 1e3, 2), "GB/s": round(mvm_bytes(rows, cols) / ms / 1e6, 1), "same_as_v0": got == ref}
+print(json.dumps(res, indent=1))
