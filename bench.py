@@ -139,6 +139,7 @@ def main() -> None:
     import torch.distributed as dist
 
     from clover_amd.lib_binding import DOT_EXACT, DOT_FAST, CloverHip
+    from clover_amd.sharding import gather_packed, packed_bytes, partition_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -173,10 +174,9 @@ def main() -> None:
     hip.check(lib.clv_fill_random_scales(sx.data_ptr(), sx.numel(), seed + 3, 0, stream))
 
     # packed result of this rank: [rows/2 nibble bytes | rows/64 fp32 scales]; gathered as one buffer
-    shard_bytes = rows // 2 + 4 * (rows // 64)
-    res = torch.empty(shard_bytes, dtype=torch.uint8, device=dev)
+    assert partition_rows(rows_total, world, rank) == (rank * rows, rows)     # weak scaling: equal contiguous shards
+    res = torch.empty(packed_bytes(rows), dtype=torch.uint8, device=dev)
     r_ptr, sr_ptr = res.data_ptr(), res.data_ptr() + rows // 2
-    gathered = torch.empty(shard_bytes * world, dtype=torch.uint8, device=dev) if world > 1 else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -187,7 +187,7 @@ def main() -> None:
         if i is not None:
             ev[i][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, res)
+            gather_packed(res, rows_total)        # RCCL all-gather of [nibbles | scales] from every rank
 
     for _ in range(args.warmup):
         step(None)

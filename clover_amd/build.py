@@ -49,8 +49,7 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> Path:
     out.parent.mkdir(parents=True, exist_ok=True)
     if force or _stale(out, deps):
         cmd = [_hipcc(), *HIP_FLAGS, f"-I{root / 'include'}", f"-I{src_dir}", "-o", str(out), *map(str, srcs)]
-        if any(s.name == "multi.hip" for s in srcs):
-            cmd += ["-L/opt/rocm/lib", "-lrccl"]
+        cmd += ["-ldl"]          # RCCL is dlopen'ed lazily by multi.hip
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

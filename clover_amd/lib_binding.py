@@ -54,6 +54,14 @@ SIGNATURES = {
     "clm4_mvm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clm4_rowdots": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clm4_gemm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
+    "clm4_shard_partition": (C.c_int, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
+    "clm4_sharded_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), _u64, _u64]),
+    "clm4_sharded_destroy": (C.c_int, [_vp]),
+    "clm4_sharded_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_vp), C.POINTER(_vp)]),
+    "clm4_sharded_upload": (C.c_int, [_vp, _vp, _vp]),
+    "clm4_sharded_fill_random": (C.c_int, [_vp, _u64]),
+    "clm4_sharded_mvm": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "clm4_sharded_result": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     "clv_fill_random_nibbles": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),
     "clv_fill_random_scales": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),
     "clv_fill_random_ints_f32": (C.c_int, [_vp, _u64, C.c_int, _u64, _u64, _vp]),

@@ -115,6 +115,24 @@ int  clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols
 int  clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K,
                const int8_t *B, const float *sB, uint64_t N, float *C, void *stream);
 
+/* ---- multi-GPU: row-sharded mvm on the GPUs of one node (one process, RCCL over xGMI) --------------- */
+/* MI355X counterpart of mvm_parallel's contiguous split of 64-row blocks over threads
+ * (CloverMatrix4.h:1700-1705): shard `part` owns a contiguous multiple of 64 rows, x is replicated, the
+ * packed result is all-gathered; no partial sums cross devices, so results equal clm4_mvm bit for bit. */
+typedef struct clm4_shard_ctx clm4_shard_ctx;
+int  clm4_shard_partition(uint64_t rows, int nparts, int part, uint64_t *row_begin, uint64_t *row_count);
+int  clm4_sharded_create(clm4_shard_ctx **ctx, int ndev, const int *devices /* NULL: 0..ndev-1 */, uint64_t rows, uint64_t cols);
+int  clm4_sharded_destroy(clm4_shard_ctx *ctx);
+int  clm4_sharded_info(const clm4_shard_ctx *ctx, int part, int *device, uint64_t *row_begin, uint64_t *row_count,
+                       int8_t **A_dev, float **sA_dev);
+/* scatter a whole matrix in the reference layout from host memory */
+int  clm4_sharded_upload(clm4_shard_ctx *ctx, const int8_t *A_host, const float *sA_host);
+/* synthetic matrix: the bytes clv_fill_random_nibbles/scales(seed, seed+1) give for the unsharded matrix */
+int  clm4_sharded_fill_random(clm4_shard_ctx *ctx, uint64_t seed);
+/* r = A*x; every device ends with the full packed result; r_host/sr_host (optional) receive a copy */
+int  clm4_sharded_mvm(clm4_shard_ctx *ctx, const int8_t *x, const float *sx, int x_on_host, int8_t *r_host, float *sr_host);
+int  clm4_sharded_result(const clm4_shard_ctx *ctx, int part, const int8_t **r_dev, const float **sr_dev);
+
 /* ---- synthetic data (bench / tests): fills device buffers without an fp32 source ------------------ */
 /* nibbles uniform in [-7,7], scales uniform in [0.5,2): counter-based splitmix64 of (seed, index), so any
  * row range of a sharded matrix regenerates independently. */

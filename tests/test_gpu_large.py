@@ -111,3 +111,38 @@ def test_gemm_2048_sampled(hip, oracle):
                 c = np.float32(np.float32(sAh[(i >> 6) * kb + b] * np.float32(1.0 / 49.0)) * sBh[(j >> 6) * kb + b])
                 acc = np.float32(np.float64(c) * np.float64(S[b]) + np.float64(acc))
             assert bits(acc) == bits(Ch[i, j]), (i, j)
+
+
+def test_sharded_c_api_single_process(hip, oracle):
+    """clm4_sharded_* (one process, N devices, RCCL gather): with the devices visible here (1 on the test
+    box; 8 on a full node) the gathered result must equal the unsharded clm4_mvm byte for byte."""
+    vp, u64 = C.c_void_p, C.c_uint64
+    lib = hip.lib
+    rows, cols = 1024, 2048
+    ndev = hip.device_count
+    ctx = vp()
+    hip.check(lib.clm4_sharded_create(C.byref(ctx), ndev, None, rows, cols))
+    try:
+        hip.check(lib.clm4_sharded_fill_random(ctx, 77))
+        # the same matrix, unsharded
+        A, sA = hip.alloc(rows * cols // 2), hip.alloc((rows // 64) * (cols // 64) * 4)
+        hip.check(lib.clv_fill_random_nibbles(A.ptr, A.nbytes, 77, 0, None))
+        hip.check(lib.clv_fill_random_scales(sA.ptr, sA.nbytes // 4, 78, 0, None))
+        rng = np.random.default_rng(5)
+        qx = (rng.integers(0, 256, size=cols // 2, dtype=np.uint8) & 0x77).astype(np.uint8)
+        sx = rng.uniform(0.5, 2, size=cols // 64).astype(np.float32)
+        r, sr = np.zeros(rows // 2, np.uint8), np.zeros(rows // 64, np.float32)
+        hip.check(lib.clm4_sharded_mvm(ctx, qx.ctypes.data, sx.ctypes.data, 1, r.ctypes.data, sr.ctypes.data))
+        r1, sr1 = hip.m4_mvm(A.download(np.uint8), sA.download(np.float32), rows, cols, qx, sx)
+        assert same(r, r1) and same(sr, sr1)
+        ro, sro = oracle.m4_mvm(A.download(np.uint8), sA.download(np.float32), rows, cols, qx, sx)
+        assert same(r, ro) and same(sr, sro)
+        # upload path: scatter a host matrix
+        hip.check(lib.clm4_sharded_upload(ctx, A.download(np.uint8).ctypes.data, sA.download(np.float32).ctypes.data))
+        hip.check(lib.clm4_sharded_mvm(ctx, qx.ctypes.data, sx.ctypes.data, 1, r.ctypes.data, sr.ctypes.data))
+        assert same(r, ro)
+        b, c = u64(), u64()
+        hip.check(lib.clm4_sharded_info(ctx, ndev - 1, None, C.byref(b), C.byref(c), None, None))
+        assert b.value + c.value == rows
+    finally:
+        hip.check(lib.clm4_sharded_destroy(ctx))
