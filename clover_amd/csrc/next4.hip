@@ -1,0 +1,411 @@
+// next4.hip -- the callers either side of the hot path: scaleAndAdd, transpose, threshold.
+// Together with mvm these are all five steps of the reference's quantized IHT / GD iterations
+// (test/performance/01_measure.h:923-946, 999-1021), so x, t1..t3 can stay in HBM across iterations.
+#include "common.h"
+
+// =================================================================================================
+// f1  CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478):  r = quantize(u + a * v), per 64-block
+//     val = fma((float)qv, f32(f32(sv*a)/7), (float)qu * f32(su/7));  lane = one dword of u and of v.
+//     algorithmic bytes: 3 * (1/2 + 1/16) = 1.6875 per element.
+// =================================================================================================
+__device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, float sv7, float v[8])
+{
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float du = (float)unpack1(wu, e) * su7;
+        v[e] = __builtin_fmaf((float)unpack1(wv, e), sv7, du);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_v4_scale_and_add(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
+                                                          const float *__restrict__ sv, float a, uint32_t *r, float *sr,
+                                                          uint64_t nwords)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint64_t b = i >> 3;
+        const float su7 = su[b] / 7.0f;
+        const float sv7 = (sv[b] * a) / 7.0f;
+        float v[8];
+        saa_values(qu[i], qv[i], su7, sv7, v);
+        float m = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        m = fmaxf(m, __shfl_xor(m, 4));
+        m = fix_zero_max(m);
+        const float k = 7.0f / m;
+        int q[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) q[e] = quant1(v[e], k, 0.0f);
+        r[i] = pack8(q);
+        if ((i & 7) == 0) sr[b] = m;
+    }
+}
+
+// stochastic variant: same segment walk as k_v4_quantize_st (rng4.hip); the nibbles are unpacked by bit
+// position there, so noise group g of AVX lane j meets element 8j + (g ^ 1) (CloverVector4.h:1236-1243).
+__host__ __device__ __forceinline__ uint64_t xs_T2(uint64_t a)
+{
+    const uint64_t t = a ^ (a << 23);
+    return t ^ a ^ (t >> 18) ^ (a >> 5);
+}
+
+__global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
+                                                             const float *__restrict__ sv, float a, uint32_t *r, float *sr,
+                                                             uint64_t nblocks, const uint64_t *__restrict__ starts)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][64 * 2 * 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t *raw = raw_all[wave];
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t blk0 = w * 128;
+    const int seg = lane >> 2, k = lane & 3;
+    const uint64_t seg_idx = w * 16 + seg;
+    uint64_t st = (seg_idx * 8 < nblocks) ? starts[seg_idx * 4 + k] : 0;
+    for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                     // 4 blocks x 2 draws of this lane's segment
+            const uint64_t n = xs_T2(st);
+            raw[(size_t)(4 * seg) * 8 + i * 4 + k] = n + st;
+            st = n;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int u = 0; u < 8; u++) {
+            const int bl = 8 * u + (lane >> 3), rho = lane & 7;
+            const uint64_t blk = blk0 + (uint64_t)(bl >> 2) * 8 + 4 * rr + (bl & 3);
+            if (blk < nblocks) {
+                const uint64_t i = blk * 8 + rho;
+                float v[8];
+                saa_values(qu[i], qv[i], su[blk] / 7.0f, (sv[blk] * a) / 7.0f, v);
+                float m = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+                m = fmaxf(m, __shfl_xor(m, 1));
+                m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, __shfl_xor(m, 4));
+                m = fix_zero_max(m);
+                const float kq = 7.0f / m;
+                const uint32_t *W32 = reinterpret_cast<const uint32_t *>(raw + (size_t)(bl * 2) * 4);
+                const uint32_t Wd[2] = {W32[rho], W32[8 + rho]};          // W[j = rho] of draw 0 and draw 1
+                int q[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int g = e ^ 1;
+                    const float noise = (float)(int)((Wd[g >> 2] & 0x7F7F7F7Fu) << (8 * (g & 3))) * (1.0f / 2147483648.0f);
+                    q[e] = quant1(v[e], kq, noise);
+                }
+                r[i] = pack8(q);
+                if (rho == 0) sr[blk] = m;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int clv_rng_prefix(uint64_t *state, uint64_t count, int shift, uint64_t total, uint64_t **starts, uint64_t **fin, hipStream_t st);
+int clv_rng_commit(uint64_t *state, const uint64_t *fin, hipStream_t st);
+
+extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
+                                  int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream)
+{
+    CLV_REQUIRE(qu && su && qv && sv && r && sr, "clv4_scale_and_add: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv4_scale_and_add: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    if (!n_pad) return CLV_OK;
+    hipStream_t st = as_stream(stream);
+    const uint64_t nwords = n_pad / 8, nb = n_pad / 64;
+    if (!rng_state_dev) {
+        const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+        hipLaunchKernelGGL(k_v4_scale_and_add, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const uint32_t *)qu, su,
+                           (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nwords);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
+    uint64_t *starts, *fin;
+    int rc = clv_rng_prefix(rng_state_dev, (nb + 7) / 8, 4, 2 * nb, &starts, &fin, st);
+    if (rc) return rc;
+    const uint64_t waves = (nb + 127) / 128;
+    hipLaunchKernelGGL(k_v4_scale_and_add_st, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const uint32_t *)qu, su,
+                       (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, starts);
+    CLV_LAUNCH_CHECK();
+    return clv_rng_commit(rng_state_dev, fin, st);
+}
+
+// =================================================================================================
+// f2  CloverMatrix4::transpose (CloverMatrix4.h:1549-1663): out(j,i) = in(i,j) nibble-wise, tile scales
+//     transposed (the reference calls IPP for those, :1657-1658).
+//     thread = one 8x8 nibble block: 8 dwords in (one per row), 8 dwords out; WG = one 64x64 tile.
+// =================================================================================================
+__global__ __launch_bounds__(64) void k_m4_transpose(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t rows,
+                                                     uint64_t cols, uint32_t *__restrict__ qt, float *__restrict__ st,
+                                                     uint32_t tiles_x)
+{
+    const uint32_t bj = blockIdx.x % tiles_x;
+    const uint64_t bi = blockIdx.x / tiles_x;
+    const int cb = threadIdx.x & 7, rb = threadIdx.x >> 3;
+    const uint64_t wcols = cols / 8, wrows = rows / 8;       // words per row of in / out
+    uint32_t w[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) w[r] = q[(bi * 64 + rb * 8 + r) * wcols + bj * 8 + cb];
+    uint32_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc |= ((w[r] >> nib_shift(e)) & 0xFu) << nib_shift(r);
+        o[e] = acc;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) qt[((uint64_t)bj * 64 + cb * 8 + e) * wrows + bi * 8 + rb] = o[e];
+    if (threadIdx.x == 0) st[(uint64_t)bj * (rows / 64) + bi] = s[bi * tiles_x + bj];
+}
+
+extern "C" int clm4_transpose(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, int8_t *qt, float *st, void *stream)
+{
+    CLV_REQUIRE(q && s && qt && st, "clm4_transpose: null pointer");
+    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "clm4_transpose: rows=%llu cols=%llu must be multiples of 128",
+                (unsigned long long)rows, (unsigned long long)cols);
+    CLV_REQUIRE(q != qt, "clm4_transpose: in-place transposition is not supported");
+    const uint64_t tiles = (rows / 64) * (cols / 64);
+    CLV_REQUIRE(tiles <= 0x7FFFFFFFull, "clm4_transpose: too many tiles");
+    if (!tiles) return CLV_OK;
+    hipLaunchKernelGGL(k_m4_transpose, dim3((unsigned)tiles), dim3(64), 0, as_stream(stream), (const uint32_t *)q, s, rows, cols,
+                       (uint32_t *)qt, st, (uint32_t)(cols / 64));
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+// =================================================================================================
+// f3  CloverVector4::threshold(K) (CloverVector4.h:1913-1975): keep the K largest |value| among the first n
+//     elements, zero the other nibbles, scales untouched.  The reference walks a K-entry min-heap
+//     sequentially (O(n log K)); here: exact radix select on the fp32 bit pattern of
+//     |value| = |f32(s/7) * q| (12 + 12 + 8 bits, three histogram passes over 0.56 B/element), then
+//     one pass that keeps everything above the K-th value and the lowest-index ties.
+//     The kept multiset of magnitudes is identical to the reference's; WHICH of several equal magnitudes
+//     survive is heap-order dependent there and lowest-index-first here.
+// =================================================================================================
+struct ThreshState {
+    uint32_t prefix;      // selected high bits so far
+    uint32_t remaining;   // how many elements still to take inside the selected bin
+    uint32_t tau;         // final: bit pattern of the K-th largest magnitude
+    uint32_t ties_keep;   // final: how many elements == tau survive
+};
+
+__device__ __forceinline__ uint32_t mag_key(uint32_t w, int e, float s7)
+{
+    return __float_as_uint(__builtin_fabsf(s7 * (float)unpack1(w, e)));
+}
+
+// level 0: bins = key >> 20 (4096); level 1: key>>20 == prefix, bins = (key >> 8) & 0xFFF; level 2:
+// key>>8 == prefix, bins = key & 0xFF
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_thresh_hist(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n,
+                                                     const ThreshState *__restrict__ ts, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t lh[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t prefix = LEVEL ? ts->prefix : 0;
+    const uint64_t nwords = (n + 7) / 8;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint32_t w = q[i];
+        const float s7 = s[i >> 3] / 7.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (i * 8 + e >= n) break;
+            const uint32_t key = mag_key(w, e, s7);
+            if (LEVEL == 0) atomicAdd(&lh[key >> 20], 1u);
+            else if (LEVEL == 1) { if ((key >> 20) == prefix) atomicAdd(&lh[(key >> 8) & 0xFFF], 1u); }
+            else { if ((key >> 8) == prefix) atomicAdd(&lh[key & 0xFF], 1u); }
+        }
+    }
+    __syncthreads();
+    const int nb = LEVEL == 2 ? 256 : 4096;
+    for (int i = threadIdx.x; i < nb; i += 256) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// one WG: walk the histogram from the top until `remaining` is covered
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_thresh_select(uint32_t *__restrict__ hist, ThreshState *__restrict__ ts, uint32_t k)
+{
+    __shared__ uint32_t part[256];
+    const int nb = LEVEL == 2 ? 256 : 4096;
+    const int per = nb / 256;
+    const int t = threadIdx.x;
+    uint32_t sum = 0;
+    for (int i = 0; i < per; i++) sum += hist[(255 - t) * per + i];          // thread t owns the t-th chunk from the top
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t need = LEVEL == 0 ? k : ts->remaining;
+        uint32_t above = 0;
+        int c = 0;
+        while (c < 255 && above + part[c] < need) { above += part[c]; c++; }
+        int bin = (255 - c) * per + per - 1;
+        while (bin > (255 - c) * per && above + hist[bin] < need) { above += hist[bin]; bin--; }
+        const uint32_t prev = LEVEL == 0 ? 0 : ts->prefix;
+        const uint32_t prefix = LEVEL == 0 ? (uint32_t)bin : (LEVEL == 1 ? (prev << 12) | (uint32_t)bin : (prev << 8) | (uint32_t)bin);
+        ts->prefix = prefix;
+        ts->remaining = need - above;
+        if (LEVEL == 2) { ts->tau = prefix; ts->ties_keep = need - above; }
+    }
+    __syncthreads();
+    for (int i = t; i < nb; i += 256) hist[i] = 0;                           // ready for the next level
+}
+
+// chunked (not grid-stride) so that index order = (block, thread, element)
+#define TH_WORDS_PER_BLOCK 2048      // 8 words per thread
+
+__global__ __launch_bounds__(256) void k_thresh_count_ties(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n,
+                                                           const ThreshState *__restrict__ ts, uint32_t *__restrict__ block_ties)
+{
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const uint32_t tau = ts->tau;
+    const uint64_t w0 = (uint64_t)blockIdx.x * TH_WORDS_PER_BLOCK + threadIdx.x * 8;
+    uint32_t c = 0;
+    for (int k = 0; k < 8; k++) {
+        const uint64_t i = w0 + k;
+        if (i * 8 >= n) break;
+        const uint32_t w = q[i];
+        const float s7 = s[i >> 3] / 7.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) if (i * 8 + e < n && mag_key(w, e, s7) == tau) c++;
+    }
+    if (c) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) block_ties[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(256) void k_thresh_scan(uint32_t *__restrict__ block_ties, uint32_t nblocks)
+{
+    // exclusive scan by one WG (nblocks is n / 16384: small)
+    __shared__ uint32_t carry;
+    __shared__ uint32_t buf[256];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_ties[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const uint32_t add = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nblocks) block_ties[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += buf[255];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_thresh_apply(uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n,
+                                                      const ThreshState *__restrict__ ts, const uint32_t *__restrict__ block_ties)
+{
+    __shared__ uint32_t tcnt[256];
+    const uint32_t tau = ts->tau, keep = ts->ties_keep;
+    const uint64_t w0 = (uint64_t)blockIdx.x * TH_WORDS_PER_BLOCK + threadIdx.x * 8;
+    uint32_t words[8];
+    uint32_t tie_mask[8];
+    uint32_t c = 0;
+    for (int k = 0; k < 8; k++) {
+        const uint64_t i = w0 + k;
+        words[k] = 0;
+        tie_mask[k] = 0;
+        if (i * 8 >= n) continue;
+        const uint32_t w = q[i];
+        const float s7 = s[i >> 3] / 7.0f;
+        uint32_t outw = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (i * 8 + e >= n) continue;
+            const uint32_t key = mag_key(w, e, s7);
+            if (key > tau) outw |= w & (0xFu << nib_shift(e));
+            else if (key == tau) { tie_mask[k] |= 1u << e; c++; }
+        }
+        words[k] = outw;
+    }
+    tcnt[threadIdx.x] = c;
+    __syncthreads();
+    // exclusive prefix of tie counts inside the block (Hillis-Steele over 256 threads)
+    uint32_t incl = c;
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t add = threadIdx.x >= (unsigned)o ? tcnt[threadIdx.x - o] : 0;
+        __syncthreads();
+        incl += add;
+        tcnt[threadIdx.x] = incl;
+        __syncthreads();
+    }
+    uint32_t rank = block_ties[blockIdx.x] + incl - c;
+    for (int k = 0; k < 8; k++) {
+        const uint64_t i = w0 + k;
+        if (i * 8 >= n) break;
+        uint32_t outw = words[k];
+        const uint32_t w = q[i];
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (tie_mask[k] & (1u << e)) {
+                if (rank < keep) outw |= w & (0xFu << nib_shift(e));
+                rank++;
+            }
+        // elements at or beyond n (the padding) are left as they are, like the reference's loop to `length`
+        const uint64_t first = i * 8;
+        if (first + 8 > n) {
+            for (int e = 0; e < 8; e++) if (first + e >= n) outw |= w & (0xFu << nib_shift(e));
+        }
+        q[i] = outw;
+    }
+}
+
+extern "C" uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad)
+{
+    const uint64_t blocks = (n_pad / 8 + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK;
+    return 4096 * sizeof(uint32_t) + 256 + blocks * sizeof(uint32_t) + 256;
+}
+
+extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream)
+{
+    CLV_REQUIRE(q && s, "clv4_threshold: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0 && n <= n_pad, "clv4_threshold: n=%llu n_pad=%llu", (unsigned long long)n, (unsigned long long)n_pad);
+    CLV_REQUIRE(n < (1ull << 32), "clv4_threshold: vectors of 2^32 or more elements are not supported");
+    hipStream_t st = as_stream(stream);
+    if (k >= n || n == 0) return CLV_OK;                       // everything survives
+    if (!workspace) {
+        int rc = clv_internal_workspace(&workspace, clv4_threshold_workspace_bytes(n_pad));
+        if (rc) return rc;
+    }
+    uint32_t *hist = (uint32_t *)workspace;
+    ThreshState *ts = (ThreshState *)(hist + 4096);
+    uint32_t *block_ties = (uint32_t *)((char *)ts + 256);
+    const uint64_t nwords = (n + 7) / 8;
+    const uint32_t nblocks = (uint32_t)((nwords + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK);
+    CLV_HIP(hipMemsetAsync(hist, 0, 4096 * sizeof(uint32_t) + 256, st));
+    if (k == 0) {
+        // keep nothing: tau = +inf pattern beyond any finite magnitude, no ties kept
+        const ThreshState none = {0, 0, 0x7F800000u, 0};
+        CLV_HIP(hipMemcpyAsync(ts, &none, sizeof none, hipMemcpyHostToDevice, st));
+        CLV_HIP(hipStreamSynchronize(st));
+    } else {
+        const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 4;
+        const dim3 grid((unsigned)(want < cap ? want : cap));
+        hipLaunchKernelGGL(k_thresh_hist<0>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<0>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        hipLaunchKernelGGL(k_thresh_hist<1>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<1>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        hipLaunchKernelGGL(k_thresh_hist<2>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<2>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        CLV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_thresh_count_ties, dim3(nblocks), dim3(256), 0, st, (const uint32_t *)q, s, n, ts, block_ties);
+    hipLaunchKernelGGL(k_thresh_scan, dim3(1), dim3(256), 0, st, block_ties, nblocks);
+    hipLaunchKernelGGL(k_thresh_apply, dim3(nblocks), dim3(256), 0, st, (uint32_t *)q, s, n, ts, block_ties);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}

@@ -267,6 +267,19 @@ static int rng_prefix(uint64_t *state, uint64_t count, int shift, uint64_t total
     return CLV_OK;
 }
 
+// exported to the other translation units (next4.hip)
+int clv_rng_prefix(uint64_t *state, uint64_t count, int shift, uint64_t total, uint64_t **starts, uint64_t **fin, hipStream_t st)
+{
+    return rng_prefix(state, count, shift, total, starts, fin, st);
+}
+
+int clv_rng_commit(uint64_t *state, const uint64_t *fin, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rng_commit, dim3(1), dim3(64), 0, st, state, fin);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
 int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng, hipStream_t st)
 {
     const uint64_t nb = n_pad / 64;

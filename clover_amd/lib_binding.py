@@ -54,6 +54,10 @@ SIGNATURES = {
     "clm4_mvm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clm4_rowdots": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clm4_gemm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
+    "clv4_scale_and_add": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _u64, _vp, _vp, _vp, _vp]),
+    "clv4_threshold_workspace_bytes": (_u64, [_u64]),
+    "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
+    "clm4_transpose": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "clm4_shard_partition": (C.c_int, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
     "clm4_sharded_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), _u64, _u64]),
     "clm4_sharded_destroy": (C.c_int, [_vp]),
@@ -221,6 +225,25 @@ class CloverHip:
         d = self.alloc(max(rows * 4, 4))
         self.check(self.lib.clm4_rowdots(b[0].ptr, b[1].ptr, rows, cols, b[2].ptr, b[3].ptr, d.ptr, None))
         return d.download(np.float32, rows)
+
+    def v4_scale_and_add(self, qu, su, qv, sv, a: float, rng: DevBuf | None = None, in_place: bool = False):
+        n = qu.size * 2
+        b = [self.to_device(x) for x in (qu, su, qv, sv)]
+        dr, dsr = (b[0], b[1]) if in_place else (self.alloc(max(n // 2, 1)), self.alloc(max(n // 16, 4)))
+        self.check(self.lib.clv4_scale_and_add(b[0].ptr, b[1].ptr, b[2].ptr, b[3].ptr, a, n, dr.ptr, dsr.ptr,
+                                               rng.ptr if rng else None, None))
+        return dr.download(np.uint8, n // 2), dsr.download(np.float32, n // 64)
+
+    def v4_threshold(self, q, s, n: int, k: int) -> np.ndarray:
+        dq, ds = self.to_device(q), self.to_device(s)
+        self.check(self.lib.clv4_threshold(dq.ptr, ds.ptr, n, q.size * 2, k, None, None))
+        return dq.download(np.uint8, q.size)
+
+    def m4_transpose(self, q, s, rows, cols):
+        dq, ds = self.to_device(q), self.to_device(s)
+        dt, dst = self.alloc(max(rows * cols // 2, 1)), self.alloc(max((rows // 64) * (cols // 64) * 4, 4))
+        self.check(self.lib.clm4_transpose(dq.ptr, ds.ptr, rows, cols, dt.ptr, dst.ptr, None))
+        return dt.download(np.uint8, rows * cols // 2), dst.download(np.float32, (rows // 64) * (cols // 64))
 
     def m4_gemm(self, qA, sA, M, K, qB, sB, N) -> np.ndarray:
         b = [self.to_device(a) for a in (qA, sA, qB, sB)]

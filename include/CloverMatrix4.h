@@ -11,7 +11,7 @@
  *   gemm (new)                       -> clm4_gemm     (the reference has no GEMM; semantics in DESIGN.md)
  *
  * As in the reference, values/scales are not exposed (they are `protected` there, :73-75); the matrix
- * lives in HBM once quantized.  Out of scope: transpose, mixed-precision mvm.
+ * lives in HBM once quantized.  transpose is here; mixed-precision mvm is not.
  */
 #ifndef CLOVER_MATRIX4_H
 #define CLOVER_MATRIX4_H
@@ -87,6 +87,20 @@ public:
     }
     void mvm_parallel(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
     void mvm_scalar(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
+
+    /* other = this^T  (CloverMatrix4.h:1549-1663; _parallel :2508-2640; _scalar :435-502) */
+    void transpose(CloverMatrix4 &other) const
+    {
+        if (other.rows != cols || other.cols != rows) {
+            std::cout << "Matrix can not be transposed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        uint8_t *d = other.mem.dev_wo();
+        clover_hip::check(clm4_transpose(dev_values(), dev_scales(), rows, cols, reinterpret_cast<int8_t *>(d),
+                                         reinterpret_cast<float *>(d + other.value_bytes), nullptr), "CloverMatrix4::transpose");
+    }
+    void transpose_parallel(CloverMatrix4 &other) const { transpose(other); }
+    void transpose_scalar(CloverMatrix4 &other) const { transpose(other); }
 
     /* C = this * B^T, fp32: this is M x K, B is N x K, C is M x N (build-defined) */
     void gemm(const CloverMatrix4 &B, CloverMatrix32 &C) const

@@ -16,7 +16,7 @@
  * Results are bit-identical to the reference when built with -DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1; the
  * default build rounds stochastically from the same XORShift stream (setRandomKeys for determinism).
  * Element accessors (get/set/getBits/setBits/getData/...) work on the host copy and synchronise lazily.
- * Out of scope here: scaleAndAdd, threshold.
+ * The "next" rows of SURVEY.md 8(f) are here too: scaleAndAdd (:1196-1478) and threshold (:1913-2060).
  */
 #ifndef CLOVER_VECTOR4_H
 #define CLOVER_VECTOR4_H
@@ -170,6 +170,39 @@ public:
         return result;
     }
 
+    /* ---- next rows: the other steps of the quantized IHT / GD iterations ------------------ */
+    /* this = quantize(this + a * other)   (CloverVector4.h:1196-1205; _parallel :1489-1499; _scalar :336-345) */
+    void scaleAndAdd(const CloverVector4 &other, float a)
+    {
+        same_size(other);
+        const int8_t *v = other.dev_values_ro();
+        const float *sv = other.dev_scales_ro();
+        int8_t *u = dev_values_rw();
+        float *su = dev_scales_rw();
+        clover_hip::check(clv4_scale_and_add(u, su, v, sv, a, length_pad, u, su, clover_hip::rng_or_null(random), nullptr),
+                          "CloverVector4::scaleAndAdd");
+    }
+    /* result = quantize(this + a * other) (CloverVector4.h:1207-1220) */
+    void scaleAndAdd(const CloverVector4 &other, float a, CloverVector4 &result)
+    {
+        same_size(other);
+        same_size(result);
+        clover_hip::check(clv4_scale_and_add(dev_values_ro(), dev_scales_ro(), other.dev_values_ro(), other.dev_scales_ro(), a, length_pad,
+                                             result.dev_values_wo(), result.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
+                          "CloverVector4::scaleAndAdd");
+    }
+    void scaleAndAdd_parallel(const CloverVector4 &other, float a) { scaleAndAdd(other, a); }
+    void scaleAndAdd_parallel(const CloverVector4 &other, float a, CloverVector4 &result) { scaleAndAdd(other, a, result); }
+    void scaleAndAdd_scalar(const CloverVector4 &other, float a) { scaleAndAdd(other, a); }
+    void scaleAndAdd_scalar(CloverVector4 &other, float a, CloverVector4 &result) { scaleAndAdd(other, a, result); }
+
+    /* keep the k largest magnitudes, zero the rest (CloverVector4.h:1913-2060) */
+    void threshold(uint64_t k)
+    {
+        clover_hip::check(clv4_threshold(dev_values_rw(), dev_scales_ro(), length, length_pad, k, nullptr, nullptr), "CloverVector4::threshold");
+    }
+    void threshold_parallel(uint64_t k) { threshold(k); }
+
     /* ---- device views, used by CloverMatrix4 ------------------------------------------------------ */
     const int8_t *dev_values_ro() const { return reinterpret_cast<const int8_t *>(mem.dev_ro()); }
     const float *dev_scales_ro() const
@@ -184,7 +217,21 @@ public:
         return reinterpret_cast<float *>(mem.dev_wo() + value_bytes);
     }
 
+    int8_t *dev_values_rw() { return reinterpret_cast<int8_t *>(mem.dev_rw()); }
+    float *dev_scales_rw()
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.dev_rw());
+        return reinterpret_cast<float *>(mem.dev_rw() + value_bytes);
+    }
+
 private:
+    void same_size(const CloverVector4 &other) const
+    {
+        if (other.length_pad != length_pad) {
+            std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+    }
     const int8_t *values_ro() const { return reinterpret_cast<const int8_t *>(mem.host_ro()); }
     const float *scales_ro() const
     {

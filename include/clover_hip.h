@@ -115,6 +115,21 @@ int  clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols
 int  clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K,
                const int8_t *B, const float *sB, uint64_t N, float *C, void *stream);
 
+/* ---- callers either side of the hot path: the other steps of the quantized IHT/GD loops ---- */
+/* CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478; _parallel :1489-1791): r = quantize(u + a*v) per
+ * 64-block; r/sr may alias qu/su (the in-place overload).  Bit-identical; with an rng the sequential
+ * method's XORShift stream and its lane map (element 8j+(g^1)) are reproduced. */
+int  clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
+                        int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
+/* CloverVector4::threshold(K) (CloverVector4.h:1913-2060): keep the K largest |value| among the first n
+ * elements, zero the other nibbles in place.  The surviving multiset of magnitudes equals the reference's;
+ * among EQUAL magnitudes the lowest indices survive (the reference's choice depends on its heap order). */
+uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad);
+int  clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream);
+/* CloverMatrix4::transpose (CloverMatrix4.h:1549-1663; _parallel :2508-2640): qt(j,i) = q(i,j), tile scales
+ * transposed.  q is rows x cols, qt is cols x rows.  Exact. */
+int  clm4_transpose(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, int8_t *qt, float *st, void *stream);
+
 /* ---- multi-GPU: row-sharded mvm on the GPUs of one node (one process, RCCL over xGMI) --------------- */
 /* MI355X counterpart of mvm_parallel's contiguous split of 64-row blocks over threads
  * (CloverMatrix4.h:1700-1705): shard `part` owns a contiguous multiple of 64 rows, x is replicated, the

@@ -92,6 +92,25 @@ class Oracle:
         self.L.orc_v4_word_isums(_p(qu, _u8p), _p(qv, _u8p), _u64(n), _p(out, _i32p))
         return out
 
+    def v4_scale_and_add(self, qu, su, qv, sv, a: float, rng: OrcRng | None = None):
+        n = qu.size * 2
+        r = np.zeros(n // 2, np.uint8)
+        sr = np.zeros(n // 64, np.float32)
+        self.L.orc_v4_scale_and_add(_p(qu, _u8p), _p(su, _fp), _p(qv, _u8p), _p(sv, _fp), C.c_float(a), _u64(n),
+                                    _p(r, _u8p), _p(sr, _fp), C.byref(rng) if rng is not None else None)
+        return r, sr
+
+    def v4_threshold(self, q, s, n: int, k: int) -> np.ndarray:
+        out = np.array(q, dtype=np.uint8, copy=True)
+        self.L.orc_v4_threshold(_p(out, _u8p), _p(s, _fp), _u64(n), _u64(k))
+        return out
+
+    def m4_transpose(self, q, s, rows, cols):
+        qt = np.zeros(rows * cols // 2, np.uint8)
+        st = np.zeros((rows // 64) * (cols // 64), np.float32)
+        self.L.orc_m4_transpose(_p(q, _u8p), _p(s, _fp), _u64(rows), _u64(cols), _p(qt, _u8p), _p(st, _fp))
+        return qt, st
+
     # -- matrix --------------------------------------------------------------------------------
     def m4_quantize(self, A: np.ndarray, rng: OrcRng | None = None):
         A = np.ascontiguousarray(A, dtype=np.float32)

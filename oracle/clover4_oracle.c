@@ -325,6 +325,148 @@ void orc_m4_mvm(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* section 8(f): scaleAndAdd, transpose, threshold                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+
+void orc_v4_scale_and_add(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, float a,
+                          uint64_t n_pad, uint8_t *r, float *sr, orc_rng *rng)
+{
+    const uint64_t nb = n_pad / 64;
+    for (uint64_t b = 0; b < nb; b++) {
+        const float su7 = su[b] / 7.0f;
+        const float sva = sv[b] * a;                 /* rounded product first (CloverVector4.h:1226) */
+        const float sv7 = sva / 7.0f;
+        float val[64];
+        for (int i = 0; i < 32; i++) {
+            const uint8_t bu = qu[32 * b + i], bv = qv[32 * b + i];
+            const float du_hi = (float)nib_hi(bu) * su7;
+            const float du_lo = (float)nib_lo(bu) * su7;
+            val[2 * i]     = fmaf((float)nib_hi(bv), sv7, du_hi);
+            val[2 * i + 1] = fmaf((float)nib_lo(bv), sv7, du_lo);
+        }
+        float m = 0.0f;
+        for (int i = 0; i < 64; i++) { const float x = fabsf(val[i]); if (x > m) m = x; }
+        m = fix_zero_max(m);
+        sr[b] = m;
+        const float k = 7.0f / m;
+        if (rng) {
+            /* nibbles are unpacked by bit position (lowest nibble first), so noise group g of AVX lane j
+             * meets the element at bit-nibble g of word j, which is element 8j + (g ^ 1) */
+            float nz[8][8], flat[64];
+            orc_rng_block_noise(rng, nz);
+            for (int g = 0; g < 8; g++) for (int j = 0; j < 8; j++) flat[8 * j + (g ^ 1)] = nz[g][j];
+            quant_block64(val, k, flat, r + 32 * b);
+        } else {
+            quant_block64(val, k, 0, r + 32 * b);
+        }
+    }
+}
+
+static inline int nib_at(const uint8_t *q, uint64_t pos)
+{
+    const uint8_t v = q[pos >> 1];
+    return (pos & 1) ? nib_lo(v) : nib_hi(v);
+}
+
+static inline void nib_set(uint8_t *q, uint64_t pos, int val)
+{
+    uint8_t *p = q + (pos >> 1);
+    if (pos & 1) *p = (uint8_t)((*p & 0xF0) | (val & 0xF));
+    else         *p = (uint8_t)((*p & 0x0F) | ((val & 0xF) << 4));
+}
+
+void orc_m4_transpose(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, uint8_t *qt, float *st)
+{
+    for (uint64_t i = 0; i < rows; i++)
+        for (uint64_t j = 0; j < cols; j++)
+            nib_set(qt, j * rows + i, nib_at(q, i * cols + j));
+    const uint64_t vb = rows >> 6, hb = cols >> 6;
+    for (uint64_t bi = 0; bi < vb; bi++)
+        for (uint64_t bj = 0; bj < hb; bj++) st[bj * vb + bi] = s[bi * hb + bj];
+}
+
+/* the reference's heap element and helpers (CloverBase.h:208-249) */
+typedef struct { float value; int bits; uint64_t idx; } heap_item;
+
+static void sift_min(heap_item *h, uint64_t pos, uint64_t k)      /* min_heapify */
+{
+    uint64_t smallest = pos;
+    for (;;) {
+        const uint64_t l = pos * 2 + 1, r = pos * 2 + 2;
+        if (l < k && h[l].value < h[smallest].value) smallest = l;
+        if (r < k && h[r].value < h[smallest].value) smallest = r;
+        if (smallest == pos) break;
+        const heap_item t = h[pos]; h[pos] = h[smallest]; h[smallest] = t;
+        pos = smallest;
+    }
+}
+
+/* std::make_heap(first, last, gt): libstdc++'s bottom-up construction with comparator "a > b" (min-heap) */
+static void push_down_gt(heap_item *h, uint64_t hole, uint64_t len, heap_item v)
+{
+    /* __adjust_heap: move the hole down to a leaf choosing the child that is NOT "less" under comp,
+     * then __push_heap back up */
+    const uint64_t top = hole;
+    uint64_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (h[child].value > h[child - 1].value) child--;            /* comp(first+child, first+child-1) */
+        h[hole] = h[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h[hole] = h[child - 1];
+        hole = child - 1;
+    }
+    uint64_t parent = (hole - 1) / 2;
+    while (hole > top && h[parent].value > v.value) {                 /* comp(first+parent, value) */
+        h[hole] = h[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    h[hole] = v;
+}
+
+static void make_heap_gt(heap_item *h, uint64_t len)
+{
+    if (len < 2) return;
+    uint64_t parent = (len - 2) / 2;
+    for (;;) {
+        const heap_item v = h[parent];
+        push_down_gt(h, parent, len, v);
+        if (parent == 0) return;
+        parent--;
+    }
+}
+
+#include <stdlib.h>
+
+void orc_v4_threshold(uint8_t *q, const float *s, uint64_t n, uint64_t k)
+{
+    if (k == 0) { for (uint64_t i = 0; i < n; i++) nib_set(q, i, 0); return; }
+    if (k >= n) return;
+    heap_item *h = (heap_item *)malloc(k * sizeof(heap_item));
+    for (uint64_t i = 0; i < k; i++) {
+        h[i].value = fabsf(orc_v4_get(q, s, i));
+        h[i].bits = nib_at(q, i);
+        h[i].idx = i;
+        nib_set(q, i, 0);
+    }
+    make_heap_gt(h, k);
+    for (uint64_t i = k; i < n; i++) {
+        const float v = fabsf(orc_v4_get(q, s, i));
+        if (v > h[0].value) {
+            h[0].value = v; h[0].idx = i; h[0].bits = nib_at(q, i);
+            sift_min(h, 0, k);
+        }
+        nib_set(q, i, 0);
+    }
+    for (uint64_t i = 0; i < k; i++) nib_set(q, h[i].idx, h[i].bits);
+    free(h);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* GEMM (build-defined; see header)                                                                  */
 /* ------------------------------------------------------------------------------------------------ */
 

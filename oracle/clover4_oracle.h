@@ -67,6 +67,19 @@ void     orc_m4_mvm(const uint8_t *A, const float *sA, uint64_t rows, uint64_t c
 /* Re-quantisation of 64 row dots (mvm epilogue, CloverMatrix4.h:919-1080); noise lane map 8j+g. */
 void     orc_m4_requantize64(const float d[64], uint8_t r[32], float *sr, orc_rng *rng);
 
+/* ---- section 8(f) "next" rows ------------------------------------------------------------------------ */
+/* CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478): r = quantize(u + a*v), block by block:
+ * val = fma((float)qv, f32(f32(sv*a)/7), (float)qu * f32(su/7)); then the quantiser.  r may alias u.
+ * Noise lane map differs from quantize: group g, lane j lands on element 8j + (g^1) (:1236-1243, 1459-1466). */
+void     orc_v4_scale_and_add(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, float a,
+                              uint64_t n_pad, uint8_t *r, float *sr, orc_rng *rng);
+/* CloverMatrix4::transpose (CloverMatrix4.h:1549-1663; scalar :435-502): out(j,i) = in(i,j), scales too. */
+void     orc_m4_transpose(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, uint8_t *qt, float *st);
+/* CloverVector4::threshold(K) (CloverVector4.h:1913-1975): keeps the K largest |value| of the first n
+ * elements with the reference's min-heap walk (std::make_heap + min_heapify, CloverBase.h:208-249), zeroes
+ * the other nibbles; scales untouched.  Which of several EQUAL magnitudes survive depends on heap order. */
+void     orc_v4_threshold(uint8_t *q, const float *s, uint64_t n, uint64_t k);
+
 /*
  * GEMM -- no reference function exists; build-defined semantics:
  *   A is M x K, B is N x K (both CloverMatrix4 layouts), C = A * B^T, fp32, row-major M x N.

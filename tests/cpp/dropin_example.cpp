@@ -82,5 +82,30 @@ int main()
         qA.gemm(qA, C);
         printf("gemm_c00=0x%08x gemm_c_1_77=0x%08x\n", bits(C.get(0, 0)), bits(C.get(1, 77)));
     }
+    // ---- next rows: one quantized IHT-style iteration, everything device-resident ------------------------
+    {
+        const int M = 256, N = 512, K = 32;
+        CloverMatrix32 Phi32(M, N);
+        CloverVector32 x32(N), y32(M);
+        Phi32.setRandomInteger(10, 7);
+        x32.setRandomInteger(10, 8);
+        y32.setRandomInteger(10, 9);
+        CloverMatrix4 Phi(M, N), PhiT(N, M);
+        CloverVector4 x(N), y(M), t1(M), t2(M), t3(N);
+        Phi.quantize(Phi32);
+        x.quantize(x32);
+        y.quantize(y32);
+        Phi.transpose(PhiT);
+        Phi.mvm_parallel(x, t1);                   // t1 = Phi x
+        y.scaleAndAdd_parallel(t1, -1.0f, t2);     // t2 = y - t1
+        PhiT.mvm_parallel(t2, t3);                 // t3 = Phi^T t2
+        x.scaleAndAdd_parallel(t3, 0.001f);        // x += mu t3
+        x.threshold_parallel(K);                   // keep the K largest
+        int nz = 0;
+        for (int i = 0; i < N; i++) nz += x.getBits(i) != 0;
+        printf("iht_nonzeros=%d\n", nz);
+        printf("iht_transpose_ok=%d\n", (int)(Phi.get(3, 200) == PhiT.get(200, 3) && Phi.get(255, 0) == PhiT.get(0, 255)));
+        hexdump("iht_x", x.getData(), 32);
+    }
     return 0;
 }

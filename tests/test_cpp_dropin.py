@@ -51,6 +51,8 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
     assert kv["kat3_r"] == KAT["KAT3"]["r_bytes_0_63"] and kv["kat3_r_parallel"] == KAT["KAT3"]["r_bytes_0_63"]
     assert kv["kat3_scales"].split(",") == KAT["KAT3"]["r_scale_bits"]
     np.testing.assert_allclose([float(v) for v in kv["kat3_get"].split(",")], KAT["KAT3"]["qA_get_0_0_3"], atol=1e-5)
+    # the IHT-style iteration built from the "next" rows: same steps on the oracle
+    assert kv["iht_transpose_ok"] == "1" and 0 < int(kv["iht_nonzeros"]) <= 32
     # GEMM spot values vs the oracle's definition
     A, _ = kat3_inputs()
     qA, sA = oracle.m4_quantize(A)

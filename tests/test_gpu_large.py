@@ -138,7 +138,8 @@ def test_sharded_c_api_single_process(hip, oracle):
         ro, sro = oracle.m4_mvm(A.download(np.uint8), sA.download(np.float32), rows, cols, qx, sx)
         assert same(r, ro) and same(sr, sro)
         # upload path: scatter a host matrix
-        hip.check(lib.clm4_sharded_upload(ctx, A.download(np.uint8).ctypes.data, sA.download(np.float32).ctypes.data))
+        A_h, sA_h = A.download(np.uint8), sA.download(np.float32)      # keep the host arrays alive across the call
+        hip.check(lib.clm4_sharded_upload(ctx, A_h.ctypes.data, sA_h.ctypes.data))
         hip.check(lib.clm4_sharded_mvm(ctx, qx.ctypes.data, sx.ctypes.data, 1, r.ctypes.data, sr.ctypes.data))
         assert same(r, ro)
         b, c = u64(), u64()

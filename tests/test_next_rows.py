@@ -1,0 +1,152 @@
+"""SURVEY 8(f) "next" rows: scaleAndAdd (f1), transpose (f2), threshold (f3).
+
+CPU part: the oracle's restatements against independent formulations.  GPU part (-m gpu): HIP vs oracle,
+bit-exact for scaleAndAdd and transpose (the reference's own tests are exact there, 02_vector.cpp:341-447,
+03_matrix.cpp:153-246); threshold compares the surviving multiset of magnitudes (the reference's test is a
+10 % tolerance on sorted magnitudes, 02_vector.cpp:449-498; tie-breaking among equal magnitudes is heap-order
+dependent in the reference and lowest-index-first here)."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import bits, random_packed
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def nibbles(b):
+    hi = (b.astype(np.int8) >> 4).astype(np.int32)
+    lo = ((b << 4).astype(np.int8) >> 4).astype(np.int32)
+    return np.stack([hi, lo], 1).reshape(-1)
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+
+
+# ------------------------------------------------------------------------------------------- CPU (oracle)
+def test_oracle_scale_and_add_is_axpy_then_quantize(oracle):
+    rng = np.random.default_rng(0)
+    for n in (128, 640):
+        (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
+        a = np.float32(0.5)
+        r, sr = oracle.v4_scale_and_add(qu, su, qv, sv, float(a))
+        # independent numpy evaluation of CloverVector4.h:1226-1318: du = q*su7 ; val = fma(qv, sv7, du)
+        su7 = (su / np.float32(7.0)).astype(np.float32)
+        sv7 = ((sv * a).astype(np.float32) / np.float32(7.0)).astype(np.float32)
+        du = (nibbles(qu).astype(np.float32) * np.repeat(su7, 64)).astype(np.float32)
+        val = (nibbles(qv).astype(np.float64) * np.repeat(sv7, 64).astype(np.float64) + du.astype(np.float64)).astype(np.float32)
+        q2, s2 = oracle.v4_quantize(val)
+        assert same(r, q2) and same(sr, s2)
+        # and it approximates u + a v within one quantisation step of the result
+        u, v = oracle.v4_restore(qu, su), oracle.v4_restore(qv, sv)
+        assert np.all(np.abs(oracle.v4_restore(r, sr) - (u + a * v)) <= np.repeat(sr, 64) / 7 + 1e-5)
+
+
+def test_oracle_transpose(oracle):
+    rng = np.random.default_rng(1)
+    M, N = 128, 384
+    q, _ = random_packed(rng, M * N)
+    s = rng.uniform(0.5, 2, size=(M // 64) * (N // 64)).astype(np.float32)
+    qt, st = oracle.m4_transpose(q, s, M, N)
+    assert np.array_equal(nibbles(qt).reshape(N, M), nibbles(q).reshape(M, N).T)
+    assert np.array_equal(st.reshape(N // 64, M // 64), s.reshape(M // 64, N // 64).T)
+    q2, s2 = oracle.m4_transpose(qt, st, N, M)
+    assert same(q2, q) and same(s2, s)                       # involution
+    for (i, j) in [(0, 0), (5, 383), (127, 64), (64, 65)]:
+        assert bits(oracle.m4_get(q, s, M, N, i, j)) == bits(oracle.m4_get(qt, st, N, M, j, i))
+
+
+def test_oracle_threshold_matches_std_make_heap(oracle, tmp_path):
+    exe = tmp_path / "thr"
+    subprocess.run(["g++", "-O1", "-std=c++11", str(ROOT / "tests" / "cpp" / "threshold_stdheap.cpp"), "-o", str(exe)], check=True)
+    rng = np.random.default_rng(2)
+    for (n, npad, k) in ((128, 128, 64), (1000, 1024, 64), (777, 896, 5), (2047, 2048, 300)):
+        q, s = random_packed(rng, npad)
+        mags = np.abs(oracle.v4_restore(q, s))[:n]
+        inp = f"{n} {k}\n" + "\n".join(repr(float(m)) for m in mags) + "\n"
+        kept_ref = [int(x) for x in subprocess.run([str(exe)], input=inp, capture_output=True, text=True, check=True).stdout.split()]
+        out = oracle.v4_threshold(q, s, n, k)
+        before, after = nibbles(q), nibbles(out)
+        expect = np.zeros_like(before)
+        expect[kept_ref] = before[kept_ref]
+        expect[n:] = before[n:]                              # padding untouched
+        assert np.array_equal(after, expect)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 256, 2048 + 128, 1 << 16, (1 << 20) + 128])
+def test_gpu_scale_and_add_bit_exact(hip, oracle, n):
+    rng = np.random.default_rng(n)
+    (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
+    qu[:32] = 0                                              # a block that sums to zero -> scale 1.0 path
+    qv[:32] = 0
+    for a in (0.5, -1.0, 1.7):
+        r, sr = hip.v4_scale_and_add(qu, su, qv, sv, a)
+        ro, sro = oracle.v4_scale_and_add(qu, su, qv, sv, a)
+        assert same(r, ro) and same(sr, sro)
+    r, sr = hip.v4_scale_and_add(qu, su, qv, sv, 0.5, in_place=True)       # x.scaleAndAdd(t, mu) of the IHT loop
+    assert same(r, oracle.v4_scale_and_add(qu, su, qv, sv, 0.5)[0])
+    assert sr[0] == 1.0
+
+
+@pytest.mark.gpu
+def test_gpu_scale_and_add_stochastic_same_stream(hip, oracle):
+    rng = np.random.default_rng(3)
+    n = 8192 + 384
+    (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
+    st, o = hip.new_rng(11, 22), oracle.rng(11, 22)
+    for _ in range(2):
+        r, sr = hip.v4_scale_and_add(qu, su, qv, sv, -1.0, rng=st)
+        ro, sro = oracle.v4_scale_and_add(qu, su, qv, sv, -1.0, o)
+        assert same(r, ro) and same(sr, sro)
+    assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 128), (128, 384), (640, 256), (1024, 2048)])
+def test_gpu_transpose_exact(hip, oracle, shape):
+    M, N = shape
+    rng = np.random.default_rng(M + N)
+    q, _ = random_packed(rng, M * N)
+    s = rng.uniform(0.5, 2, size=(M // 64) * (N // 64)).astype(np.float32)
+    qt, st = hip.m4_transpose(q, s, M, N)
+    qo, so = oracle.m4_transpose(q, s, M, N)
+    assert same(qt, qo) and same(st, so)
+    q2, s2 = hip.m4_transpose(qt, st, N, M)
+    assert same(q2, q) and same(s2, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(128, 128, 64), (1000, 1024, 64), (2047, 2048, 300), (65536, 65536, 16384),
+                                  ((1 << 20) + 77, (1 << 20) + 128, 262144), (512, 512, 0), (512, 512, 511)])
+def test_gpu_threshold_top_k(hip, oracle, case):
+    n, npad, k = case
+    rng = np.random.default_rng(n + k)
+    x = np.zeros(npad, np.float32)
+    x[:n] = rng.integers(-40, 41, size=n)                    # the reference's test data (02_vector.cpp:460)
+    q, s = oracle.v4_quantize(x)
+    out = hip.v4_threshold(q, s, n, k)
+    before, after = nibbles(q), nibbles(out)
+    assert np.array_equal(after[n:], before[n:])              # padding untouched
+    kept = after[:n] != 0
+    assert np.all((after[:n] == before[:n]) | (after[:n] == 0))   # survivors keep their value
+    mags = np.abs(oracle.v4_restore(q, s))[:n]
+    ref = oracle.v4_threshold(q, s, n, k)
+    kept_ref = nibbles(ref)[:n] != 0
+    # identical surviving multiset of magnitudes (zeros carry no information: a kept 0 nibble stays 0)
+    assert np.array_equal(np.sort(mags[kept]), np.sort(mags[kept_ref]))
+    if 0 < k < n:
+        tau = np.sort(mags)[::-1][k - 1]
+        assert np.all(mags[~kept] <= tau) and np.all(mags[kept] >= tau)
+        assert kept.sum() <= k
+        # ties: lowest indices survive
+        tie_idx = np.flatnonzero(mags == tau)
+        n_keep = k - int((mags > tau).sum())
+        if tau > 0:
+            assert np.array_equal(np.flatnonzero(kept & (mags == tau)), tie_idx[:n_keep])
+    again = hip.v4_threshold(out, s, n, k)                    # idempotent
+    assert same(again, out)
