@@ -312,7 +312,37 @@ def extras(hip, torch, dev, stream) -> dict:
             "frac_of_int8_mfma_peak": round(2.0 * G ** 3 / g_ms / 1e9 / 5000.0, 4),
             "note": "int4 x int4 via v_mfma_i32_16x16x64_i8 (nibbles widened to int8 in LDS), peak = 5 POP/s dense int8"}
     del gA, gB, gC
+    # the caller loop: one quantized IHT iteration, N = 8192 (m x 2m, K = 25 % of m), HBM-resident
+    m, nn = 4096, 8192
+    Phi = torch.empty(m * nn // 2, dtype=torch.uint8, device=dev)
+    PhiT = torch.empty(m * nn // 2, dtype=torch.uint8, device=dev)
+    sPhi = torch.empty((m // 64) * (nn // 64), dtype=torch.float32, device=dev)
+    sPhiT = torch.empty((m // 64) * (nn // 64), dtype=torch.float32, device=dev)
+    hip.check(lib.clv_fill_random_nibbles(Phi.data_ptr(), Phi.numel(), 31, 0, stream))
+    hip.check(lib.clv_fill_random_scales(sPhi.data_ptr(), sPhi.numel(), 32, 0, stream))
+    hip.check(lib.clm4_transpose(Phi.data_ptr(), sPhi.data_ptr(), m, nn, PhiT.data_ptr(), sPhiT.data_ptr(), stream))
+
+    def vec(n_, sd):
+        qv_ = torch.empty(n_ // 2, dtype=torch.uint8, device=dev)
+        sv_ = torch.empty(n_ // 64, dtype=torch.float32, device=dev)
+        hip.check(lib.clv_fill_random_nibbles(qv_.data_ptr(), qv_.numel(), sd, 0, stream))
+        hip.check(lib.clv_fill_random_scales(sv_.data_ptr(), sv_.numel(), sd + 1, 0, stream))
+        return qv_, sv_
+    (xq, xs_), (yq, ys_), (t1q, t1s), (t2q, t2s), (t3q, t3s) = vec(nn, 41), vec(m, 43), vec(m, 45), vec(m, 47), vec(nn, 49)
+
+    def iht_iter():
+        hip.check(lib.clm4_mvm(Phi.data_ptr(), sPhi.data_ptr(), m, nn, xq.data_ptr(), xs_.data_ptr(), t1q.data_ptr(), t1s.data_ptr(), None, stream))
+        hip.check(lib.clv4_scale_and_add(yq.data_ptr(), ys_.data_ptr(), t1q.data_ptr(), t1s.data_ptr(), -1.0, m, t2q.data_ptr(), t2s.data_ptr(), None, stream))
+        hip.check(lib.clm4_mvm(PhiT.data_ptr(), sPhiT.data_ptr(), nn, m, t2q.data_ptr(), t2s.data_ptr(), t3q.data_ptr(), t3s.data_ptr(), None, stream))
+        hip.check(lib.clv4_scale_and_add(xq.data_ptr(), xs_.data_ptr(), t3q.data_ptr(), t3s.data_ptr(), 1e-3, nn, xq.data_ptr(), xs_.data_ptr(), None, stream))
+        hip.check(lib.clv4_threshold(xq.data_ptr(), xs_.data_ptr(), nn, nn, m // 4, None, stream))
+    i_ms = timeit(iht_iter, 100)
+    iht_bytes = 2 * (m * nn // 2 + 4 * (m // 64) * (nn // 64)) + (2 * nn + 3 * m) * 9 // 16
+    iht = {"ms_per_iteration": round(i_ms, 5), "GB/s": round(iht_bytes / i_ms / 1e6, 1),
+           "note": "Q_IHT step sequence (mvm, scaleAndAdd, mvm^T, scaleAndAdd, threshold) at N=8192 (4096x8192), bytes counted like "
+                   "01_measure.h:1117-1125; reference published 19.5 GB/s with 4 threads (performance.txt:581)"}
     return {
+        "iht_iteration_N8192": iht,
         "gemm_8192^3": gemm,
         "note": "n=2^24 operands (76.5 MB / 18.9 MB) fit the Infinity Cache: cache-resident rates, not HBM-roofline claims",
         "quantize_n2^24": {"ms": round(q_ms, 5), "GB/s": round(4.5625 * n / q_ms / 1e6, 1)},

@@ -1,0 +1,44 @@
+/*
+ * CloverIHT.h -- the two application loops that call the 4-bit hot path in the reference:
+ * quantized Iterative Hard Thresholding and quantized Gradient Descent
+ * (test/performance/01_measure.h:923-946 and :999-1021).
+ *
+ * Same function names, argument order and step sequence as the reference's templates.  With the containers
+ * of this directory every step is a kernel on the device mirrors and nothing is copied back between steps:
+ * Phi, PhiT, x, y and the temporaries stay in HBM for the whole loop (the reference re-streams them from
+ * DRAM through the caches every iteration).
+ */
+#ifndef CLOVER_IHT_H
+#define CLOVER_IHT_H
+
+#include "CloverMatrix4.h"
+#include "CloverVector4.h"
+
+template <class QMatrix, class QVector>
+inline void Q_IHT(QMatrix &Phi, QMatrix &PhiT, QVector &x, QVector &y, QVector &t1, QVector &t2, QVector &t3,
+                  const uint64_t iterations, const uint64_t K, const float mu)
+{
+    x.clear();
+    for (uint64_t i = 0; i < iterations; i += 1) {
+        Phi.mvm_parallel(x, t1);                 // t1 = Phi * x
+        y.scaleAndAdd_parallel(t1, -1.0f, t2);   // t2 = y - Phi * x
+        PhiT.mvm_parallel(t2, t3);               // t3 = Phi' * (y - Phi * x)
+        x.scaleAndAdd_parallel(t3, mu);          // x = x + mu * Phi' * (y - Phi * x)
+        x.threshold_parallel(K);                 // hard thresholding
+    }
+}
+
+template <class QMatrix, class QVector>
+inline void Q_GD(QMatrix &Phi, QMatrix &PhiT, QVector &x, QVector &y, QVector &t1, QVector &t2, QVector &t3,
+                 const uint64_t iterations, const float mu)
+{
+    x.clear();
+    for (uint64_t i = 0; i < iterations; i += 1) {
+        Phi.mvm_parallel(x, t1);
+        y.scaleAndAdd_parallel(t1, -1.0f, t2);
+        PhiT.mvm_parallel(t2, t3);
+        x.scaleAndAdd_parallel(t3, mu);
+    }
+}
+
+#endif

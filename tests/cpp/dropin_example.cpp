@@ -1,6 +1,7 @@
 // dropin_example.cpp -- user code written against the reference's class surface (README.md:70-107 style),
 // compiled against THIS repository's include/ and linked with libclover_hip.so.  Prints key=value lines that
 // tests/test_gpu_cpp_dropin.py compares with the oracle / the reference's known answers.
+#include <CloverIHT.h>
 #include <CloverMatrix32.h>
 #include <CloverMatrix4.h>
 #include <CloverVector32.h>
@@ -106,6 +107,12 @@ int main()
         printf("iht_nonzeros=%d\n", nz);
         printf("iht_transpose_ok=%d\n", (int)(Phi.get(3, 200) == PhiT.get(200, 3) && Phi.get(255, 0) == PhiT.get(0, 255)));
         hexdump("iht_x", x.getData(), 32);
+        // the reference's loop templates (01_measure.h:923-946, 999-1021) on the same operands
+        Q_IHT(Phi, PhiT, x, y, t1, t2, t3, 3, K, 0.001f);
+        hexdump("qiht_x", x.getData(), 256);
+        printf("qiht_scales=0x%08x,0x%08x\n", bits(x.getScales()[0]), bits(x.getScales()[7]));
+        Q_GD(Phi, PhiT, x, y, t1, t2, t3, 2, 0.001f);
+        hexdump("qgd_x", x.getData(), 256);
     }
     return 0;
 }

@@ -51,8 +51,49 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
     assert kv["kat3_r"] == KAT["KAT3"]["r_bytes_0_63"] and kv["kat3_r_parallel"] == KAT["KAT3"]["r_bytes_0_63"]
     assert kv["kat3_scales"].split(",") == KAT["KAT3"]["r_scale_bits"]
     np.testing.assert_allclose([float(v) for v in kv["kat3_get"].split(",")], KAT["KAT3"]["qA_get_0_0_3"], atol=1e-5)
-    # the IHT-style iteration built from the "next" rows: same steps on the oracle
+    # the IHT-style iteration built from the "next" rows
     assert kv["iht_transpose_ok"] == "1" and 0 < int(kv["iht_nonzeros"]) <= 32
+    # Q_IHT / Q_GD (CloverIHT.h) against the same loops on the oracle.  Data = the C++ setRandomInteger streams.
+    def ints(n, mx, seed):
+        z, out, m = seed, np.zeros(n, np.float32), (1 << 64) - 1
+        for i in range(n):
+            z = (z + 0x9E3779B97F4A7C15) & m
+            r = z
+            r = ((r ^ (r >> 30)) * 0xBF58476D1CE4E5B9) & m
+            r = ((r ^ (r >> 27)) * 0x94D049BB133111EB) & m
+            r ^= r >> 31
+            out[i] = float(int(r % (2 * mx + 1)) - mx)
+        return out
+    M, N, K = 256, 512, 32
+    Phi = oracle.m4_quantize(ints(M * N, 10, 7).reshape(M, N))
+    PhiT = oracle.m4_transpose(*Phi, M, N)
+    y = oracle.v4_quantize(ints(M, 10, 9))
+
+    def threshold_lowest_index(q, s, k):          # the GPU's tie rule: > tau, then first ties
+        mags = np.abs(oracle.v4_restore(q, s))
+        tau = np.sort(mags)[::-1][k - 1]
+        keep = mags > tau
+        ties = np.flatnonzero(mags == tau)[: k - int(keep.sum())]
+        keep[ties] = True
+        hi = (q.astype(np.int8) >> 4).astype(np.int32)
+        lo = ((q << 4).astype(np.int8) >> 4).astype(np.int32)
+        nib = np.stack([hi, lo], 1).reshape(-1) * keep
+        return (((nib[0::2] & 0xF) << 4) | (nib[1::2] & 0xF)).astype(np.uint8)
+
+    def loop(iters, thr):
+        x = (np.zeros(N // 2, np.uint8), np.ones(N // 64, np.float32))       # x.clear()
+        for _ in range(iters):
+            t1 = oracle.m4_mvm(*Phi, M, N, *x)
+            t2 = oracle.v4_scale_and_add(*y, *t1, -1.0)
+            t3 = oracle.m4_mvm(*PhiT, N, M, *t2)
+            x = oracle.v4_scale_and_add(*x, *t3, 0.001)
+            if thr:
+                x = (threshold_lowest_index(x[0], x[1], K), x[1])
+        return x
+    xi = loop(3, True)
+    assert kv["qiht_x"] == xi[0].tobytes().hex()
+    assert kv["qiht_scales"].split(",") == [hex(bits(xi[1][0])), hex(bits(xi[1][7]))]
+    assert kv["qgd_x"] == loop(2, False)[0].tobytes().hex()
     # GEMM spot values vs the oracle's definition
     A, _ = kat3_inputs()
     qA, sA = oracle.m4_quantize(A)
