@@ -6,8 +6,9 @@
 // One K-block (64 elements, one Clover scale block) is exactly one v_mfma_i32_16x16x64_i8.
 //
 // Mapping
-//   workgroup 256 threads = 2x2 waves, tile 128x128; wave tile 64x64 = 4x4 MFMA tiles = ONE scale tile of A
-//   and of B, so c_b is wave-uniform.
+//   workgroup 512 threads = 2x4 waves, tile 128x128; wave tile 64x32 = 4x2 MFMA tiles inside ONE scale tile
+//   of A and of B, so c_b is wave-uniform.  Two sets of int32 results are ping-ponged per K-block so that the
+//   VALU folds K-block b-1 while the matrix pipe works on K-block b.
 //   staging: global (packed nibbles, 64 B per row per stage = 2 K-blocks) -> registers -> unpack -> LDS int8,
 //   double-buffered.  Unpacking needs no sign extension: (w & 0xF0F0F0F0) holds 16*q of the high nibbles and
 //   ((w << 4) & 0xF0F0F0F0) 16*q of the low nibbles as int8, so the MFMA returns 256*S_b exactly; the 2^-8
@@ -19,13 +20,15 @@
 //   epilogue per K-block and accumulator element: v_cvt_f32_i32 + v_fma_f32 (VALU beside the MFMA pipe).
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define GM_TILE 128
-#define GM_KB_PER_STAGE 2
-#define GM_STAGE_BYTES (2 * GM_KB_PER_STAGE * GM_TILE * 64)   // A + B, int8: 32 KiB
 
-__device__ __forceinline__ int swz(int row) { return (0x1320 >> (4 * ((row >> 2) & 3))) & 3; }   // f = {0,2,3,1}
+// f(row>>2) = {0,2,3,1} makes every ds_read_b128 lane group conflict-free; the extra XOR with the K-block index
+// (constant per read) separates the kb=0 / kb=1 pieces that one 8-lane ds_write_b128 group stores together.
+__device__ __forceinline__ int swz(int row, int kb) { return ((0x1320 >> (4 * ((row >> 2) & 3))) ^ kb) & 3; }
 
 // 16 packed bytes (32 nibbles) -> two 16-byte int8 slots (each nibble as 16*q)
 __device__ __forceinline__ void unpack32(const u32x4 p, u32x4 &s0, u32x4 &s1)
@@ -35,12 +38,17 @@ __device__ __forceinline__ void unpack32(const u32x4 p, u32x4 &s0, u32x4 &s1)
     s1 = u32x4{p.z & M, (p.z << 4) & M, p.w & M, (p.w << 4) & M};
 }
 
-__global__ __launch_bounds__(256, 2) void k_m4_gemm_mfma(const uint8_t *__restrict__ A, const float *__restrict__ sA,
+// KBS = K-blocks per LDS stage (one barrier per stage), MINW = occupancy target in waves per SIMD
+template <int KBS, int MINW, bool PINGPONG>
+__global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__restrict__ A, const float *__restrict__ sA,
                                                          const uint8_t *__restrict__ B, const float *__restrict__ sB,
                                                          uint64_t M, uint64_t N, uint64_t K, float *__restrict__ C,
                                                          uint32_t tiles_m, uint32_t tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int GM_KB_PER_STAGE = KBS;
+    constexpr int GM_STAGE_BYTES = 2 * KBS * GM_TILE * 64;     // A + B as int8
+    constexpr int NP = KBS / 2;                                // 16-byte pieces per thread, operand and stage
 
     // ---- tile assignment: XCD-aware (block b runs on XCD b % 8): give each XCD a contiguous range of tiles,
     // walked in 8-wide column groups so neighbours share A rows / B columns in that XCD's L2
@@ -61,53 +69,139 @@ __global__ __launch_bounds__(256, 2) void k_m4_gemm_mfma(const uint8_t *__restri
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 2, wc = wave & 3;                   // 2 x 4 waves, each 64 rows x 32 columns
     const uint64_t m0 = (uint64_t)tm * GM_TILE, n0 = (uint64_t)tn * GM_TILE;
     const uint64_t kbn = K / 64;                               // K-blocks
     const uint64_t nstages = kbn / GM_KB_PER_STAGE;            // K is a multiple of 128
 
-    // staging role: 2 x (row, quarter) per operand per stage
-    const int srow0 = tid >> 2, squarter = tid & 3;            // rows srow0 and srow0 + 64
-    const uint8_t *Ag = A + (m0 + srow0) * (K / 2) + 16 * squarter;
-    const uint8_t *Bg = B + (n0 + srow0) * (K / 2) + 16 * squarter;
-    const uint64_t row64 = 64 * (K / 2);
-
-    u32x4 pa0, pa1, pb0, pb1;
+    // staging role: NP x (row, 16-byte piece) per operand per stage; a row holds 32*KBS packed bytes per stage
+    u32x4 pa[NP], pb[NP];
     auto fetch = [&](uint64_t st) {
-        const uint64_t off = st * 64;                          // 64 packed bytes per row per stage
-        pa0 = *reinterpret_cast<const u32x4 *>(Ag + off);
-        pa1 = *reinterpret_cast<const u32x4 *>(Ag + off + row64);
-        pb0 = *reinterpret_cast<const u32x4 *>(Bg + off);
-        pb1 = *reinterpret_cast<const u32x4 *>(Bg + off + row64);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int idx = tid + 512 * p;
+            const int row = idx / (2 * KBS), piece = idx % (2 * KBS);
+            const uint64_t off = st * (32 * KBS) + 16 * piece;
+            pa[p] = *reinterpret_cast<const u32x4 *>(A + (m0 + row) * (K / 2) + off);
+            pb[p] = *reinterpret_cast<const u32x4 *>(B + (n0 + row) * (K / 2) + off);
+        }
     };
     auto stash = [&](int buf) {
         char *base = smem + buf * GM_STAGE_BYTES;
-        const int kb = squarter >> 1, half = squarter & 1;
-        auto put = [&](char *tile, int row, const u32x4 p) {
+        auto put = [&](char *tile, int row, int piece, const u32x4 p) {
+            const int kb = piece >> 1, half = piece & 1;
             u32x4 s0, s1;
             unpack32(p, s0, s1);
             char *r = tile + (kb * GM_TILE + row) * 64;
-            const int f = swz(row);
+            const int f = swz(row, kb);
             *reinterpret_cast<u32x4 *>(r + (((2 * half) ^ f) << 4)) = s0;
             *reinterpret_cast<u32x4 *>(r + (((2 * half + 1) ^ f) << 4)) = s1;
         };
-        put(base, srow0, pa0);
-        put(base, srow0 + 64, pa1);
-        put(base + GM_KB_PER_STAGE * GM_TILE * 64, srow0, pb0);
-        put(base + GM_KB_PER_STAGE * GM_TILE * 64, srow0 + 64, pb1);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int idx = tid + 512 * p;
+            const int row = idx / (2 * KBS), piece = idx % (2 * KBS);
+            put(base, row, piece, pa[p]);
+            put(base + GM_KB_PER_STAGE * GM_TILE * 64, row, piece, pb[p]);
+        }
     };
 
-    float acc[4][4][4];
+    float acc[4][2][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++)
+        for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int t = 0; t < 4; t++) acc[a][b][t] = 0.0f;
 
+    // Two sets of int32 MFMA results, ping-ponged per K-block: while the matrix pipe produces K-block kb into
+    // one set, the VALU folds the previous K-block's set into the fp32 accumulators, so no VALU instruction ever
+    // waits on the MFMA issued just before it.
+    i32x4 S0[4][2], S1[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) { S0[a][b] = i32x4{0, 0, 0, 0}; S1[a][b] = i32x4{0, 0, 0, 0}; }
+    float c_prev = 0.0f;                      // scale factor belonging to the set that is folded next
+
     const float *sArow = sA + ((m0 >> 6) + wr) * kbn;
-    const float *sBrow = sB + ((n0 >> 6) + wc) * kbn;
+    const float *sBrow = sB + ((n0 >> 6) + (wc >> 1)) * kbn;
     const int frow = lane & 15, fkg = lane >> 4;
+
+    // one K-block: MFMAs into `Sn` interleaved with the fold of the previous set `Sp`
+    auto kblock = [&](const char *tA, const char *tB, int kb, i32x4 (&Sn)[4][2], const i32x4 (&Sp)[4][2], float cp) {
+        i32x4 fa[4], fb[2];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int row = wr * 64 + a * 16 + frow;
+            fa[a] = *reinterpret_cast<const i32x4 *>(tA + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int row = wc * 32 + b * 16 + frow;
+            fb[b] = *reinterpret_cast<const i32x4 *>(tB + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
+        }
+        const bool normal = __builtin_fabsf(cp) >= 1.0e-30f || cp == 0.0f;  // hoisted: ONE uniform branch per K-block
+        const float c8 = cp * 0.00390625f;
+        if (normal) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const i32x4 prev = Sp[a][b];
+                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], i32x4{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, (float)prev[t], acc[a][b][t]);
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const i32x4 prev = Sp[a][b];
+                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], i32x4{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(cp, (float)(prev[t] >> 8), acc[a][b][t]);
+                }
+        }
+    };
+
+    // single-set variant (fewer registers -> more waves per SIMD): MFMAs of a K-block, then its own fold;
+    // the MFMA->VALU dependency is covered by the other resident waves instead of by a second register set
+    auto kblock_simple = [&](const char *tA, const char *tB, int kb, float c) {
+        i32x4 fa[4], fb[2];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int row = wr * 64 + a * 16 + frow;
+            fa[a] = *reinterpret_cast<const i32x4 *>(tA + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int row = wc * 32 + b * 16 + frow;
+            fb[b] = *reinterpret_cast<const i32x4 *>(tB + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) S0[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], i32x4{0, 0, 0, 0}, 0, 0, 0);
+        const bool normal = __builtin_fabsf(c) >= 1.0e-30f || c == 0.0f;
+        const float c8 = c * 0.00390625f;
+        if (normal) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, (float)S0[a][b][t], acc[a][b][t]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c, (float)(S0[a][b][t] >> 8), acc[a][b][t]);
+        }
+    };
 
     fetch(0);
     stash(0);
@@ -118,50 +212,46 @@ __global__ __launch_bounds__(256, 2) void k_m4_gemm_mfma(const uint8_t *__restri
         if (st + 1 < nstages) fetch(st + 1);
         const char *tA = smem + buf * GM_STAGE_BYTES;
         const char *tB = tA + GM_KB_PER_STAGE * GM_TILE * 64;
+        const uint64_t blk = st * GM_KB_PER_STAGE;
 #pragma unroll
-        for (int kb = 0; kb < GM_KB_PER_STAGE; kb++) {
-            const uint64_t blk = st * GM_KB_PER_STAGE + kb;
-            const float c = (sArow[blk] * CLV_RCP49) * sBrow[blk];
-            const float c8 = c * 0.00390625f;                               // 2^-8, exact unless it underflows
-            const bool tiny = __builtin_fabsf(c) < 1.0e-30f;                // wave-uniform
-            i32x4 fa[4], fb[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                const int row = wr * 64 + a * 16 + frow;
-                fa[a] = *reinterpret_cast<const i32x4 *>(tA + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row)) << 4));
+        for (int kb = 0; kb < KBS; kb += 2) {
+            const float c0 = (sArow[blk + kb] * CLV_RCP49) * sBrow[blk + kb];
+            const float c1 = (sArow[blk + kb + 1] * CLV_RCP49) * sBrow[blk + kb + 1];
+            if (PINGPONG) {
+                kblock(tA, tB, kb, S0, S1, c_prev);     // even K-block -> S0, folding the previous odd one (S1)
+                kblock(tA, tB, kb + 1, S1, S0, c0);     // odd K-block  -> S1, folding the even one (S0)
+                c_prev = c1;
+            } else {
+                kblock_simple(tA, tB, kb, c0);
+                kblock_simple(tA, tB, kb + 1, c1);
             }
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int row = wc * 64 + b * 16 + frow;
-                fb[b] = *reinterpret_cast<const i32x4 *>(tB + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row)) << 4));
-            }
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const i32x4 s = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], i32x4{0, 0, 0, 0}, 0, 0, 0);
-                    if (!tiny) {
-#pragma unroll
-                        for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, (float)s[t], acc[a][b][t]);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c, (float)(s[t] >> 8), acc[a][b][t]);
-                    }
-                }
         }
         if (st + 1 < nstages) stash(buf ^ 1);
         __syncthreads();
+    }
+    // fold the last K-block
+    if (PINGPONG) {
+        const bool normal = __builtin_fabsf(c_prev) >= 1.0e-30f || c_prev == 0.0f;
+        const float c8 = c_prev * 0.00390625f;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[a][b][t] = normal ? __builtin_fmaf(c8, (float)S1[a][b][t], acc[a][b][t])
+                                          : __builtin_fmaf(c_prev, (float)(S1[a][b][t] >> 8), acc[a][b][t]);
     }
 
     // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + t
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++)
+        for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const uint64_t i = m0 + wr * 64 + a * 16 + 4 * (lane >> 4) + t;
-                const uint64_t j = n0 + wc * 64 + b * 16 + (lane & 15);
+                const uint64_t j = n0 + wc * 32 + b * 16 + (lane & 15);
                 __builtin_nontemporal_store(acc[a][b][t], &C[i * N + j]);
             }
 }
@@ -170,16 +260,20 @@ int clm4_gemm_mfma(const int8_t *A, const float *sA, uint64_t M, uint64_t K, con
                    hipStream_t st)
 {
     const uint32_t tiles_m = (uint32_t)(M / GM_TILE), tiles_n = (uint32_t)(N / GM_TILE);
-    const size_t lds = 2 * GM_STAGE_BYTES;
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    CLV_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(k_m4_gemm_mfma, dim3(tiles_m * tiles_n), dim3(256), lds, st, (const uint8_t *)A, sA, (const uint8_t *)B, sB, M, N, K, C,
-                       tiles_m, tiles_n);
+    static const int variant = [] { const char *e = getenv("CLV_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+    const bool kbs4 = (variant & 1) && (K % 256 == 0);
+    const size_t lds = 2 * (size_t)(2 * (kbs4 ? 4 : 2) * GM_TILE * 64);
+#define GM_LAUNCH(KBS, MINW, PP)                                                                                                  \
+    do {                                                                                                                          \
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_mfma<KBS, MINW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_m4_gemm_mfma<KBS, MINW, PP>), dim3(tiles_m * tiles_n), dim3(512), lds, st, (const uint8_t *)A, sA,    \
+                           (const uint8_t *)B, sB, M, N, K, C, tiles_m, tiles_n);                                                \
+    } while (0)
+    // default = single result set, 4 waves/SIMD (1.30 POP/s at 8192^3); variants kept for A/B runs (r01 notes)
+    if (kbs4) GM_LAUNCH(4, 2, true);
+    else if (variant & 2) GM_LAUNCH(2, 2, true);
+    else GM_LAUNCH(2, 4, false);
+#undef GM_LAUNCH
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""GEMM timing at 8192^3 / 4096^3 (variant via CLV_GEMM_VARIANT)."""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clover_amd.lib_binding import CloverHip  # noqa: E402
+
+hip = CloverHip()
+lib = hip.lib
+for G in (4096, 8192):
+    A, B = hip.alloc(G * G // 2), hip.alloc(G * G // 2)
+    sA, sB = hip.alloc((G // 64) ** 2 * 4), hip.alloc((G // 64) ** 2 * 4)
+    Cc = hip.alloc(G * G * 4)
+    for t, sd in ((A, 1), (B, 2)):
+        hip.check(lib.clv_fill_random_nibbles(t.ptr, t.nbytes, sd, 0, None))
+    for t, sd in ((sA, 3), (sB, 4)):
+        hip.check(lib.clv_fill_random_scales(t.ptr, t.nbytes // 4, sd, 0, None))
+    fn = lambda: hip.check(lib.clm4_gemm(A.ptr, sA.ptr, G, G, B.ptr, sB.ptr, G, Cc.ptr, None))
+    for _ in range(3):
+        fn()
+    hip.sync()
+    a, b = C.c_void_p(), C.c_void_p()
+    hip.check(lib.clv_event_create(C.byref(a)))
+    hip.check(lib.clv_event_create(C.byref(b)))
+    ts = []
+    for _ in range(5):
+        hip.check(lib.clv_event_record(a, None))
+        for _ in range(5):
+            fn()
+        hip.check(lib.clv_event_record(b, None))
+        hip.check(lib.clv_event_sync(b))
+        ms = C.c_float()
+        hip.check(lib.clv_event_elapsed_ms(a, b, C.byref(ms)))
+        ts.append(ms.value / 5)
+    ms = sorted(ts)[2]
+    chk = float(np.abs(Cc.download(np.float32, 4096)).sum())
+    print(f"variant={os.environ.get('CLV_GEMM_VARIANT', '0')} G={G} {ms:.4f} ms {2.0 * G ** 3 / ms / 1e9:.1f} TOP/s checksum={chk:.6e}")
