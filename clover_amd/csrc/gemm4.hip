@@ -17,12 +17,23 @@
 //   order-free.
 //   LDS: [kblock][row][64 B] int8, 16-byte slots XOR-swizzled with f(row>>2) = {0,2,3,1} so that each
 //   ds_read_b128 lane group (MI355X_MICROARCH.md LDS table) touches 16 distinct slots: conflict-free.
-//   epilogue per K-block and accumulator element: v_cvt_f32_i32 + v_fma_f32 (VALU beside the MFMA pipe).
+//   epilogue per K-block and accumulator element: the MFMA accumulates onto the constant 0x4B400000 (the bit
+//   pattern of 12582912.0f = 1.5 * 2^23, where one ulp is 1), so its int32 result, read as fp32, IS the float
+//   12582912 + 256*S_b exactly (|256*S_b| <= 802816 < 2^20 keeps the exponent).  One exact v_sub_f32 replaces
+//   the half-rate v_cvt_f32_i32 (measured on this chip: cvt 4.3 cycles, fma/sub 2.8 cycles per wave64), then
+//   v_fma_f32 folds it in: 8 full-rate VALU per MFMA instead of 4 half-rate + 4 full-rate.
 #include "common.h"
 
 #include <stdlib.h>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define GM_BIAS_BITS 0x4B400000          // 12582912.0f
+#define GM_BIAS_F 12582912.0f
+#define GM_BIAS4 (i32x4{GM_BIAS_BITS, GM_BIAS_BITS, GM_BIAS_BITS, GM_BIAS_BITS})
+
+// exact (float)(raw - bias) for a biased MFMA result
+__device__ __forceinline__ float unbias(int raw) { return __int_as_float(raw) - GM_BIAS_F; }
 
 #define GM_TILE 128
 
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) { S0[a][b] = i32x4{0, 0, 0, 0}; S1[a][b] = i32x4{0, 0, 0, 0}; }
+        for (int b = 0; b < 2; b++) { S0[a][b] = GM_BIAS4; S1[a][b] = GM_BIAS4; }
     float c_prev = 0.0f;                      // scale factor belonging to the set that is folded next
 
     const float *sArow = sA + ((m0 >> 6) + wr) * kbn;
@@ -149,9 +160,9 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
                     const i32x4 prev = Sp[a][b];
-                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, (float)prev[t], acc[a][b][t]);
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, unbias(prev[t]), acc[a][b][t]);
                 }
         } else {
 #pragma unroll
@@ -159,17 +170,18 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
                     const i32x4 prev = Sp[a][b];
-                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(cp, (float)(prev[t] >> 8), acc[a][b][t]);
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(cp, (float)((prev[t] - GM_BIAS_BITS) >> 8), acc[a][b][t]);
                 }
         }
     };
 
-    // single-set variant (fewer registers -> more waves per SIMD): MFMAs of a K-block, then its own fold;
-    // the MFMA->VALU dependency is covered by the other resident waves instead of by a second register set
-    auto kblock_simple = [&](const char *tA, const char *tB, int kb, float c) {
-        i32x4 fa[4], fb[2];
+    // single-set variant (fewer registers -> more waves per SIMD): MFMAs of a K-block, then its own fold; the
+    // MFMA->VALU dependency is covered by the other resident waves.  The fragments of K-block kb+1 are requested
+    // from LDS right after the MFMAs of kb were issued, so their latency hides behind the fold of kb.
+    i32x4 fa[4], fb[2];
+    auto load_frags = [&](const char *tA, const char *tB, int kb) {
 #pragma unroll
         for (int a = 0; a < 4; a++) {
             const int row = wr * 64 + a * 16 + frow;
@@ -180,10 +192,14 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
             const int row = wc * 32 + b * 16 + frow;
             fb[b] = *reinterpret_cast<const i32x4 *>(tB + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
         }
+    };
+    auto mfma_all = [&]() {
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) S0[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], i32x4{0, 0, 0, 0}, 0, 0, 0);
+            for (int b = 0; b < 2; b++) S0[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
+    };
+    auto fold_all = [&](float c) {
         const bool normal = __builtin_fabsf(c) >= 1.0e-30f || c == 0.0f;
         const float c8 = c * 0.00390625f;
         if (normal) {
@@ -192,14 +208,14 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 #pragma unroll
                 for (int b = 0; b < 2; b++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, (float)S0[a][b][t], acc[a][b][t]);
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, unbias(S0[a][b][t]), acc[a][b][t]);
         } else {
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int b = 0; b < 2; b++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c, (float)(S0[a][b][t] >> 8), acc[a][b][t]);
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c, (float)((S0[a][b][t] - GM_BIAS_BITS) >> 8), acc[a][b][t]);
         }
     };
 
@@ -222,8 +238,13 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
                 kblock(tA, tB, kb + 1, S1, S0, c0);     // odd K-block  -> S1, folding the even one (S0)
                 c_prev = c1;
             } else {
-                kblock_simple(tA, tB, kb, c0);
-                kblock_simple(tA, tB, kb + 1, c1);
+                if (kb == 0) load_frags(tA, tB, 0);
+                mfma_all();
+                load_frags(tA, tB, kb + 1);
+                fold_all(c0);
+                mfma_all();
+                if (kb + 2 < KBS) load_frags(tA, tB, kb + 2);
+                fold_all(c1);
             }
         }
         if (st + 1 < nstages) stash(buf ^ 1);
@@ -239,8 +260,8 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
             for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int t = 0; t < 4; t++)
-                    acc[a][b][t] = normal ? __builtin_fmaf(c8, (float)S1[a][b][t], acc[a][b][t])
-                                          : __builtin_fmaf(c_prev, (float)(S1[a][b][t] >> 8), acc[a][b][t]);
+                    acc[a][b][t] = normal ? __builtin_fmaf(c8, unbias(S1[a][b][t]), acc[a][b][t])
+                                          : __builtin_fmaf(c_prev, (float)((S1[a][b][t] - GM_BIAS_BITS) >> 8), acc[a][b][t]);
     }
 
     // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + t
