@@ -72,16 +72,23 @@ __device__ __forceinline__ float fix_zero_max(float m)
     return __float_as_uint(m) == 0u ? m + 1.0f : m;
 }
 
-// one element of the quantiser: trunc(fma(|x|, k, noise)), sign of x re-applied the way
-// _mm256_sign_epi32 does (CloverVector4.h:741-772).  Returns the value in [-7,7].
+// One element of the quantiser.  The reference computes trunc(fma(|x|, k, noise)) and re-applies the sign of x
+// (_mm256_sign_epi32, CloverVector4.h:741-772).  Rounding is sign-symmetric, so the same integer comes out of
+// the SIGNED product: RN(x*k + copysign(noise, x)) == copysign(RN(|x|*k + noise), x), and the float->int
+// conversion truncates toward zero for either sign.  That is one multiply + one convert per element
+// (v_cvt_i32_f32 truncates like cvttps).  The only input for which cvttps' out-of-range answer (0x80000000,
+// i.e. nibble 0) differs from v_cvt's saturation is k == inf (block maximum below 2.06e-38, 7/max overflows):
+// there every element becomes 0 in the reference, which the callers mirror per block with `k < INFINITY`.
+__device__ __forceinline__ int quant1_det(float x, float k) { return (int)(x * k); }
+__device__ __forceinline__ int quant1_st(float x, float k, float noise)
+{
+    return (int)__builtin_fmaf(x, k, __builtin_copysignf(noise, x));
+}
+// single-element form with the overflow guard folded in (mvm epilogue: one value per lane)
 __device__ __forceinline__ int quant1(float x, float k, float noise)
 {
-    const float p = __builtin_fmaf(__builtin_fabsf(x), k, noise);
-    // v_cvt_i32_f32 truncates like cvttps but saturates; cvttps returns 0x80000000 for anything outside
-    // int32 (only reachable when 7/max overflows, i.e. a block maximum below 2.06e-38): mirror that.
-    const int t = (p < 2147483648.0f) ? (int)p : (int)0x80000000;   // p >= 0 or NaN here
-    const int xb = __float_as_int(x);
-    return xb < 0 ? (int)(0u - (unsigned)t) : (xb == 0 ? 0 : t);
+    const int t = quant1_st(x, k, noise);
+    return k < __builtin_inff() ? t : 0;
 }
 
 // bit position of element e (0..7) of a little-endian 32-bit word: even elements sit in the HIGH nibble
@@ -93,6 +100,15 @@ __device__ __forceinline__ uint32_t pack8(const int q[8])
 #pragma unroll
     for (int e = 0; e < 8; e++) w |= ((uint32_t)q[e] & 0xFu) << nib_shift(e);
     return w;
+}
+
+// quantise + pack 8 consecutive elements (one output dword); noise == nullptr <=> rounding disabled
+__device__ __forceinline__ uint32_t quant_pack8(const float v[8], float k, const float *noise)
+{
+    int q[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) q[e] = noise ? quant1_st(v[e], k, noise[e]) : quant1_det(v[e], k);
+    return k < __builtin_inff() ? pack8(q) : 0u;
 }
 
 // signed nibble e of word w

@@ -150,11 +150,8 @@ __global__ __launch_bounds__(256) void k_m4_quantize(const float *__restrict__ A
     if (tid == 0) s[bi * tiles_x + bj] = m;
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        int qv[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) qv[e] = quant1(v[p][e], k, 0.0f);
         const uint64_t row = bi * 64 + r0 + 32 * p;
-        q[(row * cols + bj * 64) / 8 + o] = pack8(qv);
+        q[(row * cols + bj * 64) / 8 + o] = quant_pack8(v[p], k, nullptr);
     }
 }
 

@@ -36,10 +36,7 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add(const uint32_t *qu, co
         m = fmaxf(m, __shfl_xor(m, 4));
         m = fix_zero_max(m);
         const float k = 7.0f / m;
-        int q[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) q[e] = quant1(v[e], k, 0.0f);
-        r[i] = pack8(q);
+        r[i] = quant_pack8(v, k, nullptr);
         if ((i & 7) == 0) sr[b] = m;
     }
 }
@@ -90,14 +87,13 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
                 const float kq = 7.0f / m;
                 const uint32_t *W32 = reinterpret_cast<const uint32_t *>(raw + (size_t)(bl * 2) * 4);
                 const uint32_t Wd[2] = {W32[rho], W32[8 + rho]};          // W[j = rho] of draw 0 and draw 1
-                int q[8];
+                float nz[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int g = e ^ 1;
-                    const float noise = (float)(int)((Wd[g >> 2] & 0x7F7F7F7Fu) << (8 * (g & 3))) * (1.0f / 2147483648.0f);
-                    q[e] = quant1(v[e], kq, noise);
+                    nz[e] = (float)(int)((Wd[g >> 2] & 0x7F7F7F7Fu) << (8 * (g & 3))) * (1.0f / 2147483648.0f);
                 }
-                r[i] = pack8(q);
+                r[i] = quant_pack8(v, kq, nz);
                 if (rho == 0) sr[blk] = m;
             }
         }

@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict_
                 const u32x4 *Wp = reinterpret_cast<const u32x4 *>(raw + (size_t)(bl * 2 + (rho >> 2)) * 4);
                 const u32x4 W0 = Wp[0], W1 = Wp[1];
                 const uint32_t W[8] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
-                int qv[8];
+                float nz[8];
 #pragma unroll
-                for (int e = 0; e < 8; e++) qv[e] = quant1(v[e], kq, noise_of(W[e], rho & 3));
-                q[i] = pack8(qv);
+                for (int e = 0; e < 8; e++) nz[e] = noise_of(W[e], rho & 3);
+                q[i] = quant_pack8(v, kq, nz);
                 if (rho == 0) s[blk] = m;
             }
         }
@@ -209,11 +209,11 @@ __global__ __launch_bounds__(256) void k_m4_quantize_st(const float *__restrict_
         const u32x4 *Wp = reinterpret_cast<const u32x4 *>(raw + (size_t)(rl * 2 + (o >> 2)) * 4);
         const u32x4 W0 = Wp[0], W1 = Wp[1];
         const uint32_t W[8] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
-        int qv[8];
+        float nz[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) qv[e] = quant1(v[p][e], kq, noise_of(W[e], o & 3));
+        for (int e = 0; e < 8; e++) nz[e] = noise_of(W[e], o & 3);
         const uint64_t row = bi * 64 + rl;
-        q[(row * cols + bj * 64) / 8 + o] = pack8(qv);
+        q[(row * cols + bj * 64) / 8 + o] = quant_pack8(v[p], kq, nz);
     }
 }
 

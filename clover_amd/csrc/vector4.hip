@@ -11,27 +11,47 @@
 //   per lane: 32 B in (2 x dwordx4), 4 B out; per wave: 2 KiB in, 256 B + 8 scales out.
 //   algorithmic bytes: 4.5625 per element.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x, uint32_t *__restrict__ q,
-                                                     float *__restrict__ s, uint64_t nwords)
+// one output word (8 elements, 8 lanes per block) from two float4
+__device__ __forceinline__ void quantize_word(const f32x4 a, const f32x4 b, uint64_t i, uint32_t *__restrict__ q, float *__restrict__ s)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
-        const f32x4 a = __builtin_nontemporal_load(&x[2 * i]);
-        const f32x4 b = __builtin_nontemporal_load(&x[2 * i + 1]);
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        float m = 0.0f;
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float m = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
-        m = fmaxf(m, __shfl_xor(m, 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
-        m = fmaxf(m, __shfl_xor(m, 4));
-        m = fix_zero_max(m);
-        const float k = 7.0f / m;                 // IEEE-correct fp32 division (CloverVector4.h:668)
-        int qv[8];
+    for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, __shfl_xor(m, 4));
+    m = fix_zero_max(m);
+    const float k = 7.0f / m;                 // IEEE-correct fp32 division (CloverVector4.h:668)
+    __builtin_nontemporal_store(quant_pack8(v, k, nullptr), &q[i]);
+    if ((i & 7) == 0) s[i >> 3] = m;
+}
+
+// Every wave walks its own contiguous span (good DRAM page locality), 4 words per lane and step with all
+// eight 16-byte loads issued before the first use: 8 KiB per wave in flight.
+#define VQ_UNROLL 4
+__global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x, uint32_t *__restrict__ q,
+                                                     float *__restrict__ s, uint64_t nwords, uint64_t words_per_wave)
+{
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint64_t w0 = wave * words_per_wave;
+    const uint64_t w1 = (w0 + words_per_wave) < nwords ? (w0 + words_per_wave) : nwords;     // multiples of 64
+    uint64_t w = w0;
+    for (; w + 64 * VQ_UNROLL <= w1; w += 64 * VQ_UNROLL) {
+        f32x4 a[VQ_UNROLL], b[VQ_UNROLL];
 #pragma unroll
-        for (int e = 0; e < 8; e++) qv[e] = quant1(v[e], k, 0.0f);
-        q[i] = pack8(qv);
-        if ((i & 7) == 0) s[i >> 3] = m;
+        for (int u = 0; u < VQ_UNROLL; u++) {
+            const uint64_t i = w + 64 * u + lane;
+            a[u] = __builtin_nontemporal_load(&x[2 * i]);
+            b[u] = __builtin_nontemporal_load(&x[2 * i + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < VQ_UNROLL; u++) quantize_word(a[u], b[u], w + 64 * u + lane, q, s);
+    }
+    for (; w < w1; w += 64) {
+        const uint64_t i = w + lane;                 // nwords is a multiple of 16: whole 8-lane blocks are in or out
+        if (i < w1) quantize_word(__builtin_nontemporal_load(&x[2 * i]), __builtin_nontemporal_load(&x[2 * i + 1]), i, q, s);
     }
 }
 
@@ -39,17 +59,22 @@ __global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x
 // restore: CloverVector4.h:1027-1093.  x = (scale / 7.0f) * q  (division first, then one multiply)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_v4_restore(const uint32_t *__restrict__ q, const float *__restrict__ s,
-                                                    f32x4 *__restrict__ x, uint64_t nwords)
+                                                    f32x4 *__restrict__ x, uint64_t nwords, uint64_t words_per_wave)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
-        const uint32_t w = q[i];
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint64_t w0 = wave * words_per_wave;
+    const uint64_t w1 = (w0 + words_per_wave) < nwords ? (w0 + words_per_wave) : nwords;
+    for (uint64_t w = w0; w < w1; w += 64) {
+        const uint64_t i = w + lane;
+        if (i >= w1) break;
+        const uint32_t wd = q[i];
         const float sc = s[i >> 3] / 7.0f;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = (float)unpack1(w, e) * sc;
-        x[2 * i]     = f32x4{v[0], v[1], v[2], v[3]};
-        x[2 * i + 1] = f32x4{v[4], v[5], v[6], v[7]};
+        for (int e = 0; e < 8; e++) v[e] = (float)unpack1(wd, e) * sc;
+        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, &x[2 * i]);          // streamed out, never re-read here
+        __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, &x[2 * i + 1]);
     }
 }
 
@@ -122,12 +147,10 @@ __global__ __launch_bounds__(256) void k_v4_dot_chain(const f32x4 *__restrict__ 
     auto fetch = [&](uint64_t tile) {
         const uint64_t g0 = tile * DX_TILE_GROUPS;
 #pragma unroll
-        for (int k = 0; k < NF; k++) {
-            const uint64_t idx = g0 * 16 + tid + 256 * k;
-            rf[k] = idx < ngroups * 16 ? F[idx] : f32x4{0, 0, 0, 0};
-        }
-        const uint64_t cidx = g0 * 2 + tid;
-        rc = (tid < DX_TILE_C4 && cidx < ngroups * 2) ? Cc[cidx] : f32x4{0, 0, 0, 0};
+        // unconditional loads: F and Cc are padded to whole tiles by k_v4_dot_prep (a per-load bounds check makes
+        // hipcc branch around every load and wait for each one separately)
+        for (int k = 0; k < NF; k++) rf[k] = F[g0 * 16 + tid + 256 * k];
+        rc = Cc[g0 * 2 + (tid & (DX_TILE_C4 - 1))];
     };
     auto stash = [&](int buf) {
         f32x4 *b = lds + buf * DX_BUF_F4;
@@ -243,15 +266,27 @@ static inline int stream_grid(uint64_t items, int threads, int per_cu)
 
 int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, hipStream_t st);
 
+// contiguous per-wave spans of whole 64-word steps: enough waves for 8 per SIMD, >= 4 steps each when there is work
+static inline void wave_spans(uint64_t nwords, uint64_t *words_per_wave, uint64_t *waves)
+{
+    const uint64_t steps = (nwords + 63) / 64;
+    uint64_t w = (uint64_t)clv_cu_count() * 32;
+    if (w * 4 > steps) w = steps / 4 ? steps / 4 : 1;
+    *words_per_wave = ((steps + w - 1) / w) * 64;
+    *waves = (nwords + *words_per_wave - 1) / *words_per_wave;
+}
+
 extern "C" int clv4_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream)
 {
     CLV_REQUIRE(x && q && s, "clv4_quantize: null pointer");
     CLV_REQUIRE(n_pad % 128 == 0, "clv4_quantize: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
     if (!n_pad) return CLV_OK;
     if (rng_state_dev) return clv4_quantize_stochastic(x, n_pad, q, s, rng_state_dev, as_stream(stream));
-    const uint64_t nwords = n_pad / 8;
-    hipLaunchKernelGGL(k_v4_quantize, dim3(stream_grid(nwords, 256, 8)), dim3(256), 0, as_stream(stream),
-                       (const f32x4 *)x, (uint32_t *)q, s, nwords);
+    const uint64_t nwords = n_pad / 8;                                   // multiple of 16
+    uint64_t words_per_wave, waves;
+    wave_spans(nwords, &words_per_wave, &waves);
+    hipLaunchKernelGGL(k_v4_quantize, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream),
+                       (const f32x4 *)x, (uint32_t *)q, s, nwords, words_per_wave);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -262,8 +297,10 @@ extern "C" int clv4_restore(const int8_t *q, const float *s, uint64_t n_pad, flo
     CLV_REQUIRE(n_pad % 128 == 0, "clv4_restore: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
     if (!n_pad) return CLV_OK;
     const uint64_t nwords = n_pad / 8;
-    hipLaunchKernelGGL(k_v4_restore, dim3(stream_grid(nwords, 256, 8)), dim3(256), 0, as_stream(stream),
-                       (const uint32_t *)q, s, (f32x4 *)x, nwords);
+    uint64_t words_per_wave, waves;
+    wave_spans(nwords, &words_per_wave, &waves);
+    hipLaunchKernelGGL(k_v4_restore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream),
+                       (const uint32_t *)q, s, (f32x4 *)x, nwords, words_per_wave);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -286,11 +323,16 @@ static inline int dot_fast_grid(uint64_t n_pad)
 }
 
 static inline uint64_t dot_exact_groups(uint64_t n_pad) { return (n_pad / 128 + 3) / 4; }
+// groups rounded up to whole LDS tiles: the chain kernel fetches tiles without bounds checks
+static inline uint64_t dot_exact_groups_padded(uint64_t n_pad)
+{
+    return (dot_exact_groups(n_pad) + DX_TILE_GROUPS - 1) / DX_TILE_GROUPS * DX_TILE_GROUPS;
+}
 
 extern "C" uint64_t clv4_dot_workspace_bytes(uint64_t n_pad)
 {
     const uint64_t fast = (uint64_t)clv_cu_count() * 4 * sizeof(float) + 256;
-    const uint64_t exact = dot_exact_groups(n_pad) * (16 + 2) * sizeof(f32x4) + 256;
+    const uint64_t exact = dot_exact_groups_padded(n_pad) * (16 + 2) * sizeof(f32x4) + 256;
     return fast > exact ? fast : exact;
 }
 
@@ -307,11 +349,11 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
         if (rc) return rc;
     }
     if (mode == CLV_DOT_EXACT) {
-        const uint64_t npairs = n_pad / 128, ngroups = dot_exact_groups(n_pad);
+        const uint64_t npairs = n_pad / 128, ngroups = dot_exact_groups(n_pad), gpad = dot_exact_groups_padded(n_pad);
         f32x4 *F = (f32x4 *)workspace;
-        f32x4 *Cc = F + ngroups * 16;
-        hipLaunchKernelGGL(k_v4_dot_prep, dim3(stream_grid(ngroups * 16, 256, 8)), dim3(256), 0, st, (const uint32_t *)qu, su,
-                           (const uint32_t *)qv, sv, npairs, ngroups, F, Cc);
+        f32x4 *Cc = F + gpad * 16;
+        hipLaunchKernelGGL(k_v4_dot_prep, dim3(stream_grid(gpad * 16, 256, 8)), dim3(256), 0, st, (const uint32_t *)qu, su,
+                           (const uint32_t *)qv, sv, npairs, gpad, F, Cc);
         CLV_LAUNCH_CHECK();
         static const size_t lds = 2 * DX_BUF_F4 * sizeof(f32x4);      // 72 KiB: above the 64 KiB default
         static bool attr_set[64] = {false};
