@@ -51,7 +51,8 @@ __host__ __device__ __forceinline__ uint64_t xs_T2(uint64_t a)
 
 __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
                                                              const float *__restrict__ sv, float a, uint32_t *r, float *sr,
-                                                             uint64_t nblocks, const uint64_t *__restrict__ starts)
+                                                             uint64_t nblocks, const uint64_t *__restrict__ starts,
+                                                             const uint64_t *__restrict__ segmat)
 {
     __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][64 * 2 * 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -59,8 +60,14 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
     const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
     const uint64_t blk0 = w * 128;
     const int seg = lane >> 2, k = lane & 3;
-    const uint64_t seg_idx = w * 16 + seg;
-    uint64_t st = (seg_idx * 8 < nblocks) ? starts[seg_idx * 4 + k] : 0;
+    uint64_t st = starts[(uint64_t)blockIdx.x * 4 + k];      // workgroup base, then this segment's T^(16 e)
+    {
+        const uint64_t *M = segmat + 64 * (wave * 16 + seg);
+        uint64_t acc = 0;
+#pragma unroll 8
+        for (int i = 0; i < 64; i++) acc ^= (0 - ((st >> i) & 1ull)) & M[i];
+        st = acc;
+    }
     for (int rr = 0; rr < 2; rr++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {                     // 4 blocks x 2 draws of this lane's segment
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
 
 int clv_rng_prefix(uint64_t *state, uint64_t count, int shift, uint64_t total, uint64_t **starts, uint64_t **fin, hipStream_t st);
 int clv_rng_commit(uint64_t *state, const uint64_t *fin, hipStream_t st);
+const uint64_t *clv_rng_segmat();
 
 extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
                                   int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream)
@@ -120,11 +128,11 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
         return CLV_OK;
     }
     uint64_t *starts, *fin;
-    int rc = clv_rng_prefix(rng_state_dev, (nb + 7) / 8, 4, 2 * nb, &starts, &fin, st);
+    const uint64_t wgs = (nb + 511) / 512;                     // one base state per workgroup = 512 blocks = 2^10 draws
+    int rc = clv_rng_prefix(rng_state_dev, wgs, 10, 2 * nb, &starts, &fin, st);
     if (rc) return rc;
-    const uint64_t waves = (nb + 127) / 128;
-    hipLaunchKernelGGL(k_v4_scale_and_add_st, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const uint32_t *)qu, su,
-                       (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, starts);
+    hipLaunchKernelGGL(k_v4_scale_and_add_st, dim3((unsigned)wgs), dim3(256), 0, st, (const uint32_t *)qu, su,
+                       (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, starts, clv_rng_segmat());
     CLV_LAUNCH_CHECK();
     return clv_rng_commit(rng_state_dev, fin, st);
 }

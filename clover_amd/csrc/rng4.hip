@@ -17,6 +17,7 @@
 #include <vector>
 
 #define RNG_POW_LEVELS 56
+#define RNG_SEG_MATS 64          // T^(16*e), e = 0..63: start of 8-block segment e relative to a workgroup base
 
 __host__ __device__ __forceinline__ uint64_t xs_T(uint64_t a)
 {
@@ -52,10 +53,15 @@ static int rng_pow_table(const uint64_t **table)
     CLV_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_pow_mutex);
     if (!g_pow_dev[dev]) {
-        std::vector<uint64_t> P((size_t)RNG_POW_LEVELS * 64);
+        std::vector<uint64_t> P((size_t)(RNG_POW_LEVELS + RNG_SEG_MATS) * 64);
         for (int i = 0; i < 64; i++) P[i] = xs_T(1ull << i);
         for (int k = 1; k < RNG_POW_LEVELS; k++)
             for (int i = 0; i < 64; i++) P[64 * k + i] = gf2_matvec(&P[64 * (k - 1)], P[64 * (k - 1) + i]);
+        // segment matrices behind the power levels: M_0 = I, M_(e+1) = T^16 * M_e
+        uint64_t *M = &P[(size_t)RNG_POW_LEVELS * 64];
+        for (int i = 0; i < 64; i++) M[i] = 1ull << i;
+        for (int e = 1; e < RNG_SEG_MATS; e++)
+            for (int i = 0; i < 64; i++) M[64 * e + i] = gf2_matvec(&P[64 * 4], M[64 * (e - 1) + i]);
         uint64_t *d = nullptr;
         CLV_HIP(hipMalloc(&d, P.size() * sizeof(uint64_t)));
         CLV_HIP(hipMemcpy(d, P.data(), P.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -63,6 +69,14 @@ static int rng_pow_table(const uint64_t **table)
     }
     *table = g_pow_dev[dev];
     return CLV_OK;
+}
+
+// segment matrices live right behind the power levels; valid once rng_pow_table() ran on this device
+static const uint64_t *rng_segmat()
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return g_pow_dev[dev] + (size_t)RNG_POW_LEVELS * 64;
 }
 
 // ---- prefix kernel ---------------------------------------------------------------------------------------
@@ -115,7 +129,8 @@ __device__ __forceinline__ uint64_t gen_blocks(uint64_t a, int nblk, uint64_t *r
 #define SQ_WAVE_BLOCKS 128
 
 __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict__ x, uint32_t *__restrict__ q, float *__restrict__ s,
-                                                        uint64_t nblocks, const uint64_t *__restrict__ starts)
+                                                        uint64_t nblocks, const uint64_t *__restrict__ starts,
+                                                        const uint64_t *__restrict__ segmat)
 {
     __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][64 * 2 * 4];   // per wave: 64 blocks x 2 draws x 4 lanes
     const int wave = threadIdx.x >> 6;
@@ -124,8 +139,8 @@ __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict_
     const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;            // global wave index
     const uint64_t blk0 = w * SQ_WAVE_BLOCKS;
     const int seg = lane >> 2, k = lane & 3;
-    const uint64_t seg_idx = w * 16 + seg;
-    uint64_t a = (seg_idx * 8 < nblocks) ? starts[seg_idx * 4 + k] : 0;
+    // start of this lane's 8-block segment = T^(16 * e) applied to the workgroup's base state (one matvec)
+    uint64_t a = gf2_matvec(segmat + 64 * (wave * 16 + seg), starts[(uint64_t)blockIdx.x * 4 + k]);
 
     for (int r = 0; r < 2; r++) {
         // 4 blocks of this lane's segment: local block id = 4*seg + i
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict_
 // stream order: tile t = bj * (rows/64) + bi (column-block outer), then the tile's 64 rows, two draws each.
 __global__ __launch_bounds__(256) void k_m4_quantize_st(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
                                                         float *__restrict__ s, uint32_t tiles_x, uint64_t tiles_y,
-                                                        const uint64_t *__restrict__ starts)
+                                                        const uint64_t *__restrict__ starts, const uint64_t *__restrict__ segmat)
 {
     __shared__ __attribute__((aligned(16))) uint64_t raw[64 * 2 * 4];
     __shared__ float sh[4];
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void k_m4_quantize_st(const float *__restrict_
 
     if (tid < 32) {                                                  // 8 segments x 4 generator lanes
         const int seg = tid >> 2, k = tid & 3;
-        gen_blocks(starts[(t * 8 + seg) * 4 + k], 8, raw + (size_t)(8 * seg) * 8, k);
+        gen_blocks(gf2_matvec(segmat + 64 * seg, starts[t * 4 + k]), 8, raw + (size_t)(8 * seg) * 8, k);
     }
 
     float v[2][8];
@@ -267,6 +282,8 @@ static int rng_prefix(uint64_t *state, uint64_t count, int shift, uint64_t total
     return CLV_OK;
 }
 
+const uint64_t *clv_rng_segmat() { return rng_segmat(); }
+
 // exported to the other translation units (next4.hip)
 int clv_rng_prefix(uint64_t *state, uint64_t count, int shift, uint64_t total, uint64_t **starts, uint64_t **fin, hipStream_t st)
 {
@@ -283,12 +300,12 @@ int clv_rng_commit(uint64_t *state, const uint64_t *fin, hipStream_t st)
 int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng, hipStream_t st)
 {
     const uint64_t nb = n_pad / 64;
-    const uint64_t nseg = (nb + 7) / 8;                              // start state every 8 blocks = 16 draws
+    const uint64_t wgs = (nb + 4 * SQ_WAVE_BLOCKS - 1) / (4 * SQ_WAVE_BLOCKS);   // one base state per workgroup = 512 blocks = 2^10 draws
     uint64_t *starts, *fin;
-    int rc = rng_prefix(rng, nseg, 4, 2 * nb, &starts, &fin, st);
+    int rc = rng_prefix(rng, wgs, 10, 2 * nb, &starts, &fin, st);
     if (rc) return rc;
-    const uint64_t waves = (nb + SQ_WAVE_BLOCKS - 1) / SQ_WAVE_BLOCKS;
-    hipLaunchKernelGGL(k_v4_quantize_st, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const f32x4 *)x, (uint32_t *)q, s, nb, starts);
+    hipLaunchKernelGGL(k_v4_quantize_st, dim3((unsigned)wgs), dim3(256), 0, st, (const f32x4 *)x, (uint32_t *)q, s, nb, starts,
+                       rng_segmat());
     CLV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rng_commit, dim3(1), dim3(64), 0, st, rng, fin);
     CLV_LAUNCH_CHECK();
@@ -299,10 +316,10 @@ int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_
 {
     const uint64_t tiles = (rows / 64) * (cols / 64);
     uint64_t *starts, *fin;
-    int rc = rng_prefix(rng, tiles * 8, 4, tiles * 128, &starts, &fin, st);
+    int rc = rng_prefix(rng, tiles, 7, tiles * 128, &starts, &fin, st);      // one base per tile = 64 rows = 2^7 draws
     if (rc) return rc;
     hipLaunchKernelGGL(k_m4_quantize_st, dim3((unsigned)tiles), dim3(256), 0, st, A, cols, (uint32_t *)q, s, (uint32_t)(cols / 64),
-                       rows / 64, starts);
+                       rows / 64, starts, rng_segmat());
     CLV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rng_commit, dim3(1), dim3(64), 0, st, rng, fin);
     CLV_LAUNCH_CHECK();
