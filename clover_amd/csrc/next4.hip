@@ -140,11 +140,73 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
 // =================================================================================================
 // f2  CloverMatrix4::transpose (CloverMatrix4.h:1549-1663): out(j,i) = in(i,j) nibble-wise, tile scales
 //     transposed (the reference calls IPP for those, :1657-1658).
-//     thread = one 8x8 nibble block: 8 dwords in (one per row), 8 dwords out; WG = one 64x64 tile.
+//     workgroup = 256 x 256 elements staged through LDS so that BOTH the reads and the writes are 128-byte
+//     runs (a row of the tile is 128 B on either side); a thread transposes 8x8 nibble blocks in registers.
+//     LDS rows are padded to 33 words: the 8x8-block reads (lanes = 8 words x 4 row groups) are conflict-free,
+//     the writes 2-way (free for ds_write_b32).  Algorithmic bytes: 2 * (1/2 + 4/4096) per element.
 // =================================================================================================
-__global__ __launch_bounds__(64) void k_m4_transpose(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t rows,
-                                                     uint64_t cols, uint32_t *__restrict__ qt, float *__restrict__ st,
-                                                     uint32_t tiles_x)
+#define TR_T 256                      // tile edge in elements
+#define TR_W (TR_T / 8)               // 32 words per tile row
+#define TR_S (TR_W + 1)               // padded LDS row stride in words
+
+__global__ __launch_bounds__(256) void k_m4_transpose(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t rows,
+                                                      uint64_t cols, uint32_t *__restrict__ qt, float *__restrict__ st,
+                                                      uint32_t tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tr_lds[];
+    uint32_t *tin = tr_lds;                       // [256][33]
+    uint32_t *tout = tr_lds + TR_T * TR_S;        // [256][33]
+    const uint32_t bj = blockIdx.x % tiles_x;
+    const uint64_t bi = blockIdx.x / tiles_x;
+    const int tid = threadIdx.x;
+    const uint64_t wcols = cols / 8, wrows = rows / 8;
+    const uint64_t r0 = bi * TR_T, c0w = (uint64_t)bj * TR_W;       // tile origin: row, word column
+
+    // 1. global -> LDS: 8 lanes x 16 B per tile row
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int idx = tid + 256 * k, r = idx >> 3, c = idx & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(q + (r0 + r) * wcols + c0w + 4 * c);
+        uint32_t *d = tin + r * TR_S + 4 * c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    // 2. 8x8 nibble blocks: block (bg, w) = rows 8bg..8bg+7, word w.  lanes: w_lo = tid&7, bg_lo = (tid>>3)&3
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int w = (tid & 7) + 8 * ((tid >> 5) & 3);
+        const int bg = ((tid >> 3) & 3) + 4 * ((tid >> 7) + 2 * k);
+        uint32_t wd[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) wd[r] = tin[(8 * bg + r) * TR_S + w];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc |= ((wd[r] >> nib_shift(e)) & 0xFu) << nib_shift(r);
+            tout[(8 * w + e) * TR_S + bg] = acc;
+        }
+    }
+    __syncthreads();
+    // 3. LDS -> global: output tile row j (a column of the input tile) = 32 words
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int idx = tid + 256 * k, r = idx >> 3, c = idx & 7;
+        const uint32_t *d = tout + r * TR_S + 4 * c;
+        const u32x4 v = {d[0], d[1], d[2], d[3]};
+        *reinterpret_cast<u32x4 *>(qt + ((uint64_t)bj * TR_T + r) * wrows + bi * TR_W + 4 * c) = v;
+    }
+    // tile scales: this 256x256 tile covers a 4x4 patch of the 64x64 scale grid
+    if (tid < 16) {
+        const uint64_t ti = bi * 4 + (tid >> 2), tj = (uint64_t)bj * 4 + (tid & 3);
+        st[tj * (rows / 64) + ti] = s[ti * (cols / 64) + tj];
+    }
+}
+
+// rows or cols not divisible by 256 (they are multiples of 128): one 64x64 tile per 64-thread workgroup
+__global__ __launch_bounds__(64) void k_m4_transpose_small(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t rows,
+                                                           uint64_t cols, uint32_t *__restrict__ qt, float *__restrict__ st,
+                                                           uint32_t tiles_x)
 {
     const uint32_t bj = blockIdx.x % tiles_x;
     const uint64_t bi = blockIdx.x / tiles_x;
@@ -172,11 +234,20 @@ extern "C" int clm4_transpose(const int8_t *q, const float *s, uint64_t rows, ui
     CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "clm4_transpose: rows=%llu cols=%llu must be multiples of 128",
                 (unsigned long long)rows, (unsigned long long)cols);
     CLV_REQUIRE(q != qt, "clm4_transpose: in-place transposition is not supported");
-    const uint64_t tiles = (rows / 64) * (cols / 64);
-    CLV_REQUIRE(tiles <= 0x7FFFFFFFull, "clm4_transpose: too many tiles");
-    if (!tiles) return CLV_OK;
-    hipLaunchKernelGGL(k_m4_transpose, dim3((unsigned)tiles), dim3(64), 0, as_stream(stream), (const uint32_t *)q, s, rows, cols,
-                       (uint32_t *)qt, st, (uint32_t)(cols / 64));
+    if (!rows || !cols) return CLV_OK;
+    if (rows % TR_T == 0 && cols % TR_T == 0) {
+        const uint64_t tiles = (rows / TR_T) * (cols / TR_T);
+        CLV_REQUIRE(tiles <= 0x7FFFFFFFull, "clm4_transpose: too many tiles");
+        const size_t lds = 2 * TR_T * TR_S * sizeof(uint32_t);                 // 66 KiB: above the 64 KiB default
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_m4_transpose, dim3((unsigned)tiles), dim3(256), lds, as_stream(stream), (const uint32_t *)q, s, rows, cols,
+                           (uint32_t *)qt, st, (uint32_t)(cols / TR_T));
+    } else {
+        const uint64_t tiles = (rows / 64) * (cols / 64);
+        CLV_REQUIRE(tiles <= 0x7FFFFFFFull, "clm4_transpose: too many tiles");
+        hipLaunchKernelGGL(k_m4_transpose_small, dim3((unsigned)tiles), dim3(64), 0, as_stream(stream), (const uint32_t *)q, s, rows, cols,
+                           (uint32_t *)qt, st, (uint32_t)(cols / 64));
+    }
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

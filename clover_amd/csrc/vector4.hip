@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x
 // ------------------------------------------------------------------------------------------------
 // restore: CloverVector4.h:1027-1093.  x = (scale / 7.0f) * q  (division first, then one multiply)
 // ------------------------------------------------------------------------------------------------
+template <bool NT>
 __global__ __launch_bounds__(256) void k_v4_restore(const uint32_t *__restrict__ q, const float *__restrict__ s,
                                                     f32x4 *__restrict__ x, uint64_t nwords, uint64_t words_per_wave)
 {
@@ -73,8 +74,14 @@ __global__ __launch_bounds__(256) void k_v4_restore(const uint32_t *__restrict__
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = (float)unpack1(wd, e) * sc;
-        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, &x[2 * i]);          // streamed out, never re-read here
-        __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, &x[2 * i + 1]);
+        const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+        if (NT) {                                  // output larger than the Infinity Cache: stream it past the caches
+            __builtin_nontemporal_store(lo, &x[2 * i]);
+            __builtin_nontemporal_store(hi, &x[2 * i + 1]);
+        } else {
+            x[2 * i] = lo;
+            x[2 * i + 1] = hi;
+        }
     }
 }
 
@@ -299,8 +306,12 @@ extern "C" int clv4_restore(const int8_t *q, const float *s, uint64_t n_pad, flo
     const uint64_t nwords = n_pad / 8;
     uint64_t words_per_wave, waves;
     wave_spans(nwords, &words_per_wave, &waves);
-    hipLaunchKernelGGL(k_v4_restore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream),
-                       (const uint32_t *)q, s, (f32x4 *)x, nwords, words_per_wave);
+    if (n_pad * sizeof(float) > (256ull << 20))
+        hipLaunchKernelGGL(k_v4_restore<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream),
+                           (const uint32_t *)q, s, (f32x4 *)x, nwords, words_per_wave);
+    else
+        hipLaunchKernelGGL(k_v4_restore<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream),
+                           (const uint32_t *)q, s, (f32x4 *)x, nwords, words_per_wave);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
