@@ -58,6 +58,8 @@ SIGNATURES = {
     "clv4_threshold_workspace_bytes": (_u64, [_u64]),
     "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "clm4_transpose": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "clm4_iht": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64,
+                          C.c_float, C.c_int, _vp, _vp]),
     "clm4_shard_partition": (C.c_int, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
     "clm4_sharded_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), _u64, _u64]),
     "clm4_sharded_destroy": (C.c_int, [_vp]),

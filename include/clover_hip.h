@@ -130,6 +130,15 @@ int  clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint6
  * transposed.  q is rows x cols, qt is cols x rows.  Exact. */
 int  clm4_transpose(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, int8_t *qt, float *st, void *stream);
 
+/* Q_IHT / Q_GD (test/performance/01_measure.h:923-946, 999-1021): x.clear(), then `iterations` times
+ *   t1 = Phi*x; t2 = y - t1; t3 = PhiT*t2; x = x + mu*t3; [threshold(K)]          (threshold != 0: IHT, else GD)
+ * entirely on the device.  Phi is m x n, PhiT its transpose (n x m), x has n (padded) / x_len (logical)
+ * elements, y, t1, t2 have m, t3 has n.  All launches are enqueued on `stream`; nothing is copied back. */
+int  clm4_iht(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n,
+              int8_t *x, float *sx, uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1,
+              int8_t *t2, float *st2, int8_t *t3, float *st3, uint64_t iterations, uint64_t K, float mu, int threshold,
+              uint64_t *rng_state_dev, void *stream);
+
 /* ---- multi-GPU: row-sharded mvm on the GPUs of one node (one process, RCCL over xGMI) --------------- */
 /* MI355X counterpart of mvm_parallel's contiguous split of 64-row blocks over threads
  * (CloverMatrix4.h:1700-1705): shard `part` owns a contiguous multiple of 64 rows, x is replicated, the

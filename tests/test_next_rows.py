@@ -150,3 +150,54 @@ def test_gpu_threshold_top_k(hip, oracle, case):
             assert np.array_equal(np.flatnonzero(kept & (mags == tau)), tie_idx[:n_keep])
     again = hip.v4_threshold(out, s, n, k)                    # idempotent
     assert same(again, out)
+
+
+def _threshold_lowest_index(oracle, q, s, n, k):
+    """the HIP tie rule on the CPU: everything above the K-th magnitude, then the first ties by index"""
+    mags = np.abs(oracle.v4_restore(q, s))[:n]
+    out = nibbles(q).copy()
+    if k < n:
+        tau = np.sort(mags)[::-1][k - 1] if k > 0 else np.inf
+        keep = mags > tau
+        ties = np.flatnonzero(mags == tau)[: max(k - int(keep.sum()), 0)]
+        keep[ties] = True
+        out[:n] *= keep
+    return (((out[0::2] & 0xF) << 4) | (out[1::2] & 0xF)).astype(np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["iht_stream", "iht_plain", "gd_stream"])
+def test_gpu_iht_loop_matches_oracle_loop(hip, oracle, mode):
+    """clm4_iht = Q_IHT / Q_GD of the reference (01_measure.h:923-946, 999-1021) on the device (own stream or the
+    default stream), against the same step sequence evaluated with the oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(42)
+    m, n, K, iters, mu = 256, 512, 48, 6, np.float32(0.002)
+    qPhi, _ = random_packed(rng, m * n)
+    sPhi = rng.uniform(0.5, 2, size=(m // 64) * (n // 64)).astype(np.float32)
+    qT, sT = oracle.m4_transpose(qPhi, sPhi, m, n)
+    y = random_packed(rng, m)
+    d = {k_: hip.to_device(v) for k_, v in dict(Phi=qPhi, sPhi=sPhi, PhiT=qT, sPhiT=sT, y=y[0], sy=y[1]).items()}
+    bufs = {k_: hip.alloc(max(sz, 4)) for k_, sz in dict(x=n // 2, sx=n // 16, t1=m // 2, st1=m // 16, t2=m // 2, st2=m // 16,
+                                                           t3=n // 2, st3=n // 16).items()}
+    stream = C.c_void_p()
+    if mode != "iht_plain":
+        hip.check(hip.lib.clv_stream_create(C.byref(stream)))
+    thr = 0 if mode.startswith("gd") else 1
+    hip.check(hip.lib.clm4_iht(d["Phi"].ptr, d["sPhi"].ptr, d["PhiT"].ptr, d["sPhiT"].ptr, m, n, bufs["x"].ptr, bufs["sx"].ptr, n,
+                               d["y"].ptr, d["sy"].ptr, bufs["t1"].ptr, bufs["st1"].ptr, bufs["t2"].ptr, bufs["st2"].ptr,
+                               bufs["t3"].ptr, bufs["st3"].ptr, iters, K, float(mu), thr, None, stream))
+    hip.check(hip.lib.clv_stream_sync(stream))
+    xq, xs = bufs["x"].download(np.uint8, n // 2), bufs["sx"].download(np.float32, n // 64)
+    # oracle loop
+    x = (np.zeros(n // 2, np.uint8), np.ones(n // 64, np.float32))
+    for _ in range(iters):
+        t1 = oracle.m4_mvm(qPhi, sPhi, m, n, *x)
+        t2 = oracle.v4_scale_and_add(*y, *t1, -1.0)
+        t3 = oracle.m4_mvm(qT, sT, n, m, *t2)
+        x = oracle.v4_scale_and_add(*x, *t3, float(mu))
+        if thr:
+            x = (_threshold_lowest_index(oracle, x[0], x[1], n, K), x[1])
+    assert same(xq, x[0]) and same(xs, x[1])
+    if stream:
+        hip.check(hip.lib.clv_stream_destroy(stream))

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A few IHT iterations at N = 8192 (for rocprofv3 passes)."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clover_amd.lib_binding import CloverHip  # noqa: E402
+
+hip = CloverHip()
+lib = hip.lib
+m, n = 4096, 8192
+Phi, PhiT = hip.alloc(m * n // 2), hip.alloc(m * n // 2)
+sPhi, sPhiT = hip.alloc((m // 64) * (n // 64) * 4), hip.alloc((m // 64) * (n // 64) * 4)
+hip.check(lib.clv_fill_random_nibbles(Phi.ptr, Phi.nbytes, 31, 0, None))
+hip.check(lib.clv_fill_random_scales(sPhi.ptr, sPhi.nbytes // 4, 32, 0, None))
+hip.check(lib.clm4_transpose(Phi.ptr, sPhi.ptr, m, n, PhiT.ptr, sPhiT.ptr, None))
+
+
+def vec(k, sd):
+    q, s = hip.alloc(k // 2), hip.alloc(k // 16)
+    hip.check(lib.clv_fill_random_nibbles(q.ptr, q.nbytes, sd, 0, None))
+    hip.check(lib.clv_fill_random_scales(s.ptr, s.nbytes // 4, sd + 1, 0, None))
+    return q, s
+
+
+x, y, t1, t2, t3 = vec(n, 41), vec(m, 43), vec(m, 45), vec(m, 47), vec(n, 49)
+hip.check(lib.clm4_iht(Phi.ptr, sPhi.ptr, PhiT.ptr, sPhiT.ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
+                       t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 3, m // 4, 1e-3, 1, None, None))
+hip.sync()
+print("iht probe done")
