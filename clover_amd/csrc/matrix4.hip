@@ -81,11 +81,32 @@ __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A,
     for (uint64_t c0 = 0; c0 < cols; c0 += MVM_CHUNK) {
         const uint32_t cw = (uint32_t)((cols - c0) < MVM_CHUNK ? (cols - c0) : MVM_CHUNK);
         if (c0) __syncthreads();
+        // stage x and c[b]: all loads first (one round trip), then the LDS writes.  Written with guarded, fully
+        // unrolled loads instead of a runtime-trip-count loop, which hipcc turns into load-wait-store chains.
         const u32x4 *xg = reinterpret_cast<const u32x4 *>(x + c0 / 2);
-        for (uint32_t i = tid; i < cw / 32; i += 256) xs[i] = xg[i];
-        for (uint32_t i = tid; i < cw / 64; i += 256) cs[i] = (sArow[c0 / 64 + i] * CLV_RCP49) * sx[c0 / 64 + i];
+        {
+            constexpr int NX = MVM_CHUNK / 32 / 256;          // 8 x 16 B per thread
+            constexpr int NC = MVM_CHUNK / 64 / 256;          // 4 factors per thread
+            u32x4 xr[NX];
+            float sa[NC], sv[NC];
+            const uint32_t nx = cw / 32, nc = cw / 64;
+#pragma unroll
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; xr[k] = xg[i < nx ? i : 0]; }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const uint32_t i = tid + 256 * k, ii = i < nc ? i : 0;
+                sa[k] = sArow[c0 / 64 + ii];
+                sv[k] = sx[c0 / 64 + ii];
+            }
+#pragma unroll
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) xs[i] = xr[k]; }
+#pragma unroll
+            for (int k = 0; k < NC; k++) { const uint32_t i = tid + 256 * k; if (i < nc) cs[i] = (sa[k] * CLV_RCP49) * sv[k]; }
+        }
         __syncthreads();
 
+        // (a register double-buffered variant -- next U loads requested before the current U are consumed -- was
+        //  measured slower at every size: it costs the fourth wave per SIMD; r01 microbench variants 5-7)
         const u32x4 *Ap = Arow + c0 / 32;
         const uint32_t npairs = cw / 128;
         uint32_t t = 0;
