@@ -648,3 +648,72 @@ extern "C" int clm4_iht(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     }
     return CLV_OK;
 }
+
+// =================================================================================================
+// f4'  mixed precision CloverMatrix4::mvm(const CloverVector32 &, CloverVector32 &) (CloverMatrix4.h:1451-1547)
+//      fp32 vector in, fp32 row dots out.  The reference keeps 4 accumulators x 8 AVX lanes = 32 sequential
+//      fma chains per row; chain (e mod 32) takes elements e, e+32, ...  Lane = (row, a = word index mod 4):
+//      it owns the 8 chains of accumulator a and walks every fourth word of its row; x lives in LDS as fp32
+//      (16384-column chunks = 64 KiB).  Products are f32((float)q * f32(s/7)) * x with one fma, as there.
+// =================================================================================================
+#define MVF_CHUNK 16384u
+
+__global__ __launch_bounds__(256) void k_m4_mvm_f32(const uint32_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
+                                                    const float *__restrict__ x, float *__restrict__ r)
+{
+    extern __shared__ __attribute__((aligned(16))) float mvf_x[];        // MVF_CHUNK floats
+    const int tid = threadIdx.x, a = tid & 3, rho = tid >> 2;
+    const uint64_t row = (uint64_t)blockIdx.x * 64 + rho;
+    const uint32_t *Arow = A + row * (cols / 8);
+    const float *su = sA + (uint64_t)blockIdx.x * (cols / 64);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+    for (uint64_t c0 = 0; c0 < cols; c0 += MVF_CHUNK) {
+        const uint32_t cw = (uint32_t)((cols - c0) < MVF_CHUNK ? (cols - c0) : MVF_CHUNK);
+        if (c0) __syncthreads();
+        for (uint32_t i = tid; i < cw / 4; i += 256) reinterpret_cast<f32x4 *>(mvf_x)[i] = reinterpret_cast<const f32x4 *>(x + c0)[i];
+        __syncthreads();
+        const uint32_t nwords = cw / 8;                                   // this lane takes words a, a+4, a+8, ...
+        const uint32_t *Ap = Arow + c0 / 8;
+        for (uint32_t w0 = 0; w0 < nwords; w0 += 32) {                    // 8 words per lane and step (cw is a multiple of 128)
+            uint32_t wd[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) wd[u] = (w0 + 4 * u + a < nwords) ? Ap[w0 + 4 * u + a] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t w = w0 + 4 * u + a;
+                if (w < nwords) {
+                    const float sc = su[(c0 + 8 * (uint64_t)w) >> 6] / 7.0f;
+                    const f32x4 xl = reinterpret_cast<const f32x4 *>(mvf_x)[2 * w];
+                    const f32x4 xh = reinterpret_cast<const f32x4 *>(mvf_x)[2 * w + 1];
+                    const float xv[8] = {xl.x, xl.y, xl.z, xl.w, xh.x, xh.y, xh.z, xh.w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(xv[j], (float)unpack1(wd[u], j) * sc, acc[j]);
+                }
+            }
+        }
+    }
+    // (acc1 + acc2) + (acc3 + acc4) per AVX lane j, then the CloverBase.h:149-157 tree over the 8 lanes
+    float s3[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float s12 = acc[j] + __shfl_xor(acc[j], 1);        // lanes a=0,1 -> acc1+acc2 ; a=2,3 -> acc3+acc4
+        s3[j] = s12 + __shfl_xor(s12, 2);
+    }
+    const float t0 = s3[4] + s3[0], t1 = s3[5] + s3[1], t2 = s3[6] + s3[2], t3 = s3[7] + s3[3];
+    const float dot = (t0 + t2) + (t1 + t3);
+    if (a == 0) r[row] = dot;
+}
+
+extern "C" int clm4_mvm_f32(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const float *x, float *r, void *stream)
+{
+    CLV_REQUIRE(A && sA && x && r, "clm4_mvm_f32: null pointer");
+    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0 && rows / 64 <= 0x7FFFFFFFull, "clm4_mvm_f32: rows=%llu cols=%llu must be multiples of 128",
+                (unsigned long long)rows, (unsigned long long)cols);
+    if (!rows) return CLV_OK;
+    const size_t lds = MVF_CHUNK * sizeof(float);
+    hipLaunchKernelGGL(k_m4_mvm_f32, dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), (const uint32_t *)A, sA, cols, x, r);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}

@@ -58,6 +58,7 @@ SIGNATURES = {
     "clv4_threshold_workspace_bytes": (_u64, [_u64]),
     "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "clm4_transpose": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "clm4_mvm_f32": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "clm4_iht": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64,
                           C.c_float, C.c_int, _vp, _vp]),
     "clm4_shard_partition": (C.c_int, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
@@ -246,6 +247,12 @@ class CloverHip:
         dt, dst = self.alloc(max(rows * cols // 2, 1)), self.alloc(max((rows // 64) * (cols // 64) * 4, 4))
         self.check(self.lib.clm4_transpose(dq.ptr, ds.ptr, rows, cols, dt.ptr, dst.ptr, None))
         return dt.download(np.uint8, rows * cols // 2), dst.download(np.float32, (rows // 64) * (cols // 64))
+
+    def m4_mvm_f32(self, qA, sA, rows, cols, x) -> np.ndarray:
+        b = [self.to_device(a) for a in (qA, sA, np.ascontiguousarray(x, dtype=np.float32))]
+        d = self.alloc(max(rows * 4, 4))
+        self.check(self.lib.clm4_mvm_f32(b[0].ptr, b[1].ptr, rows, cols, b[2].ptr, d.ptr, None))
+        return d.download(np.float32, rows)
 
     def m4_gemm(self, qA, sA, M, K, qB, sB, N) -> np.ndarray:
         b = [self.to_device(a) for a in (qA, sA, qB, sB)]

@@ -11,7 +11,8 @@
  *   gemm (new)                       -> clm4_gemm     (the reference has no GEMM; semantics in DESIGN.md)
  *
  * As in the reference, values/scales are not exposed (they are `protected` there, :73-75); the matrix
- * lives in HBM once quantized.  transpose is here; mixed-precision mvm is not.
+ * lives in HBM once quantized.  transpose and the 4-bit x fp32 mixed mvm are here; the 4-bit x
+ * 8-bit mvm is not (it needs the 8-bit container format).
  */
 #ifndef CLOVER_MATRIX4_H
 #define CLOVER_MATRIX4_H
@@ -87,6 +88,18 @@ public:
     }
     void mvm_parallel(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
     void mvm_scalar(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
+
+    /* mixed precision: fp32 vector in, fp32 vector out (CloverMatrix4.h:1451-1547; _parallel :2397-2505) */
+    void mvm(const CloverVector32 &productVector, CloverVector32 &resultVector)
+    {
+        if (productVector.size() != getCols() || resultVector.size_pad() != getRows()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        clover_hip::check(clm4_mvm_f32(dev_values(), dev_scales(), rows, cols, productVector.device_ro(), resultVector.device_wo(), nullptr),
+                          "CloverMatrix4::mvm");
+    }
+    void mvm_parallel(const CloverVector32 &productVector, CloverVector32 &resultVector) { mvm(productVector, resultVector); }
 
     /* other = this^T  (CloverMatrix4.h:1549-1663; _parallel :2508-2640; _scalar :435-502) */
     void transpose(CloverMatrix4 &other) const

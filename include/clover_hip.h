@@ -130,6 +130,9 @@ int  clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint6
  * transposed.  q is rows x cols, qt is cols x rows.  Exact. */
 int  clm4_transpose(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, int8_t *qt, float *st, void *stream);
 
+/* mixed precision CloverMatrix4::mvm(const CloverVector32&, CloverVector32&) (CloverMatrix4.h:1451-1547):
+ * x: cols floats, r: rows floats (fp32 row dots, no re-quantisation).  Bit-identical (32 fma chains per row). */
+int  clm4_mvm_f32(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const float *x, float *r, void *stream);
 /* Q_IHT / Q_GD (test/performance/01_measure.h:923-946, 999-1021): x.clear(), then `iterations` times
  *   t1 = Phi*x; t2 = y - t1; t3 = PhiT*t2; x = x + mu*t3; [threshold(K)]          (threshold != 0: IHT, else GD)
  * entirely on the device.  Phi is m x n, PhiT its transpose (n x m), x has n (padded) / x_len (logical)

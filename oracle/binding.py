@@ -136,6 +136,12 @@ class Oracle:
                           _p(r, _u8p), _p(sr, _fp), C.byref(rng) if rng is not None else None)
         return r, sr
 
+    def m4_mvm_f32(self, qA, sA, rows, cols, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        r = np.zeros(rows, np.float32)
+        self.L.orc_m4_mvm_f32(_p(qA, _u8p), _p(sA, _fp), _u64(rows), _u64(cols), _p(x, _fp), _p(r, _fp))
+        return r
+
     def m4_gemm(self, qA, sA, M, K, qB, sB, N) -> np.ndarray:
         c = np.zeros(M * N, np.float32)
         self.L.orc_m4_gemm(_p(qA, _u8p), _p(sA, _fp), _u64(M), _u64(K), _p(qB, _u8p), _p(sB, _fp), _u64(N), _p(c, _fp))

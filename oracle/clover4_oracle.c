@@ -466,6 +466,35 @@ void orc_v4_threshold(uint8_t *q, const float *s, uint64_t n, uint64_t k)
     free(h);
 }
 
+void orc_m4_mvm_f32(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const float *x, float *r)
+{
+    const uint64_t hb = cols >> 6;
+    for (uint64_t i = 0; i < rows; i++) {
+        const uint8_t *u = A + i * (cols / 2);
+        const float *su = sA + (i >> 6) * hb;
+        float acc[4][8];
+        memset(acc, 0, sizeof acc);
+        for (uint64_t b = 0; b < hb; b++) {
+            const float sc = su[b] / 7.0f;
+            for (int g = 0; g < 8; g++)                      /* acc_{g mod 4} gets group g; g and g+4 in this order */
+                for (int j = 0; j < 8; j++) {
+                    const uint64_t e = 64 * b + 8 * g + j;
+                    const float f = (float)nib_at(u, e) * sc;
+                    acc[g & 3][j] = fmaf(x[e], f, acc[g & 3][j]);
+                }
+        }
+        float s3[8], t[4];
+        for (int j = 0; j < 8; j++) {
+            const float s1 = acc[0][j] + acc[1][j];
+            const float s2 = acc[2][j] + acc[3][j];
+            s3[j] = s1 + s2;
+        }
+        for (int j = 0; j < 4; j++) t[j] = s3[j + 4] + s3[j];
+        const float y0 = t[0] + t[2], y1 = t[1] + t[3];
+        r[i] = y0 + y1;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* GEMM (build-defined; see header)                                                                  */
 /* ------------------------------------------------------------------------------------------------ */

@@ -80,6 +80,12 @@ void     orc_m4_transpose(const uint8_t *q, const float *s, uint64_t rows, uint6
  * the other nibbles; scales untouched.  Which of several EQUAL magnitudes survive depends on heap order. */
 void     orc_v4_threshold(uint8_t *q, const float *s, uint64_t n, uint64_t k);
 
+/* Mixed precision CloverMatrix4::mvm(const CloverVector32&, CloverVector32&) (CloverMatrix4.h:1451-1547):
+ * fp32 vector in, fp32 result out (no re-quantisation).  Per row 4 accumulators x 8 AVX lanes = 32 sequential
+ * fma chains, chain (e mod 32) takes elements e, e+32, ...: acc = fma(x[e], f32((float)q * f32(s/7)), acc);
+ * then (acc1+acc2)+(acc3+acc4) per lane and the CloverBase.h:149-157 tree. */
+void     orc_m4_mvm_f32(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const float *x, float *r);
+
 /*
  * GEMM -- no reference function exists; build-defined semantics:
  *   A is M x K, B is N x K (both CloverMatrix4 layouts), C = A * B^T, fp32, row-major M x N.

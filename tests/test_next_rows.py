@@ -201,3 +201,27 @@ def test_gpu_iht_loop_matches_oracle_loop(hip, oracle, mode):
     assert same(xq, x[0]) and same(xs, x[1])
     if stream:
         hip.check(hip.lib.clv_stream_destroy(stream))
+
+
+def test_oracle_mixed_mvm_is_dequantized_product(oracle):
+    rng = np.random.default_rng(4)
+    M, N = 128, 384
+    qA, _ = random_packed(rng, M * N)
+    sA = rng.uniform(0.5, 2, size=(M // 64) * (N // 64)).astype(np.float32)
+    x = rng.normal(size=N).astype(np.float32)
+    r = oracle.m4_mvm_f32(qA, sA, M, N, x)
+    Ad = (nibbles(qA).reshape(M, N).astype(np.float64) * np.repeat(np.repeat(sA.reshape(M // 64, N // 64), 64, 0), 64, 1) / 7.0)
+    assert np.allclose(r, Ad @ x.astype(np.float64), rtol=0, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 128), (256, 640), (384, 16384 + 128), (128, 65536)])
+def test_gpu_mixed_mvm_f32_bit_exact(hip, oracle, shape):
+    # the reference's own test compares with a double-accumulated scalar loop at 0.01 (03_matrix.cpp:419-491);
+    # here the 32-chain order is reproduced, so the fp32 results are identical
+    M, N = shape
+    rng = np.random.default_rng(M + N)
+    qA, _ = random_packed(rng, M * N)
+    sA = rng.uniform(0.5, 2, size=(M // 64) * (N // 64)).astype(np.float32)
+    x = rng.normal(size=N).astype(np.float32)
+    assert same(hip.m4_mvm_f32(qA, sA, M, N, x), oracle.m4_mvm_f32(qA, sA, M, N, x))
