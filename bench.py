@@ -228,13 +228,14 @@ def main() -> None:
         "metric": "int4 GEMV (CloverMatrix4::mvm) effective GB/s, algorithmic operand bytes / time",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int4 x int4 -> int32 word sums, fp32 scale/accumulate (reference order)", "data": "synthetic",
+        "dtype": "int4", "data": "synthetic",
         "config": {
             "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 (BASELINE configs[2] per GPU), x and result CloverVector4, "
                         f"STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
             "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of packed result" if world > 1 else ""),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_step": bytes_total,
+            "arithmetic": "int4 x int4 products summed exactly per 32-bit word (v_dot8_i32_i4), fp32 per-block scale + fma chains in reference order",
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -210,3 +210,20 @@ def test_bad_sizes_are_rejected(hip):
         hip.v4_quantize(np.zeros(100, np.float32))
     buf = hip.alloc(1024)
     assert hip.lib.clm4_mvm(buf.ptr, buf.ptr, 192, 128, buf.ptr, buf.ptr, buf.ptr, buf.ptr, None, None) == -1
+
+
+def test_degenerate_sizes(hip):
+    """n_pad == 0 / rows == 0 are accepted as no-ops (the reference's containers always hold >= 128 elements)"""
+    buf = hip.alloc(256)
+    lib = hip.lib
+    assert lib.clv4_quantize(buf.ptr, 0, buf.ptr, buf.ptr, None, None) == 0
+    assert lib.clv4_restore(buf.ptr, buf.ptr, 0, buf.ptr, None) == 0
+    assert lib.clv4_scale_and_add(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 1.0, 0, buf.ptr, buf.ptr, None, None) == 0
+    assert lib.clm4_mvm(buf.ptr, buf.ptr, 0, 128, buf.ptr, buf.ptr, buf.ptr, buf.ptr, None, None) == 0
+    assert lib.clm4_quantize(buf.ptr, 0, 0, buf.ptr, buf.ptr, None, None) == 0
+    assert lib.clm4_transpose(buf.ptr, buf.ptr, 0, 0, buf.offset(128), buf.ptr, None) == 0
+    out = hip.alloc(4)
+    hip.check(hip.lib.clv_memset(out.ptr, 0xFF, 4, None))
+    assert lib.clv4_dot(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 0, 0, out.ptr, None, None) == 0
+    assert out.download(np.float32, 1)[0] == 0.0
+    hip.sync()
