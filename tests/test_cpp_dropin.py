@@ -100,3 +100,18 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
     C = oracle.m4_gemm(qA, sA, 128, 256, qA, sA, 128)
     assert kv["gemm_c00"] == hex(bits(C[0, 0])) or int(kv["gemm_c00"], 16) == int(bits(C[0, 0]))
     assert int(kv["gemm_c_1_77"], 16) == int(bits(C[1, 77]))
+
+
+def test_error_convention_and_layout_without_gpu(tmp_path):
+    """message + exit(1) on shape errors, like the reference; host layout contract of the containers"""
+    lib = build_hip_library()
+    exe = tmp_path / "errs"
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "error_behaviour.cpp"),
+                    "-o", str(exe), f"-L{lib.parent}", "-lclover_hip", f"-Wl,-rpath,{lib.parent}", "-L/opt/rocm/lib",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    for case, msg in (("mvm", "MVM can not be performed. Exiting ..."), ("quantize", "Matrices do not have the same size. Exiting ..."),
+                      ("transpose", "Matrix can not be transposed. Exiting ...")):
+        p = subprocess.run([str(exe), case], capture_output=True, text=True)
+        assert p.returncode == 1 and msg in p.stdout and "not reached" not in p.stdout
+    p = subprocess.run([str(exe), "layout"], capture_output=True, text=True)
+    assert p.returncode == 0 and "layout ok" in p.stdout, (p.returncode, p.stdout)
