@@ -17,27 +17,39 @@ __device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_v4_scale_and_add(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
-                                                          const float *__restrict__ sv, float a, uint32_t *r, float *sr,
-                                                          uint64_t nwords)
+// lane = 4 dwords (half a block) of u and of v: 16-byte loads/stores, one shuffle for the block maximum
+template <bool NT>
+__global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
+                                                          const float *__restrict__ sv, float a, u32x4 *r, float *sr,
+                                                          uint64_t nquads)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
-        const uint64_t b = i >> 3;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += stride) {
+        const uint64_t b = i >> 1;
+        const u32x4 wu = NT ? __builtin_nontemporal_load(qu + i) : qu[i];
+        const u32x4 wv = NT ? __builtin_nontemporal_load(qv + i) : qv[i];
         const float su7 = su[b] / 7.0f;
         const float sv7 = (sv[b] * a) / 7.0f;
-        float v[8];
-        saa_values(qu[i], qv[i], su7, sv7, v);
+        float v[4][8];
+        saa_values(wu.x, wv.x, su7, sv7, v[0]);
+        saa_values(wu.y, wv.y, su7, sv7, v[1]);
+        saa_values(wu.z, wv.z, su7, sv7, v[2]);
+        saa_values(wu.w, wv.w, su7, sv7, v[3]);
         float m = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[q][e]));
         m = fmaxf(m, __shfl_xor(m, 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
-        m = fmaxf(m, __shfl_xor(m, 4));
         m = fix_zero_max(m);
         const float k = 7.0f / m;
-        r[i] = quant_pack8(v, k, nullptr);
-        if ((i & 7) == 0) sr[b] = m;
+        u32x4 o;
+        o.x = quant_pack8(v[0], k, nullptr);
+        o.y = quant_pack8(v[1], k, nullptr);
+        o.z = quant_pack8(v[2], k, nullptr);
+        o.w = quant_pack8(v[3], k, nullptr);
+        if (NT) __builtin_nontemporal_store(o, r + i); else r[i] = o;
+        if ((i & 1) == 0) sr[b] = m;
     }
 }
 
@@ -121,9 +133,15 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
     hipStream_t st = as_stream(stream);
     const uint64_t nwords = n_pad / 8, nb = n_pad / 64;
     if (!rng_state_dev) {
-        const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
-        hipLaunchKernelGGL(k_v4_scale_and_add, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const uint32_t *)qu, su,
-                           (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nwords);
+        const uint64_t nquads = nwords / 4;
+        const uint64_t want = (nquads + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+        const dim3 grid((unsigned)(want < cap ? want : cap));
+        if (3 * (n_pad / 2) > (256ull << 20))           // operands + result exceed the Infinity Cache: stream past it
+            hipLaunchKernelGGL(k_v4_scale_and_add<true>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a,
+                               (u32x4 *)r, sr, nquads);
+        else
+            hipLaunchKernelGGL(k_v4_scale_and_add<false>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a,
+                               (u32x4 *)r, sr, nquads);
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
