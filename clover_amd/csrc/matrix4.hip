@@ -2,7 +2,7 @@
 //
 // HBM layout = the reference's (CloverMatrix4.h:77-93, 123-139): row-major nibbles (rows*cols/2 bytes),
 // then one fp32 scale per 64x64 tile in a row-major (rows/64) x (cols/64) grid.
-#include "common.h"
+#include "rng_device.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -58,15 +58,22 @@ __device__ __forceinline__ void requantize_wave(float d, float noise, uint32_t *
     if (lane == 0) *sr = m;
 }
 
-template <int U, bool NT>
+// ST: stochastic re-quantisation fused into the epilogue (CloverMatrix4.h:919-1080 with the rnd_* branch).  Row group
+// rb consumes draws 2rb, 2rb+1 of the stream; the dots sit pre-transposed in the reference's block_values, so noise
+// group g of AVX lane j lands on row 8j+g: row l uses group g = l&7 (draw g>>2, byte g&3) of word W[l>>3].
+template <int U, bool NT, bool ST>
 __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A, const float *__restrict__ sA,
                                                   uint64_t cols, const uint8_t *__restrict__ x, const float *__restrict__ sx,
-                                                  float *__restrict__ d_out, uint32_t *__restrict__ r, float *__restrict__ sr)
+                                                  float *__restrict__ d_out, uint32_t *__restrict__ r, float *__restrict__ sr,
+                                                  uint64_t *rng_state, uint64_t seq, const uint64_t *__restrict__ pow_rows)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4 *xs = reinterpret_cast<u32x4 *>(smem);                        // MVM_CHUNK/2 bytes
     float *cs = reinterpret_cast<float *>(smem + MVM_CHUNK / 2);        // MVM_CHUNK/64 floats
     float *dsh = cs + MVM_CHUNK / 64;                                   // 64 floats
+    uint64_t *rbase = reinterpret_cast<uint64_t *>(dsh + 64);           // ST: 4 lane bases, 8 raw draws
+    uint64_t *raw = rbase + 4;
+    if (ST) rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, 2ull * gridDim.x, rbase);
 
     const uint64_t rb = blockIdx.x;
     const int tid = threadIdx.x;
@@ -129,8 +136,16 @@ __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A,
         dsh[rho] = dot;
         if (d_out) d_out[row] = dot;
     }
+    if (ST && tid < 4) gen_blocks(rbase[tid], 1, raw, tid);
     __syncthreads();
-    if (r && tid < 64) requantize_wave(dsh[tid], 0.0f, r + rb * 8, sr + rb);
+    if (r && tid < 64) {
+        float noise = 0.0f;
+        if (ST) {
+            const int grp = tid & 7, j = tid >> 3;
+            noise = noise_of(reinterpret_cast<const uint32_t *>(raw + (size_t)(grp >> 2) * 4)[j], grp & 3);
+        }
+        requantize_wave(dsh[tid], noise, r + rb * 8, sr + rb);
+    }
 }
 
 // ================================================================================================
@@ -205,22 +220,34 @@ __global__ __launch_bounds__(256) void k_m4_gemm_simple(const uint8_t *__restric
 // C ABI
 // ================================================================================================
 int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng, hipStream_t st);
-int clm4_requantize_stochastic(const float *d, uint64_t rows, int8_t *r, float *sr, uint64_t *rng, hipStream_t st);
 int clm4_gemm_mfma(const int8_t *A, const float *sA, uint64_t M, uint64_t K, const int8_t *B, const float *sB, uint64_t N, float *C, hipStream_t st);
 
+#define MVM_LDS_BYTES (MVM_CHUNK / 2 + (MVM_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 128)
+
 static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
-                      float *d, int8_t *r, float *sr, hipStream_t st)
+                      float *d, int8_t *r, float *sr, uint64_t *rng, hipStream_t st)
 {
-    const size_t lds = MVM_CHUNK / 2 + (MVM_CHUNK / 64) * sizeof(float) + 64 * sizeof(float);
+    const size_t lds = MVM_LDS_BYTES;
+    const dim3 grid((unsigned)(rows / 64)), block(256);
+    RngTables T = {nullptr, nullptr};
+    uint64_t seq = 0;
+    if (rng) {
+        int rc = clv_rng_tables(&T);
+        if (rc) return rc;
+        seq = clv_rng_next_seq();
+    }
+#define MVM_LAUNCH(NT, ST)                                                                                                 \
+    hipLaunchKernelGGL((k_m4_mvm64<8, NT, ST>), grid, block, lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, sx, d, \
+                       (uint32_t *)r, sr, rng, seq, T.pow_rows)
     // Streaming (nt) loads win once the matrix cannot live in the 256 MiB Infinity Cache (+14 % at 2 GiB); below
     // that, default-policy loads keep it cache-resident across calls (8192^2: 7.3 vs 11.9 us) -- measured, r01.
     const bool streaming = rows * (cols / 2) > (256ull << 20);
-    if (streaming)
-        hipLaunchKernelGGL((k_m4_mvm64<8, true>), dim3((unsigned)(rows / 64)), dim3(256), lds, st, (const uint8_t *)A, sA, cols,
-                           (const uint8_t *)x, sx, d, (uint32_t *)r, sr);
-    else
-        hipLaunchKernelGGL((k_m4_mvm64<8, false>), dim3((unsigned)(rows / 64)), dim3(256), lds, st, (const uint8_t *)A, sA, cols,
-                           (const uint8_t *)x, sx, d, (uint32_t *)r, sr);
+    if (streaming) {
+        if (rng) MVM_LAUNCH(true, true); else MVM_LAUNCH(true, false);
+    } else {
+        if (rng) MVM_LAUNCH(false, true); else MVM_LAUNCH(false, false);
+    }
+#undef MVM_LAUNCH
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -253,12 +280,12 @@ extern "C" int clvx_read_bw(const void *p, uint64_t bytes, int nt, int blocks_pe
 extern "C" int clvx_mvm_variant(int variant, const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x,
                                 const float *sx, int8_t *r, float *sr, void *stream)
 {
-    const size_t lds = MVM_CHUNK / 2 + (MVM_CHUNK / 64) * sizeof(float) + 64 * sizeof(float);
+    const size_t lds = MVM_LDS_BYTES;
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)(rows / 64)), block(256);
-#define CLVX_LAUNCH(U, NT)                                                                                               \
-    hipLaunchKernelGGL((k_m4_mvm64<U, NT>), grid, block, lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, sx, \
-                       (float *)nullptr, (uint32_t *)r, sr)
+#define CLVX_LAUNCH(U, NT)                                                                                                      \
+    hipLaunchKernelGGL((k_m4_mvm64<U, NT, false>), grid, block, lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, sx, \
+                       (float *)nullptr, (uint32_t *)r, sr, (uint64_t *)nullptr, 0ull, (const uint64_t *)nullptr)
     switch (variant) {
     case 0: CLVX_LAUNCH(8, true); break;
     case 1: CLVX_LAUNCH(8, false); break;
@@ -289,15 +316,7 @@ extern "C" int clm4_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_
     CLV_REQUIRE(r && sr, "clm4_mvm: null result pointer");
     if (!rows) return CLV_OK;
     hipStream_t st = as_stream(stream);
-    if (!rng_state_dev) return launch_mvm(A, sA, rows, cols, x, sx, nullptr, r, sr, st);
-    // stochastic: fp32 row dots to scratch, then the re-quantiser that walks the XORShift stream
-    void *ws = nullptr;
-    // row dots at the front, the XORShift prefix data (see rng4.hip) behind them
-    rc = clv_internal_workspace(&ws, ((rows * sizeof(float) + 255) & ~255ull) + ((rows / 64) * 4 + 8) * sizeof(uint64_t));
-    if (rc) return rc;
-    rc = launch_mvm(A, sA, rows, cols, x, sx, (float *)ws, nullptr, nullptr, st);
-    if (rc) return rc;
-    return clm4_requantize_stochastic((const float *)ws, rows, r, sr, rng_state_dev, st);
+    return launch_mvm(A, sA, rows, cols, x, sx, nullptr, r, sr, rng_state_dev, st);
 }
 
 extern "C" int clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
@@ -307,7 +326,7 @@ extern "C" int clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uin
     if (rc) return rc;
     CLV_REQUIRE(d, "clm4_rowdots: null result pointer");
     if (!rows) return CLV_OK;
-    return launch_mvm(A, sA, rows, cols, x, sx, d, nullptr, nullptr, as_stream(stream));
+    return launch_mvm(A, sA, rows, cols, x, sx, d, nullptr, nullptr, nullptr, as_stream(stream));
 }
 
 extern "C" int clm4_quantize(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream)

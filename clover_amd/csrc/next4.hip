@@ -1,7 +1,7 @@
 // next4.hip -- the callers either side of the hot path: scaleAndAdd, transpose, threshold.
 // Together with mvm these are all five steps of the reference's quantized IHT / GD iterations
 // (test/performance/01_measure.h:923-946, 999-1021), so x, t1..t3 can stay in HBM across iterations.
-#include "common.h"
+#include "rng_device.h"
 
 // =================================================================================================
 // f1  CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478):  r = quantize(u + a * v), per 64-block
@@ -55,35 +55,25 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const
 
 // stochastic variant: same segment walk as k_v4_quantize_st (rng4.hip); the nibbles are unpacked by bit
 // position there, so noise group g of AVX lane j meets element 8j + (g ^ 1) (CloverVector4.h:1236-1243).
-__host__ __device__ __forceinline__ uint64_t xs_T2(uint64_t a)
-{
-    const uint64_t t = a ^ (a << 23);
-    return t ^ a ^ (t >> 18) ^ (a >> 5);
-}
-
 __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
                                                              const float *__restrict__ sv, float a, uint32_t *r, float *sr,
-                                                             uint64_t nblocks, const uint64_t *__restrict__ starts,
-                                                             const uint64_t *__restrict__ segmat)
+                                                             uint64_t nblocks, uint64_t *state, uint64_t seq, RngTables T)
 {
     __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][64 * 2 * 4];
+    __shared__ uint64_t base[4];
+    SegRows<16> segs;
+    segs.load(T.seg_rows, (threadIdx.x >> 6) * 16);
+    rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, 10, 2 * nblocks, base);   // workgroup = 512 blocks = 2^10 draws
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint64_t *raw = raw_all[wave];
     const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
     const uint64_t blk0 = w * 128;
     const int seg = lane >> 2, k = lane & 3;
-    uint64_t st = starts[(uint64_t)blockIdx.x * 4 + k];      // workgroup base, then this segment's T^(16 e)
-    {
-        const uint64_t *M = segmat + 64 * (wave * 16 + seg);
-        uint64_t acc = 0;
-#pragma unroll 8
-        for (int i = 0; i < 64; i++) acc ^= (0 - ((st >> i) & 1ull)) & M[i];
-        st = acc;
-    }
+    uint64_t st = segs.starts(base);                          // workgroup base, then this segment's T^(16 e)
     for (int rr = 0; rr < 2; rr++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {                     // 4 blocks x 2 draws of this lane's segment
-            const uint64_t n = xs_T2(st);
+            const uint64_t n = xs_T(st);
             raw[(size_t)(4 * seg) * 8 + i * 4 + k] = n + st;
             st = n;
         }
@@ -120,10 +110,6 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
     }
 }
 
-int clv_rng_prefix(uint64_t *state, uint64_t count, int shift, uint64_t total, uint64_t **starts, uint64_t **fin, hipStream_t st);
-int clv_rng_commit(uint64_t *state, const uint64_t *fin, hipStream_t st);
-const uint64_t *clv_rng_segmat();
-
 extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
                                   int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream)
 {
@@ -145,14 +131,14 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
-    uint64_t *starts, *fin;
-    const uint64_t wgs = (nb + 511) / 512;                     // one base state per workgroup = 512 blocks = 2^10 draws
-    int rc = clv_rng_prefix(rng_state_dev, wgs, 10, 2 * nb, &starts, &fin, st);
+    RngTables T;
+    int rc = clv_rng_tables(&T);
     if (rc) return rc;
+    const uint64_t wgs = (nb + 511) / 512;
     hipLaunchKernelGGL(k_v4_scale_and_add_st, dim3((unsigned)wgs), dim3(256), 0, st, (const uint32_t *)qu, su,
-                       (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, starts, clv_rng_segmat());
+                       (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, rng_state_dev, clv_rng_next_seq(), T);
     CLV_LAUNCH_CHECK();
-    return clv_rng_commit(rng_state_dev, fin, st);
+    return CLV_OK;
 }
 
 // =================================================================================================

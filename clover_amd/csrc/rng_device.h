@@ -1,0 +1,174 @@
+// rng_device.h -- device-side pieces of the XORShift stream shared by rng4.hip, next4.hip and matrix4.hip.
+//
+// A draw never reads part1 (simdxorshift128plus.h:97-109 as written), so each generator lane k is one 64-bit
+// word a with  n = T(a), out = n + a, a <- n  and T linear over GF(2).  T^e is applied by square-and-multiply
+// over a table of T^(2^k); see rng4.hip for the tables.
+//
+// State buffer (CLV_RNG_STATE_BYTES = 256 = 32 x u64), two slots so that ONE launch can both read the state in
+// every workgroup and write the advanced state, without a grid-wide hand-over:
+//     slot i (i = 0, 1) at word 16 i:  [0..3] part1 lanes, [4..7] part2 lanes (the reference's two __m256i keys,
+//     CloverRandom.h:90-94), [8] = sequence number of the launch (or clv_rng_set call) that wrote the slot.
+// Every launch carries a host-side, process-wide increasing sequence number `seq`.  Readers use the slot with the
+// largest stamp below `seq`; workgroup 0 writes the state after the launch's draws into the OTHER slot and stamps
+// it with `seq` -- which readers of the same launch ignore whether or not they already see it.  Launches on one
+// state must be stream-ordered (they are a sequential stream by definition), and a captured hipGraph would replay
+// a stale `seq`: stochastic calls are not graph-capturable.
+#pragma once
+
+#include "common.h"
+
+#define RNG_POW_LEVELS 56
+#define RNG_SEG_MATS 64          // T^(16*e), e = 0..63: start of 8-block segment e relative to a workgroup base
+#define RNG_SLOT_WORDS 16        // u64 stride between the two state slots
+#define RNG_STAMP_WORD 8         // u64 index of the slot's sequence stamp
+
+// device tables, one allocation, all in ROW form (bit i of row j = bit j of the image of bit i), which is what the
+// whole-wave product below wants: pow_rows[56][64] = T^(2^k), seg_rows[64][64] = T^(16 e)
+struct RngTables {
+    const uint64_t *pow_rows;
+    const uint64_t *seg_rows;
+};
+int clv_rng_tables(RngTables *t);      // rng4.hip; builds the tables on first use per device
+uint64_t clv_rng_next_seq();           // runtime.hip; process-wide launch sequence number (>= 1)
+
+__host__ __device__ __forceinline__ uint64_t xs_T(uint64_t a)
+{
+    const uint64_t t = a ^ (a << 23);
+    return t ^ a ^ (t >> 18) ^ (a >> 5);
+}
+
+// r = M * v over GF(2); M is 64 columns (column i = image of bit i).  Per-lane form: every lane its own v.
+__host__ __device__ __forceinline__ uint64_t gf2_matvec(const uint64_t *M, uint64_t v)
+{
+    uint64_t r = 0;
+#pragma unroll 32
+    for (int i = 0; i < 64; i++) r ^= (0 - ((v >> i) & 1ull)) & M[i];
+    return r;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// bit j of M*v for the lane holding row j of M; the ballot of it over the wave is M*v
+__device__ __forceinline__ uint64_t wave_matvec(uint64_t row, uint64_t v)
+{
+    return __ballot(__popcll(row & v) & 1);
+}
+
+// Whole-wave form: T^(e << k0)(v) for wave-uniform v and e.  Lane j holds ROW j of the level's matrix, so bit j of
+// the product is the parity of (row & v) and the new v is one ballot: ~6 instructions per set bit of e, no
+// cross-lane traffic.  The rows of up to 8 levels are fetched together (one memory round trip per 8 bits of e),
+// and before v is touched, so that round trip overlaps the load that produces v.
+__device__ __forceinline__ uint64_t wave_pow_apply(const uint64_t *__restrict__ pow_rows, uint64_t v, uint64_t e, int k0)
+{
+    const int lane = threadIdx.x & 63;
+    e = uniform64(e);
+    const uint64_t *row = pow_rows + (size_t)k0 * 64 + lane;
+    uint64_t R[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) R[i] = ((e >> i) & 1ull) ? row[64 * i] : 0ull;
+    v = uniform64(v);
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((e >> i) & 1ull) v = wave_matvec(R[i], v);
+        e >>= 8;
+        if (!e) break;
+        row += 8 * 64;
+#pragma unroll
+        for (int i = 0; i < 8; i++) R[i] = ((e >> i) & 1ull) ? row[64 * i] : 0ull;
+    }
+    return v;
+}
+
+// the slot a launch with sequence number `seq` reads: largest stamp below seq
+__device__ __forceinline__ int rng_read_slot(const uint64_t *state, uint64_t seq)
+{
+    const uint64_t s0 = state[RNG_STAMP_WORD], s1 = state[RNG_SLOT_WORDS + RNG_STAMP_WORD];
+    return (s1 < seq && (s0 >= seq || s1 > s0)) ? 1 : 0;
+}
+
+// noise lane: byte `sh` of W, as the reference builds it (mask, shift left, int->float, * 2^-31)
+__device__ __forceinline__ float noise_of(uint32_t W, int sh)
+{
+    return (float)(int)((W & 0x7F7F7F7Fu) << (8 * sh)) * (1.0f / 2147483648.0f);
+}
+
+// generate the two draws of `nblk` consecutive blocks for generator lane k and store the raw 64-bit outputs
+// at raw[(blk*2 + draw)*4 + k]  (so W[2k], W[2k+1] of a draw are the two dwords of entry k)
+__device__ __forceinline__ uint64_t gen_blocks(uint64_t a, int nblk, uint64_t *raw, int k)
+{
+#pragma unroll
+    for (int i = 0; i < nblk * 2; i++) {
+        const uint64_t n = xs_T(a);
+        raw[i * 4 + k] = n + a;
+        a = n;
+    }
+    return a;
+}
+
+// Start-of-kernel step for 256-thread workgroups whose 4 waves map to the 4 generator lanes:
+// lds_base[k] = T^(index << shift)(a0[k]); workgroup 0 also writes the state after `total` (>= 1) draws
+// (part2 = T^total(a0), part1 = T^(total-1)(a0), exactly what `total` sequential draws leave behind).
+// Ends with a barrier: call from uniform control flow.
+__device__ __forceinline__ void rng_workgroup_begin(uint64_t *state, uint64_t seq, const uint64_t *__restrict__ pow_rows,
+                                                    uint64_t index, int shift, uint64_t total, uint64_t *lds_base)
+{
+    const int k = threadIdx.x >> 6;
+    const int slot = rng_read_slot(state, seq);
+    const uint64_t a0 = state[slot * RNG_SLOT_WORDS + 4 + k];
+    const uint64_t b = wave_pow_apply(pow_rows, a0, index, shift);
+    if ((threadIdx.x & 63) == 0) lds_base[k] = b;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        uint64_t *next = state + (slot ^ 1) * RNG_SLOT_WORDS;
+        const uint64_t f = wave_pow_apply(pow_rows, a0, total - 1, 0);
+        if ((threadIdx.x & 63) == 0) {
+            next[k] = f;
+            next[4 + k] = xs_T(f);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            next[RNG_STAMP_WORD] = seq;
+        }
+    } else {
+        __syncthreads();
+    }
+}
+
+// lane (seg = l>>2, k = l&3) <- SEG[seg0 + seg] * base[k]: the segment starts of one wave as NSEG*4 whole-wave
+// products.  Lane j holds row j of each of the wave's NSEG segment matrices (coalesced loads); load them BEFORE
+// rng_workgroup_begin so that they share its memory round trip.  All 64 lanes of the wave must take part.
+template <int NSEG>
+struct SegRows {
+    uint64_t R[NSEG];
+    __device__ __forceinline__ void load(const uint64_t *__restrict__ seg_rows, int seg0)
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int s = 0; s < NSEG; s++) R[s] = seg_rows[(size_t)(seg0 + s) * 64 + lane];
+    }
+    __device__ __forceinline__ uint64_t starts(const uint64_t *lds_base) const
+    {
+        const int lane = threadIdx.x & 63;
+        uint64_t b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) b[k] = uniform64(lds_base[k]);
+        uint64_t a = 0;
+#pragma unroll
+        for (int s = 0; s < NSEG; s++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t v = wave_matvec(R[s], b[k]);
+                a = (lane == 4 * s + k) ? v : a;
+            }
+        }
+        return a;
+    }
+};
+#endif

@@ -1,6 +1,8 @@
 // runtime.hip -- device/stream/memory plumbing, XORShift key handling and synthetic-data fills.
 #include "common.h"
 
+#include <atomic>
+
 #include <stdarg.h>
 #include <string.h>
 
@@ -188,12 +190,19 @@ static void canon_jump(uint64_t in0, uint64_t in1, uint64_t &out0, uint64_t &out
     out1 = b;
 }
 
+uint64_t clv_rng_next_seq()
+{
+    static std::atomic<uint64_t> seq{1};
+    return seq.fetch_add(1, std::memory_order_relaxed);
+}
+
 extern "C" int clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const uint64_t key2[4], void *stream)
 {
     CLV_REQUIRE(state_dev && key1 && key2, "clv_rng_set: null argument");
-    uint64_t st[8];
+    uint64_t st[CLV_RNG_STATE_BYTES / 8] = {0};      // slot 0 = keys + stamp, slot 1 empty with stamp 0 (rng_device.h)
     memcpy(st, key1, 32);
     memcpy(st + 4, key2, 32);
+    st[8] = clv_rng_next_seq();
     CLV_HIP(hipMemcpyAsync(state_dev, st, sizeof st, hipMemcpyHostToDevice, as_stream(stream)));
     CLV_HIP(hipStreamSynchronize(as_stream(stream)));   // st is a stack buffer
     return CLV_OK;
@@ -211,11 +220,12 @@ extern "C" int clv_rng_seed(uint64_t *state_dev, uint64_t key1, uint64_t key2, v
 extern "C" int clv_rng_get(const uint64_t *state_dev, uint64_t key1[4], uint64_t key2[4], void *stream)
 {
     CLV_REQUIRE(state_dev && key1 && key2, "clv_rng_get: null argument");
-    uint64_t st[8];
+    uint64_t st[CLV_RNG_STATE_BYTES / 8];
     CLV_HIP(hipMemcpyAsync(st, state_dev, sizeof st, hipMemcpyDeviceToHost, as_stream(stream)));
     CLV_HIP(hipStreamSynchronize(as_stream(stream)));
-    memcpy(key1, st, 32);
-    memcpy(key2, st + 4, 32);
+    const uint64_t *cur = st[16 + 8] > st[8] ? st + 16 : st;      // the slot stamped last
+    memcpy(key1, cur, 32);
+    memcpy(key2, cur + 4, 32);
     return CLV_OK;
 }
 

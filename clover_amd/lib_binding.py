@@ -166,7 +166,7 @@ class CloverHip:
         return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}
 
     def new_rng(self, key1: int, key2: int) -> DevBuf:
-        st = self.alloc(64)
+        st = self.alloc(256)      # CLV_RNG_STATE_BYTES
         self.check(self.lib.clv_rng_seed(st.ptr, key1, key2, None))
         return st
 

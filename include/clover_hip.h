@@ -71,10 +71,13 @@ int  clv_event_sync(void *event);
 int  clv_event_elapsed_ms(void *start, void *stop, float *ms);
 
 /* ---- XORShift state (CloverRandom.h:90-114, simdxorshift128plus.h:47-109) ------------------------ */
-/* The generator state lives in device memory: 8 x uint64 = s0[4], s1[4] (random_key1, random_key2).
- * clv_rng_seed() reproduces avx_xorshift128plus_init(key1, key2) on the host and uploads it;
- * clv_rng_set() uploads explicit keys (CloverRandom::setRandomKeys). */
-#define CLV_RNG_STATE_BYTES 64
+/* The generator state lives in a CLV_RNG_STATE_BYTES device buffer: 8 x uint64 = s0[4], s1[4] (random_key1,
+ * random_key2), kept twice plus launch stamps so that a kernel can advance the state inside its own launch.
+ * Initialise it with clv_rng_seed() (reproduces avx_xorshift128plus_init(key1, key2) on the host and uploads
+ * it) or clv_rng_set() (explicit keys, CloverRandom::setRandomKeys); never write the buffer directly.
+ * Calls that share a state must be ordered (same stream, or synchronised) -- they consume one sequential
+ * stream -- and must not be captured into a hipGraph (each call carries a fresh launch stamp). */
+#define CLV_RNG_STATE_BYTES 256
 int  clv_rng_seed(uint64_t *state_dev, uint64_t key1, uint64_t key2, void *stream);
 int  clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const uint64_t key2[4], void *stream);
 int  clv_rng_get(const uint64_t *state_dev, uint64_t key1[4], uint64_t key2[4], void *stream); /* syncs */

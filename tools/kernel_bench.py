@@ -5,6 +5,7 @@ Algorithmic bytes per element follow SURVEY 8(d): quantize/restore 4.5625, dot 1
 threshold 0.5625 read per pass (reported as time only), transpose 2 x (1/2 + 4/4096), matrix quantize 4.5625."""
 import ctypes as C
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -39,7 +40,13 @@ def timeit(fn, reps=10, rounds=5, warm=2):
 res = {}
 
 
-def rec(name, nbytes, ms, extra=None):
+ONLY = os.environ.get("KB_ONLY")      # substring filter: KB_ONLY=scale_and_add python tools/kernel_bench.py
+
+
+def rec(name, nbytes, fn, extra=None, reps=10):
+    if ONLY and ONLY not in name:
+        return
+    ms = timeit(fn, reps=reps)
     res[name] = {"ms": round(ms, 5), "GB/s": round(nbytes / ms / 1e6, 1), "frac_of_8TBs": round(nbytes / ms / 1e6 / 8000.0, 4)}
     if extra:
         res[name].update(extra)
@@ -55,18 +62,20 @@ for logn in (24, 30):
     q3, s3 = hip.alloc(n // 2), hip.alloc(n // 16)
     out = hip.alloc(8)
     rng = hip.new_rng(1, 2)
-    rec(f"quantize_n2^{logn}", 4.5625 * n, timeit(lambda: hip.check(lib.clv4_quantize(x.ptr, n, q.ptr, s.ptr, None, None))))
-    rec(f"quantize_stochastic_n2^{logn}", 4.5625 * n, timeit(lambda: hip.check(lib.clv4_quantize(x.ptr, n, q2.ptr, s2.ptr, rng.ptr, None))))
-    rec(f"dot_fast_n2^{logn}", 1.125 * n, timeit(lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_FAST, out.ptr, None, None))))
-    rec(f"scale_and_add_n2^{logn}", 1.6875 * n, timeit(lambda: hip.check(lib.clv4_scale_and_add(q.ptr, s.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, None, None))))
-    rec(f"scale_and_add_stochastic_n2^{logn}", 1.6875 * n, timeit(lambda: hip.check(lib.clv4_scale_and_add(q.ptr, s.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, rng.ptr, None))))
-    rec(f"restore_n2^{logn}", 4.5625 * n, timeit(lambda: hip.check(lib.clv4_restore(q.ptr, s.ptr, n, x.ptr, None))))
+    hip.check(lib.clv4_quantize(x.ptr, n, q.ptr, s.ptr, None, None))         # operands exist even when KB_ONLY skips the timed calls
+    hip.check(lib.clv4_quantize(x.ptr, n, q2.ptr, s2.ptr, None, None))
+    rec(f"quantize_n2^{logn}", 4.5625 * n, lambda: hip.check(lib.clv4_quantize(x.ptr, n, q.ptr, s.ptr, None, None)))
+    rec(f"quantize_stochastic_n2^{logn}", 4.5625 * n, lambda: hip.check(lib.clv4_quantize(x.ptr, n, q2.ptr, s2.ptr, rng.ptr, None)))
+    rec(f"dot_fast_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_FAST, out.ptr, None, None)))
+    rec(f"scale_and_add_n2^{logn}", 1.6875 * n, lambda: hip.check(lib.clv4_scale_and_add(q.ptr, s.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, None, None)))
+    rec(f"scale_and_add_stochastic_n2^{logn}", 1.6875 * n, lambda: hip.check(lib.clv4_scale_and_add(q.ptr, s.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, rng.ptr, None)))
+    rec(f"restore_n2^{logn}", 4.5625 * n, lambda: hip.check(lib.clv4_restore(q.ptr, s.ptr, n, x.ptr, None)))
     if logn == 24:
         k = n // 4
         hip.check(lib.clv_memcpy_d2d(q3.ptr, q.ptr, n // 2, None))
-        rec(f"threshold_k25pct_n2^{logn}", 0.5625 * n * 5, timeit(lambda: hip.check(lib.clv4_threshold(q3.ptr, s.ptr, n, n, k, None, None)), reps=3),
-            {"note": "5 passes over nibbles+scales (3 histogram, tie count, apply) + 4 tiny kernels"})
-        rec(f"dot_exact_n2^{logn}", 1.125 * n, timeit(lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2))
+        rec(f"threshold_k25pct_n2^{logn}", 0.5625 * n * 5, lambda: hip.check(lib.clv4_threshold(q3.ptr, s.ptr, n, n, k, None, None)), reps=3,
+            extra={"note": "5 passes over nibbles+scales (3 histogram, tie count, apply) + 4 tiny kernels"})
+        rec(f"dot_exact_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2)
     del x, q, s, q2, s2, q3, s3
 
 # ---- matrix ops: 32768 x 32768 (4 GiB fp32 source, 512 MiB quantized)
@@ -76,14 +85,14 @@ hip.check(lib.clv_fill_random_ints_f32(A.ptr, M * N, 10, 6, 0, None))
 qA, sA = hip.alloc(M * N // 2), hip.alloc((M // 64) * (N // 64) * 4)
 qT, sT = hip.alloc(M * N // 2), hip.alloc((M // 64) * (N // 64) * 4)
 rngm = hip.new_rng(3, 4)
-rec("matrix_quantize_32768^2", 4.5625 * M * N, timeit(lambda: hip.check(lib.clm4_quantize(A.ptr, M, N, qA.ptr, sA.ptr, None, None)), reps=3))
-rec("matrix_quantize_stochastic_32768^2", 4.5625 * M * N, timeit(lambda: hip.check(lib.clm4_quantize(A.ptr, M, N, qT.ptr, sT.ptr, rngm.ptr, None)), reps=3))
-rec("transpose_32768^2", 2 * (M * N // 2 + 4 * (M // 64) * (N // 64)), timeit(lambda: hip.check(lib.clm4_transpose(qA.ptr, sA.ptr, M, N, qT.ptr, sT.ptr, None)), reps=3))
+rec("matrix_quantize_32768^2", 4.5625 * M * N, lambda: hip.check(lib.clm4_quantize(A.ptr, M, N, qA.ptr, sA.ptr, None, None)), reps=3)
+rec("matrix_quantize_stochastic_32768^2", 4.5625 * M * N, lambda: hip.check(lib.clm4_quantize(A.ptr, M, N, qT.ptr, sT.ptr, rngm.ptr, None)), reps=3)
+rec("transpose_32768^2", 2 * (M * N // 2 + 4 * (M // 64) * (N // 64)), lambda: hip.check(lib.clm4_transpose(qA.ptr, sA.ptr, M, N, qT.ptr, sT.ptr, None)), reps=3)
 x, sx = hip.alloc(N // 2), hip.alloc(N // 16)
 r, sr = hip.alloc(M // 2), hip.alloc(M // 16)
 hip.check(lib.clv_fill_random_nibbles(x.ptr, x.nbytes, 9, 0, None))
 hip.check(lib.clv_fill_random_scales(sx.ptr, sx.nbytes // 4, 10, 0, None))
 mvb = M * N // 2 + 4 * (M // 64) * (N // 64) + (N // 2 + N // 16) + (M // 2 + M // 16)
-rec("mvm_32768^2", mvb, timeit(lambda: hip.check(lib.clm4_mvm(qA.ptr, sA.ptr, M, N, x.ptr, sx.ptr, r.ptr, sr.ptr, None, None))))
-rec("mvm_stochastic_32768^2", mvb, timeit(lambda: hip.check(lib.clm4_mvm(qA.ptr, sA.ptr, M, N, x.ptr, sx.ptr, r.ptr, sr.ptr, rngm.ptr, None))))
+rec("mvm_32768^2", mvb, lambda: hip.check(lib.clm4_mvm(qA.ptr, sA.ptr, M, N, x.ptr, sx.ptr, r.ptr, sr.ptr, None, None)))
+rec("mvm_stochastic_32768^2", mvb, lambda: hip.check(lib.clm4_mvm(qA.ptr, sA.ptr, M, N, x.ptr, sx.ptr, r.ptr, sr.ptr, rngm.ptr, None)))
 print(json.dumps(res, indent=1))
