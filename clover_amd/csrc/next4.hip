@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
             st = n;
         }
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 8
         for (int u = 0; u < 8; u++) {
             const int bl = 8 * u + (lane >> 3), rho = lane & 7;
             const uint64_t blk = blk0 + (uint64_t)(bl >> 2) * 8 + 4 * rr + (bl & 3);

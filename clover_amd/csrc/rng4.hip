@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict_
         // 4 blocks of this lane's segment: local block id = 4*seg + i
         a = gen_blocks(a, 4, raw + (size_t)(4 * seg) * 8, k);
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 8
         for (int u = 0; u < 8; u++) {
             const int bl = 8 * u + (lane >> 3);                     // local block 0..63
             const int rho = lane & 7;
