@@ -338,6 +338,17 @@ def extras(hip, torch, dev, stream) -> dict:
         hip.check(lib.clv4_scale_and_add(xq.data_ptr(), xs_.data_ptr(), t3q.data_ptr(), t3s.data_ptr(), 1e-3, nn, xq.data_ptr(), xs_.data_ptr(), None, stream))
         hip.check(lib.clv4_threshold(xq.data_ptr(), xs_.data_ptr(), nn, nn, m // 4, None, stream))
     i_ms = timeit(iht_iter, 100)
+    # the reference's default build rounds stochastically: same loop, every re-quantisation drawing from one XORShift stream
+    rng_state = hip.new_rng(5, 6)
+
+    def iht_iter_st():
+        rs = rng_state.ptr
+        hip.check(lib.clm4_mvm(Phi.data_ptr(), sPhi.data_ptr(), m, nn, xq.data_ptr(), xs_.data_ptr(), t1q.data_ptr(), t1s.data_ptr(), rs, stream))
+        hip.check(lib.clv4_scale_and_add(yq.data_ptr(), ys_.data_ptr(), t1q.data_ptr(), t1s.data_ptr(), -1.0, m, t2q.data_ptr(), t2s.data_ptr(), rs, stream))
+        hip.check(lib.clm4_mvm(PhiT.data_ptr(), sPhiT.data_ptr(), nn, m, t2q.data_ptr(), t2s.data_ptr(), t3q.data_ptr(), t3s.data_ptr(), rs, stream))
+        hip.check(lib.clv4_scale_and_add(xq.data_ptr(), xs_.data_ptr(), t3q.data_ptr(), t3s.data_ptr(), 1e-3, nn, xq.data_ptr(), xs_.data_ptr(), rs, stream))
+        hip.check(lib.clv4_threshold(xq.data_ptr(), xs_.data_ptr(), nn, nn, m // 4, None, stream))
+    s_ms = timeit(iht_iter_st, 100)
     # the same loop as ONE C call (clm4_iht enqueues all iterations from C++)
     import ctypes as C
     side = C.c_void_p()
@@ -356,6 +367,7 @@ def extras(hip, torch, dev, stream) -> dict:
     hip.check(lib.clv_stream_destroy(side))
     iht_bytes = 2 * (m * nn // 2 + 4 * (m // 64) * (nn // 64)) + (2 * nn + 3 * m) * 9 // 16
     iht = {"ms_per_iteration": round(i_ms, 5), "GB/s": round(iht_bytes / i_ms / 1e6, 1),
+           "ms_per_iteration_stochastic": round(s_ms, 5), "GB/s_stochastic": round(iht_bytes / s_ms / 1e6, 1),
            "ms_per_iteration_clm4_iht": round(g_ms, 5), "GB/s_clm4_iht": round(iht_bytes / g_ms / 1e6, 1),
            "note": "Q_IHT step sequence (mvm, scaleAndAdd, mvm^T, scaleAndAdd, threshold) at N=8192 (4096x8192), bytes counted like "
                    "01_measure.h:1117-1125; reference published 19.5 GB/s with 4 threads (performance.txt:581)"}

@@ -55,58 +55,65 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const
 
 // stochastic variant: same segment walk as k_v4_quantize_st (rng4.hip); the nibbles are unpacked by bit
 // position there, so noise group g of AVX lane j meets element 8j + (g ^ 1) (CloverVector4.h:1236-1243).
+template <int S>
 __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
                                                              const float *__restrict__ sv, float a, uint32_t *r, float *sr,
                                                              uint64_t nblocks, uint64_t *state, uint64_t seq, RngTables T)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][64 * 2 * 4];
+    typedef StShape<S> Sh;
+    __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][Sh::NBR * 2 * 4];
     __shared__ uint64_t base[4];
-    SegRows<16> segs;
-    segs.load(T.seg_rows, (threadIdx.x >> 6) * 16);
-    rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, 10, 2 * nblocks, base);   // workgroup = 512 blocks = 2^10 draws
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    SegRows<S> segs;
+    segs.load(T.seg_rows, wave * S);
+    rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
     uint64_t *raw = raw_all[wave];
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
-    const uint64_t blk0 = w * 128;
-    const int seg = lane >> 2, k = lane & 3;
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
+    const int seg = lane >> 2, k = lane & 3, rho = lane & 7;
     uint64_t st = segs.starts(base);                          // workgroup base, then this segment's T^(16 e)
-    for (int rr = 0; rr < 2; rr++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {                     // 4 blocks x 2 draws of this lane's segment
-            const uint64_t n = xs_T(st);
-            raw[(size_t)(4 * seg) * 8 + i * 4 + k] = n + st;
-            st = n;
-        }
+    for (int rr = 0; rr < Sh::ROUNDS; rr++) {
+        if (lane < 4 * S) st = gen_blocks(st, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
-#pragma unroll 8
-        for (int u = 0; u < 8; u++) {
-            const int bl = 8 * u + (lane >> 3), rho = lane & 7;
-            const uint64_t blk = blk0 + (uint64_t)(bl >> 2) * 8 + 4 * rr + (bl & 3);
+        uint32_t wu[Sh::STEPS], wv[Sh::STEPS];
+        float fu[Sh::STEPS], fv[Sh::STEPS];
+#pragma unroll
+        for (int u = 0; u < Sh::STEPS; u++) {                 // all loads of the round first (r may alias qu: loads precede stores per block)
+            const uint64_t blk = Sh::block(blk0, rr, 8 * u + (lane >> 3));
+            const uint64_t b = blk < nblocks ? blk : 0;
+            wu[u] = qu[b * 8 + rho];
+            wv[u] = qv[b * 8 + rho];
+            fu[u] = su[b];
+            fv[u] = sv[b];
+        }
+#pragma unroll
+        for (int u = 0; u < Sh::STEPS; u++) {
+            const int bl = 8 * u + (lane >> 3);
+            const uint64_t blk = Sh::block(blk0, rr, bl);
+            float v[8];
+            saa_values(wu[u], wv[u], fu[u] / 7.0f, (fv[u] * a) / 7.0f, v);
+            float m = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            m = fix_zero_max(m);
+            const float kq = 7.0f / m;
+            const uint32_t *W32 = reinterpret_cast<const uint32_t *>(raw + (size_t)(bl * 2) * 4);
+            const uint32_t Wd[2] = {W32[rho], W32[8 + rho]};          // W[j = rho] of draw 0 and draw 1
+            float nz[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int g = e ^ 1;
+                nz[e] = noise_of(Wd[g >> 2], g & 3);
+            }
+            const uint32_t packed = quant_pack8(v, kq, nz);
             if (blk < nblocks) {
-                const uint64_t i = blk * 8 + rho;
-                float v[8];
-                saa_values(qu[i], qv[i], su[blk] / 7.0f, (sv[blk] * a) / 7.0f, v);
-                float m = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
-                m = fmaxf(m, __shfl_xor(m, 1));
-                m = fmaxf(m, __shfl_xor(m, 2));
-                m = fmaxf(m, __shfl_xor(m, 4));
-                m = fix_zero_max(m);
-                const float kq = 7.0f / m;
-                const uint32_t *W32 = reinterpret_cast<const uint32_t *>(raw + (size_t)(bl * 2) * 4);
-                const uint32_t Wd[2] = {W32[rho], W32[8 + rho]};          // W[j = rho] of draw 0 and draw 1
-                float nz[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int g = e ^ 1;
-                    nz[e] = (float)(int)((Wd[g >> 2] & 0x7F7F7F7Fu) << (8 * (g & 3))) * (1.0f / 2147483648.0f);
-                }
-                r[i] = quant_pack8(v, kq, nz);
+                r[blk * 8 + rho] = packed;
                 if (rho == 0) sr[blk] = m;
             }
         }
-        __syncthreads();
+        if (rr + 1 < Sh::ROUNDS) __syncthreads();
     }
 }
 
@@ -134,9 +141,16 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
     RngTables T;
     int rc = clv_rng_tables(&T);
     if (rc) return rc;
-    const uint64_t wgs = (nb + 511) / 512;
-    hipLaunchKernelGGL(k_v4_scale_and_add_st, dim3((unsigned)wgs), dim3(256), 0, st, (const uint32_t *)qu, su,
-                       (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, rng_state_dev, clv_rng_next_seq(), T);
+    const uint64_t seq = clv_rng_next_seq();
+#define SAA_LAUNCH(S)                                                                                                                  \
+    hipLaunchKernelGGL(k_v4_scale_and_add_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const uint32_t *)qu, \
+                       su, (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, rng_state_dev, seq, T)
+    switch (clv_st_segments(nb)) {
+    case 1: SAA_LAUNCH(1); break;
+    case 4: SAA_LAUNCH(4); break;
+    default: SAA_LAUNCH(16); break;
+    }
+#undef SAA_LAUNCH
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

@@ -14,6 +14,8 @@
 // State in device memory: rng_device.h.
 #include "rng_device.h"
 
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
@@ -60,61 +62,67 @@ int clv_rng_tables(RngTables *t)
 }
 
 // ---- vector quantize, stochastic (CloverVector4.h:605-807 with the rnd_* branch) --------------------
-// wave = 128 consecutive blocks = 16 segments of 8; lane (seg = l>>2, k = l&3) generates its segment's
-// draws 4 blocks at a time into LDS; then lane = 8 elements quantises 8 blocks per sub-step.
+// wave = S segments of 8 consecutive blocks; lane (seg = l>>2, k = l&3) generates its segment's draws into LDS
+// (S = 16: four blocks per round, two rounds); then lane = 8 elements quantises 8 blocks per sub-step, all loads of a
+// round in flight together.  S is picked by size (st_segments): small vectors want many short waves, because one
+// wave walks its blocks serially; large ones want the jump-ahead amortised over 128 blocks.
 // noise group g = element/8 (draw g>>2, byte g&3), AVX lane j = element%8 -> W[j].
-#define SQ_WAVE_BLOCKS 128
-
+template <int S>
 __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict__ x, uint32_t *__restrict__ q, float *__restrict__ s,
                                                         uint64_t nblocks, uint64_t *state, uint64_t seq, RngTables T)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][64 * 2 * 4];   // per wave: 64 blocks x 2 draws x 4 lanes
+    typedef StShape<S> Sh;
+    __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][Sh::NBR * 2 * 4];   // per wave: NBR blocks x 2 draws x 4 lanes
     __shared__ uint64_t base[4];
-    SegRows<16> segs;
-    segs.load(T.seg_rows, (threadIdx.x >> 6) * 16);
-    rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, 10, 2 * nblocks, base);   // workgroup = 512 blocks = 2^10 draws
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
+    SegRows<S> segs;
+    segs.load(T.seg_rows, wave * S);
+    rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
     uint64_t *raw = raw_all[wave];
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;            // global wave index
-    const uint64_t blk0 = w * SQ_WAVE_BLOCKS;
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
     const int seg = lane >> 2, k = lane & 3;
     // start of this lane's 8-block segment = T^(16 * e) applied to the workgroup's base state
     uint64_t a = segs.starts(base);
+    const int rho = lane & 7;
 
-    for (int r = 0; r < 2; r++) {
-        // 4 blocks of this lane's segment: local block id = 4*seg + i
-        a = gen_blocks(a, 4, raw + (size_t)(4 * seg) * 8, k);
+    for (int r = 0; r < Sh::ROUNDS; r++) {
+        if (lane < 4 * S) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
-#pragma unroll 8
-        for (int u = 0; u < 8; u++) {
-            const int bl = 8 * u + (lane >> 3);                     // local block 0..63
-            const int rho = lane & 7;
-            const uint64_t blk = blk0 + (uint64_t)(bl >> 2) * 8 + 4 * r + (bl & 3);
+        f32x4 lo[Sh::STEPS], hi[Sh::STEPS];
+#pragma unroll
+        for (int u = 0; u < Sh::STEPS; u++) {
+            const uint64_t blk = Sh::block(blk0, r, 8 * u + (lane >> 3));
+            const uint64_t i = blk < nblocks ? blk * 8 + rho : 0;           // output dword index (clamped: block 0 always exists)
+            lo[u] = __builtin_nontemporal_load(&x[2 * i]);
+            hi[u] = __builtin_nontemporal_load(&x[2 * i + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < Sh::STEPS; u++) {
+            const int bl = 8 * u + (lane >> 3);
+            const uint64_t blk = Sh::block(blk0, r, bl);
+            const float v[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            float m = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            m = fix_zero_max(m);
+            const float kq = 7.0f / m;
+            const u32x4 *Wp = reinterpret_cast<const u32x4 *>(raw + (size_t)(bl * 2 + (rho >> 2)) * 4);
+            const u32x4 W0 = Wp[0], W1 = Wp[1];
+            const uint32_t W[8] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
+            float nz[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) nz[e] = noise_of(W[e], rho & 3);
+            const uint32_t packed = quant_pack8(v, kq, nz);
             if (blk < nblocks) {
-                const uint64_t i = blk * 8 + rho;                   // output dword index
-                const f32x4 lo = __builtin_nontemporal_load(&x[2 * i]);
-                const f32x4 hi = __builtin_nontemporal_load(&x[2 * i + 1]);
-                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                float m = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
-                m = fmaxf(m, __shfl_xor(m, 1));
-                m = fmaxf(m, __shfl_xor(m, 2));
-                m = fmaxf(m, __shfl_xor(m, 4));
-                m = fix_zero_max(m);
-                const float kq = 7.0f / m;
-                const u32x4 *Wp = reinterpret_cast<const u32x4 *>(raw + (size_t)(bl * 2 + (rho >> 2)) * 4);
-                const u32x4 W0 = Wp[0], W1 = Wp[1];
-                const uint32_t W[8] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
-                float nz[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) nz[e] = noise_of(W[e], rho & 3);
-                q[i] = quant_pack8(v, kq, nz);
+                q[blk * 8 + rho] = packed;
                 if (rho == 0) s[blk] = m;
             }
         }
-        __syncthreads();
+        if (r + 1 < Sh::ROUNDS) __syncthreads();
     }
 }
 
@@ -177,15 +185,39 @@ __global__ __launch_bounds__(256) void k_m4_quantize_st(const float *__restrict_
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
+// segments (of 8 blocks) per wave for the vector kernels.  The choice never changes results, only speed;
+// clvx_set_st_segments (tests, experiments; not in the public header) or CLV_ST_SEGMENTS=1|4|16 force one shape.
+static int g_st_forced = [] { const char *e = getenv("CLV_ST_SEGMENTS"); return e ? atoi(e) : 0; }();
+
+extern "C" int clvx_set_st_segments(int s)
+{
+    CLV_REQUIRE(s == 0 || s == 1 || s == 4 || s == 16, "clvx_set_st_segments: %d is not one of 0, 1, 4, 16", s);
+    g_st_forced = s;
+    return CLV_OK;
+}
+
+int clv_st_segments(uint64_t nblocks)
+{
+    if (g_st_forced == 1 || g_st_forced == 4 || g_st_forced == 16) return g_st_forced;
+    return nblocks <= 8192 ? 1 : nblocks <= (1u << 18) ? 4 : 16;
+}
+
 int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng, hipStream_t st)
 {
     RngTables T;
     int rc = clv_rng_tables(&T);
     if (rc) return rc;
     const uint64_t nb = n_pad / 64;
-    const uint64_t wgs = (nb + 4 * SQ_WAVE_BLOCKS - 1) / (4 * SQ_WAVE_BLOCKS);
-    hipLaunchKernelGGL(k_v4_quantize_st, dim3((unsigned)wgs), dim3(256), 0, st, (const f32x4 *)x, (uint32_t *)q, s, nb, rng,
-                       clv_rng_next_seq(), T);
+    const uint64_t seq = clv_rng_next_seq();
+#define QST_LAUNCH(S)                                                                                                          \
+    hipLaunchKernelGGL(k_v4_quantize_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const f32x4 *)x, \
+                       (uint32_t *)q, s, nb, rng, seq, T)
+    switch (clv_st_segments(nb)) {
+    case 1: QST_LAUNCH(1); break;
+    case 4: QST_LAUNCH(4); break;
+    default: QST_LAUNCH(16); break;
+    }
+#undef QST_LAUNCH
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

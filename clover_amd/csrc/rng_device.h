@@ -171,4 +171,18 @@ struct SegRows {
         return a;
     }
 };
+
+// shape of the vector stochastic kernels (quantize, scaleAndAdd): wave = S segments of 8 blocks
+template <int S>
+struct StShape {
+    static constexpr int ROUNDS = S == 16 ? 2 : 1;
+    static constexpr int BPR = 8 / ROUNDS;              // blocks per segment per round
+    static constexpr int NBR = S * BPR;                 // blocks per wave per round (<= 64)
+    static constexpr int STEPS = NBR / 8;               // 8 blocks (64 lanes x 8 elements) per step
+    static constexpr int SHIFT = 6 + (S == 16 ? 4 : S == 4 ? 2 : 0);     // log2(draws per workgroup = 4 waves x 16 S)
+    // global block of (round r, local block bl): segment bl / BPR, block BPR r + bl % BPR inside it
+    __device__ static __forceinline__ uint64_t block(uint64_t blk0, int r, int bl) { return blk0 + (uint64_t)(bl / BPR) * 8 + BPR * r + (bl % BPR); }
+};
+
+int clv_st_segments(uint64_t nblocks);     // rng4.hip: S by size
 #endif

@@ -188,6 +188,35 @@ def test_stochastic_vector_quantize_same_stream(hip, oracle, n):
     assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
 
 
+@pytest.mark.parametrize("segments", [1, 4, 16])
+def test_stochastic_vector_ops_every_kernel_shape(hip, oracle, segments):
+    """The size-picked kernel shape (segments per wave) must not change a bit: force each one on sizes that span several
+    workgroups of that shape (32 * segments blocks each) with a ragged tail, for quantize and scaleAndAdd, two calls each."""
+    n = 64 * (32 * segments * 5 + 7 * segments + 3)
+    n += (-n) % 128
+    rng = np.random.default_rng(segments)
+    x = (rng.normal(size=n) * 3).astype(np.float32)
+    (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
+    assert hip.lib.clvx_set_st_segments(segments) == 0
+    try:
+        st, o = hip.new_rng(77, 88), oracle.rng(77, 88)
+        for _ in range(2):
+            q, s = hip.v4_quantize(x, rng=st)
+            qo, so = oracle.v4_quantize(x, o)
+            assert same(q, qo) and same(s, so)
+            r, sr = hip.v4_scale_and_add(qu, su, qv, sv, 0.75, rng=st)
+            ro, sro = oracle.v4_scale_and_add(qu, su, qv, sv, 0.75, o)
+            assert same(r, ro) and same(sr, sro)
+        r, sr = hip.v4_scale_and_add(qu, su, qv, sv, -0.5, rng=st, in_place=True)      # x += a*v, the IHT update
+        ro, sro = oracle.v4_scale_and_add(qu, su, qv, sv, -0.5, o)
+        assert same(r, ro) and same(sr, sro)
+        k1, k2 = hip.rng_get(st)
+        o1, o2 = oracle.rng_keys(o)
+        assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
+    finally:
+        hip.lib.clvx_set_st_segments(0)
+
+
 def test_stochastic_matrix_quantize_and_mvm_same_stream(hip, oracle):
     rng = np.random.default_rng(8)
     M, N = 256, 384

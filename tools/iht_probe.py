@@ -24,7 +24,8 @@ def vec(k, sd):
 
 
 x, y, t1, t2, t3 = vec(n, 41), vec(m, 43), vec(m, 45), vec(m, 47), vec(n, 49)
+rng = hip.new_rng(5, 6) if len(sys.argv) > 1 and sys.argv[1] == "st" else None      # "st": stochastic rounding
 hip.check(lib.clm4_iht(Phi.ptr, sPhi.ptr, PhiT.ptr, sPhiT.ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
-                       t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 3, m // 4, 1e-3, 1, None, None))
+                       t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 20, m // 4, 1e-3, 1, rng.ptr if rng else None, None))
 hip.sync()
 print("iht probe done")
