@@ -458,114 +458,181 @@ __global__ __launch_bounds__(256) void k_thresh_apply(uint32_t *__restrict__ q, 
 }
 
 // ---- single-workgroup path (n_pad <= 131072: every IHT size the reference benchmarks): one launch, the vector,
-// the histograms and the scans all live in LDS.
+// the histograms and the scans all live in LDS.  One workgroup on one CU is latency-bound code, so this kernel is
+// written to execute few instructions and few barriers:
+//  * A block holds at most 9 distinct magnitudes (|nibble| in 0..8 times one scale), so the selection runs over
+//    9 * n/64 weighted CANDIDATES (block, |nibble|), weight = how many elements of the block carry that magnitude,
+//    instead of over the n elements.
+//  * Radix select with four 8-bit levels: a 256-bin histogram is scanned by four waves in one step, where the
+//    4096-bin levels used before cost 16 serial, bank-conflicting LDS reads per thread and level.
+//  * Words are handled whole (SWAR over the 8 nibbles): magnitudes, per-block cut-offs and tie masks are bit
+//    operations on the 32-bit word; there is no per-element float work after the selection.
 #define TS_THREADS 1024
 #define TS_MAXW 16
+
+// inclusive scan over the 64 lanes of a wave with DPP moves (no LDS crossbar): Hillis-Steele inside each row of 16,
+// then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+#define DPP_ADD(ctrl, row_mask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xF, false)
+    DPP_ADD(0x111, 0xF);      // row_shr:1
+    DPP_ADD(0x112, 0xF);      // row_shr:2
+    DPP_ADD(0x114, 0xF);      // row_shr:4
+    DPP_ADD(0x118, 0xF);      // row_shr:8
+    DPP_ADD(0x142, 0xA);      // row_bcast:15 -> rows 1, 3
+    DPP_ADD(0x143, 0xC);      // row_bcast:31 -> rows 2, 3
+#undef DPP_ADD
+    return v;
+}
 
 // inclusive block scan over 1024 threads (wave scan + 16 wave totals)
 __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *wsum)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
+    v = wave_scan_incl(v);
     __syncthreads();                       // wsum may still be read from a previous call
     if (lane == 63) wsum[wave] = v;
     __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; w++) base += wsum[w];
-    return v + base;
+    const uint32_t tot = lane < 16 ? wsum[lane] : 0;          // exclusive scan of the 16 wave totals, read off at `wave`
+    const uint32_t inc = wave_scan_incl(tot);
+    return v + __shfl(inc - tot, wave);
 }
+
+__device__ __forceinline__ uint32_t cand_key(float s7, int m) { return __float_as_uint(__builtin_fabsf(s7 * (float)m)); }
+
+// element e of a word sits in nibble e after the two nibbles of every byte are swapped (even elements are stored high)
+__device__ __forceinline__ uint32_t swap_nibbles(uint32_t w) { return ((w & 0x0F0F0F0Fu) << 4) | ((w >> 4) & 0x0F0F0F0Fu); }
+// |two's complement nibble| for all 8 nibbles: 0..8, no carries between nibbles
+__device__ __forceinline__ uint32_t abs_nibbles(uint32_t w)
+{
+    const uint32_t sgn = (w >> 3) & 0x11111111u;
+    return (w ^ (sgn * 0xFu)) + sgn;
+}
+// bit 3 of every nibble whose value (0..8) is >= t, t in 0..9
+__device__ __forceinline__ uint32_t ge_nibbles(uint32_t ab, uint32_t t)
+{
+    if (t == 0) return 0x88888888u;
+    if (t > 8) return 0u;
+    return (ab + (8u - t) * 0x11111111u) & 0x88888888u;
+}
+// bit 3 of each of the first `count` nibbles (count 0..8)
+__device__ __forceinline__ uint32_t first_nibbles(uint32_t count) { return count >= 8 ? 0x88888888u : 0x88888888u & ((1u << (4 * count)) - 1u); }
 
 // the vector (<= 64 KiB of nibbles) and the per-block s/7 are staged in LDS once; every pass walks them there
 __global__ __launch_bounds__(TS_THREADS) void k_thresh_small(uint32_t *__restrict__ q, const float *__restrict__ s, uint32_t n, uint32_t k)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ts_lds[];
-    uint32_t *hist = ts_lds;                 // 4096
-    uint32_t *wsum = hist + 4096;            // 16
+    uint32_t *hist = ts_lds;                 // 4 levels x 256
+    uint32_t *wsum = hist + 1024;            // 16
     uint32_t *sel = wsum + 16;               // 2 (+14 pad)
-    uint32_t *words = sel + 16;              // nwords
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(sel + 16);      // per block: 9 fields of 7 bits, field m = #(|nibble| == m)
     const int tid = threadIdx.x;
     const uint32_t nwords = (n + 7) / 8, nblocks = (n + 63) / 64;
-    float *s7 = reinterpret_cast<float *>(words + ((nwords + 15) & ~15u));
+    float *s7 = reinterpret_cast<float *>(cnt + nblocks);
+    uint32_t *words = reinterpret_cast<uint32_t *>(s7 + ((nblocks + 3) & ~3u));
     const uint32_t W = (nwords + TS_THREADS - 1) / TS_THREADS;          // contiguous words per thread: index order = thread order
     const uint32_t w0 = tid * W, w1 = (w0 + W) < nwords ? (w0 + W) : nwords;
     for (uint32_t i = tid; i < nwords; i += TS_THREADS) words[i] = q[i];
-    for (uint32_t i = tid; i < nblocks; i += TS_THREADS) s7[i] = s[i] / 7.0f;
+    for (uint32_t i = tid; i < nblocks; i += TS_THREADS) { s7[i] = s[i] / 7.0f; cnt[i] = 0ull; }
+    hist[tid] = 0;
     __syncthreads();
 
-    uint32_t prefix = 0, need = k, tau = 0x7F800000u, keep = 0;
+    uint32_t tau = 0x7F800000u, keep = 0;
     if (k != 0) {
-        for (int level = 0; level < 3; level++) {
-            const int nb = level == 2 ? 256 : 4096;
-            for (int i = tid; i < nb; i += TS_THREADS) hist[i] = 0;
-            __syncthreads();
-            for (uint32_t i = w0; i < w1; i++) {
-                const uint32_t wd = words[i];
-                const float sc = s7[i >> 3];
+        for (uint32_t i = w0; i < w1; i++) {                             // magnitude counts of this word into its block
+            const uint32_t ab = abs_nibbles(swap_nibbles(words[i]));
+            const uint32_t valid = n - 8 * i < 8 ? n - 8 * i : 8;
+            unsigned long long acc = 0;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    if (i * 8 + e < n) {
-                        const uint32_t key = mag_key(wd, e, sc);
-                        if (level == 0) atomicAdd(&hist[key >> 20], 1u);
-                        else if (level == 1) { if ((key >> 20) == prefix) atomicAdd(&hist[(key >> 8) & 0xFFF], 1u); }
-                        else { if ((key >> 8) == prefix) atomicAdd(&hist[key & 0xFF], 1u); }
-                    }
+            for (uint32_t e = 0; e < 8; e++)
+                if (e < valid) acc += 1ull << (7u * ((ab >> (4 * e)) & 0xFu));
+            atomicAdd(&cnt[i >> 3], acc);
+        }
+        __syncthreads();
+        uint32_t prefix = 0, need = k;
+        for (int level = 0; level < 4; level++) {
+            const int shift = 24 - 8 * level;
+            uint32_t *h = hist + 256 * level;
+            for (uint32_t c = tid; c < 9 * nblocks; c += TS_THREADS) {
+                const uint32_t b = c / 9, m = c - 9 * b;
+                const uint32_t wgt = (uint32_t)(cnt[b] >> (7 * m)) & 0x7Fu;
+                if (wgt) {
+                    const uint32_t key = cand_key(s7[b], (int)m);
+                    if (level == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&h[(key >> shift) & 0xFFu], wgt);
                 }
             }
             __syncthreads();
-            // select from the top: thread t owns `per` bins ending at nb-1 - t*per
-            const int per = nb / TS_THREADS > 0 ? nb / TS_THREADS : 1;
-            const bool owns = tid * per < nb;
-            uint32_t mine = 0;
-            if (owns) for (int b = 0; b < per; b++) mine += hist[nb - 1 - (tid * per + b)];
-            const uint32_t incl = block_scan_incl(mine, wsum);
-            if (owns && incl >= need && incl - mine < need) {
-                uint32_t above = incl - mine;
-                int b = 0;
-                while (above + hist[nb - 1 - (tid * per + b)] < need) { above += hist[nb - 1 - (tid * per + b)]; b++; }
-                sel[0] = (uint32_t)(nb - 1 - (tid * per + b));
-                sel[1] = need - above;
+            // select from the top: thread t < 256 owns bin 255 - t
+            const uint32_t mine = tid < 256 ? h[255 - tid] : 0;
+            uint32_t v = wave_scan_incl(mine);
+            if (tid < 256 && (tid & 63) == 63) wsum[tid >> 6] = v;
+            __syncthreads();
+            if (tid < 256) {
+                for (int w = 0; w < (tid >> 6); w++) v += wsum[w];
+                if (v >= need && v - mine < need) {
+                    sel[0] = 255u - tid;
+                    sel[1] = need - (v - mine);
+                }
             }
             __syncthreads();
-            prefix = level == 0 ? sel[0] : (level == 1 ? (prefix << 12) | sel[0] : (prefix << 8) | sel[0]);
+            prefix = (prefix << 8) | sel[0];
             need = sel[1];
-            __syncthreads();
         }
         tau = prefix;
         keep = need;
     }
-    // ties in index order
-    uint32_t c = 0;
-    for (uint32_t i = w0; i < w1; i++) {
-        const uint32_t wd = words[i];
-        const float sc = s7[i >> 3];
+    // per block: magnitudes >= hi_t are above tau, [lo_t, hi_t) equal tau (keys grow with the magnitude)
+    uint32_t *cut = reinterpret_cast<uint32_t *>(cnt);                   // the counts are dead: every level ended with a barrier
+    for (uint32_t b = tid; b < nblocks; b += TS_THREADS) {
+        const float sc = s7[b];
+        uint32_t lo_t = 0, hi_t = 0;
 #pragma unroll
-        for (int e = 0; e < 8; e++) if (i * 8 + e < n && mag_key(wd, e, sc) == tau) c++;
-    }
-    uint32_t rank = block_scan_incl(c, wsum) - c;
-    for (uint32_t i = w0; i < w1; i++) {
-        const uint32_t wd = words[i];
-        const float sc = s7[i >> 3];
-        uint32_t outw = 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t nib = wd & (0xFu << nib_shift(e));
-            if (i * 8 + e >= n) { outw |= nib; continue; }          // padding is left alone
-            const uint32_t key = mag_key(wd, e, sc);
-            if (key > tau) outw |= nib;
-            else if (key == tau) { if (rank < keep) outw |= nib; rank++; }
+        for (int m = 0; m <= 8; m++) {
+            const uint32_t key = cand_key(sc, m);
+            lo_t += key < tau;
+            hi_t += key <= tau;
         }
-        q[i] = outw;
+        cut[b] = lo_t | (hi_t << 8);
+    }
+    __syncthreads();
+    uint32_t c = 0;
+    uint32_t keepbits[TS_MAXW], tiebits[TS_MAXW];
+#pragma unroll
+    for (uint32_t j = 0; j < TS_MAXW; j++) {
+        const uint32_t i = w0 + j;
+        if (j < W && i < w1) {
+            const uint32_t lo_t = cut[i >> 3] & 0xFFu, hi_t = cut[i >> 3] >> 8;
+            const uint32_t ab = abs_nibbles(swap_nibbles(words[i]));
+            const uint32_t valid = first_nibbles(n - 8 * i < 8 ? n - 8 * i : 8);
+            const uint32_t above = ge_nibbles(ab, hi_t);
+            keepbits[j] = above | (0x88888888u & ~valid);                 // padding is left alone
+            tiebits[j] = ge_nibbles(ab, lo_t) & ~above & valid;
+            c += __popc(tiebits[j]);
+        } else {
+            keepbits[j] = tiebits[j] = 0;
+        }
+    }
+    // ties in index order: the first `keep` of them survive
+    uint32_t rank = block_scan_incl(c, wsum) - c;
+#pragma unroll
+    for (uint32_t j = 0; j < TS_MAXW; j++) {
+        const uint32_t i = w0 + j;
+        if (j < W && i < w1) {
+            uint32_t t = tiebits[j], kb = keepbits[j];
+            const uint32_t nt = __popc(t), room = keep > rank ? keep - rank : 0;
+            if (room >= nt) kb |= t;
+            else for (uint32_t r = 0; r < room; r++) { kb |= t & (0u - t); t &= t - 1; }
+            rank += nt;
+            const uint32_t full = (kb >> 3) * 0xFu;                       // bit 3 -> whole nibble, then back to the stored nibble order
+            q[i] = words[i] & swap_nibbles(full);
+        }
     }
 }
 
 static inline size_t thresh_small_lds(uint64_t n)
 {
     const uint64_t nwords = (n + 7) / 8, nblocks = (n + 63) / 64;
-    return (4096 + 16 + 16 + ((nwords + 15) & ~15ull) + nblocks) * sizeof(uint32_t);
+    return (1024 + 16 + 16 + 2 * nblocks + ((nblocks + 3) & ~3ull) + nwords) * sizeof(uint32_t);
 }
 
 extern "C" uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad)
@@ -582,7 +649,7 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
     hipStream_t st = as_stream(stream);
     if (k >= n || n == 0) return CLV_OK;                       // everything survives
     if (n_pad <= (uint64_t)TS_THREADS * TS_MAXW * 8) {
-        const size_t lds = thresh_small_lds(n);                                    // up to 88 KiB
+        const size_t lds = thresh_small_lds(n);                                    // up to 92 KiB
         if (lds > 64 * 1024) CLV_HIP(hipFuncSetAttribute((const void *)k_thresh_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_thresh_small, dim3(1), dim3(TS_THREADS), lds, st, (uint32_t *)q, s, (uint32_t)n, (uint32_t)k);
         CLV_LAUNCH_CHECK();

@@ -122,7 +122,8 @@ def test_gpu_transpose_exact(hip, oracle, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(128, 128, 64), (1000, 1024, 64), (2047, 2048, 300), (65536, 65536, 16384),
-                                  ((1 << 20) + 77, (1 << 20) + 128, 262144), (512, 512, 0), (512, 512, 511)])
+                                  ((1 << 20) + 77, (1 << 20) + 128, 262144), (512, 512, 0), (512, 512, 511),
+                                  (131072 - 5, 131072, 40000), (100000, 100096, 1), (131072 + 128, 131072 + 128, 999)])
 def test_gpu_threshold_top_k(hip, oracle, case):
     n, npad, k = case
     rng = np.random.default_rng(n + k)
@@ -148,6 +149,7 @@ def test_gpu_threshold_top_k(hip, oracle, case):
         n_keep = k - int((mags > tau).sum())
         if tau > 0:
             assert np.array_equal(np.flatnonzero(kept & (mags == tau)), tie_idx[:n_keep])
+    assert same(out, _threshold_lowest_index(oracle, q, s, n, k))   # the whole output, bit for bit, under the lowest-index tie rule
     again = hip.v4_threshold(out, s, n, k)                    # idempotent
     assert same(again, out)
 
