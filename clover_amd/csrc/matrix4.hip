@@ -42,38 +42,69 @@ __device__ __forceinline__ void mvm_steps(const u32x4 *__restrict__ Ap, const u3
     }
 }
 
-// re-quantise 64 row dots held one per lane of a full wave (CloverMatrix4.h:919-1080, rounding disabled)
-__device__ __forceinline__ void requantize_wave(float d, float noise, uint32_t *r_words, float *sr)
+// re-quantise 64 values held one per lane of a full wave (CloverMatrix4.h:919-1080); returns this lane's nibble value,
+// *scale = the block maximum.  r_words / sr may be NULL (result not stored).
+__device__ __forceinline__ int requantize_wave(float d, float noise, uint32_t *r_words, float *sr, float *scale)
 {
     const int lane = threadIdx.x & 63;
     float m = wave_max(__builtin_fabsf(d));
     m = fix_zero_max(m);
     const float k = 7.0f / m;
     const int qv = quant1(d, k, noise);
-    uint32_t w = ((uint32_t)qv & 0xFu) << nib_shift(lane & 7);
-    w |= __shfl_xor(w, 1);
-    w |= __shfl_xor(w, 2);
-    w |= __shfl_xor(w, 4);
-    if ((lane & 7) == 0) r_words[lane >> 3] = w;
-    if (lane == 0) *sr = m;
+    if (r_words) {
+        uint32_t w = ((uint32_t)qv & 0xFu) << nib_shift(lane & 7);
+        w |= __shfl_xor(w, 1);
+        w |= __shfl_xor(w, 2);
+        w |= __shfl_xor(w, 4);
+        if ((lane & 7) == 0) r_words[lane >> 3] = w;
+        if (lane == 0) *sr = m;
+    }
+    *scale = m;
+    return qv;
 }
+
+// FUSE: the scaleAndAdd that follows mvm in the IHT / GD loops (t2 = y - Phi x;  x += mu Phi' t2), done on the row
+// group while it is still in the wave:  r2 = quantize(u + a * quantize(A x))  (CloverVector4.h:1196-1478).
+struct MvmFuse {
+    const uint32_t *qu;      // u, one 64-element block per row group
+    const float *su;
+    float a;
+    uint32_t *r2;            // may alias qu (the in-place overload)
+    float *sr2;
+};
 
 // ST: stochastic re-quantisation fused into the epilogue (CloverMatrix4.h:919-1080 with the rnd_* branch).  Row group
 // rb consumes draws 2rb, 2rb+1 of the stream; the dots sit pre-transposed in the reference's block_values, so noise
 // group g of AVX lane j lands on row 8j+g: row l uses group g = l&7 (draw g>>2, byte g&3) of word W[l>>3].
-template <int U, bool NT, bool ST>
+// With FUSE the scaleAndAdd draws follow ALL the mvm draws in the stream, as in the two separate calls: row group rb
+// then uses draws 2G + 2rb, 2G + 2rb + 1 (G = number of row groups), with the scaleAndAdd lane map 8j + (g ^ 1).
+template <int U, bool NT, bool ST, bool FUSE>
 __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A, const float *__restrict__ sA,
                                                   uint64_t cols, const uint8_t *__restrict__ x, const float *__restrict__ sx,
-                                                  float *__restrict__ d_out, uint32_t *__restrict__ r, float *__restrict__ sr,
-                                                  uint64_t *rng_state, uint64_t seq, const uint64_t *__restrict__ pow_rows)
+                                                  float *__restrict__ d_out, uint32_t *r, float *sr,
+                                                  uint64_t *rng_state, uint64_t seq, const uint64_t *__restrict__ pow_rows, MvmFuse fuse)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4 *xs = reinterpret_cast<u32x4 *>(smem);                        // MVM_CHUNK/2 bytes
     float *cs = reinterpret_cast<float *>(smem + MVM_CHUNK / 2);        // MVM_CHUNK/64 floats
     float *dsh = cs + MVM_CHUNK / 64;                                   // 64 floats
-    uint64_t *rbase = reinterpret_cast<uint64_t *>(dsh + 64);           // ST: 4 lane bases, 8 raw draws
+    uint64_t *rbase = reinterpret_cast<uint64_t *>(dsh + 64);           // ST: 4 lane bases, 8 raw draws (twice with FUSE)
     uint64_t *raw = rbase + 4;
-    if (ST) rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, 2ull * gridDim.x, rbase);
+    uint64_t *rbase2 = raw + 8, *raw2 = rbase2 + 4;
+    if (ST) {
+        const uint64_t a0 = rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, (FUSE ? 4ull : 2ull) * gridDim.x, rbase);
+        if (FUSE) {
+            const uint64_t b2 = wave_pow_apply(pow_rows, a0, (uint64_t)gridDim.x + blockIdx.x, 1);
+            if ((threadIdx.x & 63) == 0) rbase2[threadIdx.x >> 6] = b2;      // read in the epilogue, barriers in between
+        }
+    }
+    // FUSE: this row group's block of u, fetched now so that the epilogue does not wait for it
+    uint32_t fuse_w = 0;
+    float fuse_s = 0.0f;
+    if (FUSE && threadIdx.x < 64) {
+        fuse_w = fuse.qu[blockIdx.x * 8 + (threadIdx.x >> 3)];
+        fuse_s = fuse.su[blockIdx.x];
+    }
 
     const uint64_t rb = blockIdx.x;
     const int tid = threadIdx.x;
@@ -136,15 +167,30 @@ __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A,
         dsh[rho] = dot;
         if (d_out) d_out[row] = dot;
     }
-    if (ST && tid < 4) gen_blocks(rbase[tid], 1, raw, tid);
+    if (ST && tid < 4) {
+        gen_blocks(rbase[tid], 1, raw, tid);
+        if (FUSE) gen_blocks(rbase2[tid], 1, raw2, tid);
+    }
     __syncthreads();
-    if (r && tid < 64) {
+    if ((r || FUSE) && tid < 64) {
         float noise = 0.0f;
         if (ST) {
             const int grp = tid & 7, j = tid >> 3;
             noise = noise_of(reinterpret_cast<const uint32_t *>(raw + (size_t)(grp >> 2) * 4)[j], grp & 3);
         }
-        requantize_wave(dsh[tid], noise, r + rb * 8, sr + rb);
+        float m;
+        const int qv = requantize_wave(dsh[tid], noise, r ? r + rb * 8 : nullptr, r ? sr + rb : nullptr, &m);
+        if (FUSE) {
+            const float su7 = fuse_s / 7.0f, sv7 = (m * fuse.a) / 7.0f;
+            const float val = __builtin_fmaf((float)qv, sv7, (float)unpack1(fuse_w, tid & 7) * su7);
+            float noise2 = 0.0f;
+            if (ST) {
+                const int g = (tid & 7) ^ 1, j = tid >> 3;
+                noise2 = noise_of(reinterpret_cast<const uint32_t *>(raw2 + (size_t)(g >> 2) * 4)[j], g & 3);
+            }
+            float m2;
+            requantize_wave(val, noise2, fuse.r2 + rb * 8, fuse.sr2 + rb, &m2);
+        }
     }
 }
 
@@ -222,10 +268,10 @@ __global__ __launch_bounds__(256) void k_m4_gemm_simple(const uint8_t *__restric
 int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng, hipStream_t st);
 int clm4_gemm_mfma(const int8_t *A, const float *sA, uint64_t M, uint64_t K, const int8_t *B, const float *sB, uint64_t N, float *C, hipStream_t st);
 
-#define MVM_LDS_BYTES (MVM_CHUNK / 2 + (MVM_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 128)
+#define MVM_LDS_BYTES (MVM_CHUNK / 2 + (MVM_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 256)
 
 static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
-                      float *d, int8_t *r, float *sr, uint64_t *rng, hipStream_t st)
+                      float *d, int8_t *r, float *sr, uint64_t *rng, hipStream_t st, const MvmFuse *fuse = nullptr)
 {
     const size_t lds = MVM_LDS_BYTES;
     const dim3 grid((unsigned)(rows / 64)), block(256);
@@ -236,9 +282,15 @@ static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t 
         if (rc) return rc;
         seq = clv_rng_next_seq();
     }
-#define MVM_LAUNCH(NT, ST)                                                                                                 \
-    hipLaunchKernelGGL((k_m4_mvm64<8, NT, ST>), grid, block, lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, sx, d, \
-                       (uint32_t *)r, sr, rng, seq, T.pow_rows)
+    const MvmFuse no_fuse = {nullptr, nullptr, 0.0f, nullptr, nullptr};
+#define MVM_LAUNCH_F(NT, ST, FUSE)                                                                                               \
+    hipLaunchKernelGGL((k_m4_mvm64<8, NT, ST, FUSE>), grid, block, lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, sx, d, \
+                       (uint32_t *)r, sr, rng, seq, T.pow_rows, FUSE ? *fuse : no_fuse)
+#define MVM_LAUNCH(NT, ST)                                  \
+    do {                                                    \
+        if (fuse) MVM_LAUNCH_F(NT, ST, true);               \
+        else MVM_LAUNCH_F(NT, ST, false);                   \
+    } while (0)
     // Streaming (nt) loads win once the matrix cannot live in the 256 MiB Infinity Cache (+14 % at 2 GiB); below
     // that, default-policy loads keep it cache-resident across calls (8192^2: 7.3 vs 11.9 us) -- measured, r01.
     const bool streaming = rows * (cols / 2) > (256ull << 20);
@@ -248,6 +300,7 @@ static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t 
         if (rng) MVM_LAUNCH(false, true); else MVM_LAUNCH(false, false);
     }
 #undef MVM_LAUNCH
+#undef MVM_LAUNCH_F
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -284,14 +337,17 @@ extern "C" int clvx_mvm_variant(int variant, const int8_t *A, const float *sA, u
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)(rows / 64)), block(256);
 #define CLVX_LAUNCH(U, NT)                                                                                                      \
-    hipLaunchKernelGGL((k_m4_mvm64<U, NT, false>), grid, block, lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, sx, \
-                       (float *)nullptr, (uint32_t *)r, sr, (uint64_t *)nullptr, 0ull, (const uint64_t *)nullptr)
+    hipLaunchKernelGGL((k_m4_mvm64<U, NT, false, false>), grid, block, lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, sx, \
+                       (float *)nullptr, (uint32_t *)r, sr, (uint64_t *)nullptr, 0ull, (const uint64_t *)nullptr,                      \
+                       MvmFuse{nullptr, nullptr, 0.0f, nullptr, nullptr})
     switch (variant) {
     case 0: CLVX_LAUNCH(8, true); break;
     case 1: CLVX_LAUNCH(8, false); break;
     case 2: CLVX_LAUNCH(4, true); break;
     case 3: CLVX_LAUNCH(16, true); break;
     case 4: CLVX_LAUNCH(2, true); break;
+    case 5: CLVX_LAUNCH(16, false); break;
+    case 6: CLVX_LAUNCH(32, false); break;
     default: clv_set_error("clvx_mvm_variant: unknown variant %d", variant); return CLV_ERR_INVALID;
     }
 #undef CLVX_LAUNCH
@@ -317,6 +373,21 @@ extern "C" int clm4_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_
     if (!rows) return CLV_OK;
     hipStream_t st = as_stream(stream);
     return launch_mvm(A, sA, rows, cols, x, sx, nullptr, r, sr, rng_state_dev, st);
+}
+
+extern "C" int clm4_mvm_scale_and_add(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                                      const int8_t *qu, const float *su, float a, int8_t *t, float *st_, int8_t *r, float *sr,
+                                      uint64_t *rng_state_dev, void *stream)
+{
+    int rc = check_mvm_args("clm4_mvm_scale_and_add", A, sA, rows, cols, x, sx);
+    if (rc) return rc;
+    CLV_REQUIRE(qu && su && r && sr, "clm4_mvm_scale_and_add: null pointer");
+    CLV_REQUIRE((t == nullptr) == (st_ == nullptr), "clm4_mvm_scale_and_add: t and st must both be given or both be NULL");
+    CLV_REQUIRE((const void *)r != (const void *)x && (const void *)sr != (const void *)sx,
+                "clm4_mvm_scale_and_add: the result must not alias the vector being multiplied");
+    if (!rows) return CLV_OK;
+    const MvmFuse fuse = {(const uint32_t *)qu, su, a, (uint32_t *)r, sr};
+    return launch_mvm(A, sA, rows, cols, x, sx, nullptr, t, st_, rng_state_dev, as_stream(stream), &fuse);
 }
 
 extern "C" int clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,

@@ -704,10 +704,9 @@ static int iht_iteration(const int8_t *Phi, const float *sPhi, const int8_t *Phi
                          int8_t *x, float *sx, uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1, int8_t *t2,
                          float *st2, int8_t *t3, float *st3, uint64_t K, float mu, int threshold, uint64_t *rng, void *stream)
 {
-    int rc = clm4_mvm(Phi, sPhi, m, n, x, sx, t1, st1, rng, stream);                       // t1 = Phi * x
-    if (!rc) rc = clv4_scale_and_add(y, sy, t1, st1, -1.0f, m, t2, st2, rng, stream);       // t2 = y - t1
-    if (!rc) rc = clm4_mvm(PhiT, sPhiT, n, m, t2, st2, t3, st3, rng, stream);               // t3 = Phi' * t2
-    if (!rc) rc = clv4_scale_and_add(x, sx, t3, st3, mu, n, x, sx, rng, stream);            // x += mu * t3
+    // each scaleAndAdd rides in the epilogue of the mvm before it (same bits, same XORShift positions): 3 launches, not 5
+    int rc = clm4_mvm_scale_and_add(Phi, sPhi, m, n, x, sx, y, sy, -1.0f, t1, st1, t2, st2, rng, stream);     // t1 = Phi * x; t2 = y - t1
+    if (!rc) rc = clm4_mvm_scale_and_add(PhiT, sPhiT, n, m, t2, st2, x, sx, mu, t3, st3, x, sx, rng, stream); // t3 = Phi' * t2; x += mu * t3
     if (!rc && threshold) rc = clv4_threshold(x, sx, x_len, n, K, nullptr, stream);         // keep the K largest
     return rc;
 }

@@ -115,8 +115,8 @@ __device__ __forceinline__ uint64_t gen_blocks(uint64_t a, int nblk, uint64_t *r
 // Start-of-kernel step for 256-thread workgroups whose 4 waves map to the 4 generator lanes:
 // lds_base[k] = T^(index << shift)(a0[k]); workgroup 0 also writes the state after `total` (>= 1) draws
 // (part2 = T^total(a0), part1 = T^(total-1)(a0), exactly what `total` sequential draws leave behind).
-// Ends with a barrier: call from uniform control flow.
-__device__ __forceinline__ void rng_workgroup_begin(uint64_t *state, uint64_t seq, const uint64_t *__restrict__ pow_rows,
+// Ends with a barrier: call from uniform control flow.  Returns a0 of this wave's generator lane.
+__device__ __forceinline__ uint64_t rng_workgroup_begin(uint64_t *state, uint64_t seq, const uint64_t *__restrict__ pow_rows,
                                                     uint64_t index, int shift, uint64_t total, uint64_t *lds_base)
 {
     const int k = threadIdx.x >> 6;
@@ -139,6 +139,7 @@ __device__ __forceinline__ void rng_workgroup_begin(uint64_t *state, uint64_t se
     } else {
         __syncthreads();
     }
+    return a0;
 }
 
 // lane (seg = l>>2, k = l&3) <- SEG[seg0 + seg] * base[k]: the segment starts of one wave as NSEG*4 whole-wave

@@ -55,6 +55,7 @@ SIGNATURES = {
     "clm4_rowdots": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clm4_gemm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
     "clv4_scale_and_add": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _u64, _vp, _vp, _vp, _vp]),
+    "clm4_mvm_scale_and_add": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clv4_threshold_workspace_bytes": (_u64, [_u64]),
     "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "clm4_transpose": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
@@ -236,6 +237,18 @@ class CloverHip:
         self.check(self.lib.clv4_scale_and_add(b[0].ptr, b[1].ptr, b[2].ptr, b[3].ptr, a, n, dr.ptr, dsr.ptr,
                                                rng.ptr if rng else None, None))
         return dr.download(np.uint8, n // 2), dsr.download(np.float32, n // 64)
+
+    def m4_mvm_scale_and_add(self, qA, sA, rows, cols, qx, sx, qu, su, a: float, rng: DevBuf | None = None, in_place: bool = False,
+                             want_t: bool = True):
+        """(t, st, r, sr) of clm4_mvm_scale_and_add; t/st are None when want_t is False"""
+        b = [self.to_device(v) for v in (qA, sA, qx, sx, qu, su)]
+        dt, dst = (self.alloc(rows // 2), self.alloc(rows // 16)) if want_t else (None, None)
+        dr, dsr = (b[4], b[5]) if in_place else (self.alloc(rows // 2), self.alloc(rows // 16))
+        self.check(self.lib.clm4_mvm_scale_and_add(b[0].ptr, b[1].ptr, rows, cols, b[2].ptr, b[3].ptr, b[4].ptr, b[5].ptr, a,
+                                                   dt.ptr if dt else None, dst.ptr if dst else None, dr.ptr, dsr.ptr,
+                                                   rng.ptr if rng else None, None))
+        t = (dt.download(np.uint8, rows // 2), dst.download(np.float32, rows // 64)) if want_t else (None, None)
+        return t[0], t[1], dr.download(np.uint8, rows // 2), dsr.download(np.float32, rows // 64)
 
     def v4_threshold(self, q, s, n: int, k: int) -> np.ndarray:
         dq, ds = self.to_device(q), self.to_device(s)

@@ -124,6 +124,14 @@ int  clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K,
  * method's XORShift stream and its lane map (element 8j+(g^1)) are reproduced. */
 int  clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
                         int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
+/* mvm immediately followed by scaleAndAdd on its result -- the pairs "t2 = y - Phi x" and "x += mu Phi' t2" of the
+ * quantized IHT / GD loops (test/performance/01_measure.h:923-946, 999-1021) -- in one launch:
+ *     t = quantize(A x)  (stored if t/st != NULL),   r = quantize(u + a * t);   u, r: rows elements.
+ * Bit-identical to clm4_mvm(...) followed by clv4_scale_and_add(u, t, a, r), including the XORShift stream positions
+ * when an rng is given.  r/sr may alias u/su; they must not alias x/sx. */
+int  clm4_mvm_scale_and_add(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                            const int8_t *qu, const float *su, float a, int8_t *t, float *st, int8_t *r, float *sr,
+                            uint64_t *rng_state_dev, void *stream);
 /* CloverVector4::threshold(K) (CloverVector4.h:1913-2060): keep the K largest |value| among the first n
  * elements, zero the other nibbles in place.  The surviving multiset of magnitudes equals the reference's;
  * among EQUAL magnitudes the lowest indices survive (the reference's choice depends on its heap order). */

@@ -227,3 +227,36 @@ def test_gpu_mixed_mvm_f32_bit_exact(hip, oracle, shape):
     sA = rng.uniform(0.5, 2, size=(M // 64) * (N // 64)).astype(np.float32)
     x = rng.normal(size=N).astype(np.float32)
     assert same(hip.m4_mvm_f32(qA, sA, M, N, x), oracle.m4_mvm_f32(qA, sA, M, N, x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 65536 + 128)])
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_gpu_fused_mvm_scale_and_add_equals_the_two_calls(hip, oracle, shape, stochastic):
+    """clm4_mvm_scale_and_add == mvm then scaleAndAdd: same t, same r, same XORShift positions; with and without storing
+    t, and with the in-place result (x += a * (A v))."""
+    M, N = shape
+    rng = np.random.default_rng(M + N + stochastic)
+    qA, _ = random_packed(rng, M * N)
+    sA = rng.uniform(0.5, 2, size=(M // 64) * (N // 64)).astype(np.float32)
+    (qx, sx), (qu, su) = random_packed(rng, N), random_packed(rng, M)
+    a = -0.37
+    st, o = (hip.new_rng(31, 41), oracle.rng(31, 41)) if stochastic else (None, None)
+    for want_t, in_place in ((True, False), (False, False), (True, True)):
+        t, s_t, r, sr = hip.m4_mvm_scale_and_add(qA, sA, M, N, qx, sx, qu, su, a, rng=st, in_place=in_place, want_t=want_t)
+        to, sto = oracle.m4_mvm(qA, sA, M, N, qx, sx, o)
+        ro, sro = oracle.v4_scale_and_add(qu, su, to, sto, a, o)
+        if want_t:
+            assert same(t, to) and same(s_t, sto)
+        assert same(r, ro) and same(sr, sro)
+    if stochastic:
+        k1, k2 = hip.rng_get(st)
+        o1, o2 = oracle.rng_keys(o)
+        assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_mvm_scale_and_add_rejects_aliasing_the_input(hip):
+    buf = hip.alloc(4096)
+    assert hip.lib.clm4_mvm_scale_and_add(buf.ptr, buf.ptr, 128, 128, buf.ptr, buf.offset(64), buf.offset(128), buf.offset(256), 1.0,
+                                          None, None, buf.ptr, buf.offset(512), None, None) == -1

@@ -2,6 +2,7 @@
 """Kernel-variant sweep on the GPU box (not part of the product): read-bandwidth ceiling and mvm variants."""
 import ctypes as C
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -37,11 +38,15 @@ def timeit(fn, reps=20, warm=3):
     return sorted(ts)[len(ts) // 2]
 
 
+# MB_SIZES="4096x8192,8192x4096" MB_VARIANTS="1,5,6" MB_SKIP_READ=1 narrow the sweep
+SIZES = [tuple(int(v) for v in t.split("x")) for t in os.environ["MB_SIZES"].split(",")] if os.environ.get("MB_SIZES") else \
+    [(65536, 65536), (32768, 32768), (16384, 16384), (8192, 8192), (131072, 32768), (16384, 131072)]
+VARIANTS = [int(v) for v in os.environ["MB_VARIANTS"].split(",")] if os.environ.get("MB_VARIANTS") else list(range(5))
 res = {}
 big = hip.alloc(2 << 30)
 hip.check(lib.clv_fill_random_nibbles(big.ptr, big.nbytes, 1, 0, None))
 out = hip.alloc(256)
-for nt in (0, 1):
+for nt in (() if os.environ.get("MB_SKIP_READ") else (0, 1)):
     for bpc in (4, 8, 16):
         ms = timeit(lambda: hip.check(lib.clvx_read_bw(big.ptr, big.nbytes, nt, bpc, out.ptr, None)))
         res[f"read_bw_2GiB_nt{nt}_bpc{bpc}"] = round(big.nbytes / ms / 1e6, 1)
@@ -51,7 +56,7 @@ def mvm_bytes(rows, cols):
     return rows * cols // 2 + 4 * (rows // 64) * (cols // 64) + (cols // 2 + cols // 16) + (rows // 2 + rows // 16)
 
 
-for (rows, cols) in ((65536, 65536), (32768, 32768), (16384, 16384), (8192, 8192), (131072, 32768), (16384, 131072)):
+for (rows, cols) in SIZES:
     sA = hip.alloc((rows // 64) * (cols // 64) * 4)
     x, sx = hip.alloc(cols // 2), hip.alloc(cols // 16)
     r, sr = hip.alloc(rows // 2), hip.alloc(rows // 16)
@@ -59,7 +64,7 @@ for (rows, cols) in ((65536, 65536), (32768, 32768), (16384, 16384), (8192, 8192
     hip.check(lib.clv_fill_random_nibbles(x.ptr, x.nbytes, 3, 0, None))
     hip.check(lib.clv_fill_random_scales(sx.ptr, sx.nbytes // 4, 4, 0, None))
     ref = None
-    for v in range(5):
+    for v in VARIANTS:
         fn = lambda: hip.check(lib.clvx_mvm_variant(v, big.ptr, sA.ptr, rows, cols, x.ptr, sx.ptr, r.ptr, sr.ptr, None))
         ms = timeit(fn)
         got = (r.download(np.uint8).tobytes(), sr.download(np.float32).tobytes())
