@@ -41,4 +41,29 @@ inline void Q_GD(QMatrix &Phi, QMatrix &PhiT, QVector &x, QVector &y, QVector &t
     }
 }
 
+
+/* The 4-bit containers of this directory pair every scaleAndAdd with the mvm before it (CloverMatrix4::mvm_scaleAndAdd:
+ * one launch instead of two, identical results), so the same calls -- Q_IHT(Phi, PhiT, x, y, t1, t2, t3, ...) -- pick
+ * these overloads. */
+inline void Q_IHT(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, CloverVector4 &y, CloverVector4 &t1, CloverVector4 &t2,
+                  CloverVector4 &t3, const uint64_t iterations, const uint64_t K, const float mu)
+{
+    x.clear();
+    for (uint64_t i = 0; i < iterations; i += 1) {
+        Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);      // t1 = Phi * x;  t2 = y - t1
+        PhiT.mvm_scaleAndAdd(t2, x, mu, t3);           // t3 = Phi' * t2;  x = x + mu * t3
+        x.threshold_parallel(K);                       // hard thresholding
+    }
+}
+
+inline void Q_GD(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, CloverVector4 &y, CloverVector4 &t1, CloverVector4 &t2,
+                 CloverVector4 &t3, const uint64_t iterations, const float mu)
+{
+    x.clear();
+    for (uint64_t i = 0; i < iterations; i += 1) {
+        Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);
+        PhiT.mvm_scaleAndAdd(t2, x, mu, t3);
+    }
+}
+
 #endif

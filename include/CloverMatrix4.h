@@ -87,7 +87,45 @@ public:
                                    resultVector.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr), "CloverMatrix4::mvm");
     }
     void mvm_parallel(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
+    void check_fused(const CloverVector4 &x, const CloverVector4 &u, const CloverVector4 &t) const
+    {
+        if (x.size() != getCols() || t.size_pad() != getRows()) { std::cout << "MVM can not be performed. Exiting ..." << std::endl; exit(1); }
+        if (u.size_pad() != getRows()) { std::cout << "Vectors do not have the same size. Exiting ..." << std::endl; exit(1); }
+    }
     void mvm_scalar(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
+
+    /* Not in the reference: t = this * x immediately followed by r = quantize(u + a * t), the pair of steps the IHT / GD
+     * loops repeat (01_measure.h:930-931, :932-933).  One launch when rounding is deterministic; with stochastic rounding
+     * the two steps draw from two objects' generators (the matrix's, then u's), as they do in the reference, and are
+     * issued as the two calls.  Results are identical to mvm(x, t); u.scaleAndAdd(t, a, r) either way. */
+    void mvm_scaleAndAdd(const CloverVector4 &x, const CloverVector4 &u, float a, CloverVector4 &t, CloverVector4 &r)
+    {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+        check_fused(x, u, t);
+        if (r.size_pad() != getRows()) { std::cout << "Vectors do not have the same size. Exiting ..." << std::endl; exit(1); }
+        clover_hip::check(clm4_mvm_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(),
+                                                 u.dev_values_ro(), u.dev_scales_ro(), a, t.dev_values_wo(), t.dev_scales_wo(),
+                                                 r.dev_values_wo(), r.dev_scales_wo(), nullptr, nullptr), "CloverMatrix4::mvm_scaleAndAdd");
+#else
+        mvm(x, t);
+        const_cast<CloverVector4 &>(u).scaleAndAdd(t, a, r);
+#endif
+    }
+    /* in place: u = quantize(u + a * (this * x)) */
+    void mvm_scaleAndAdd(const CloverVector4 &x, CloverVector4 &u, float a, CloverVector4 &t)
+    {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+        check_fused(x, u, t);
+        int8_t *qu = u.dev_values_rw();
+        float *su = u.dev_scales_rw();
+        clover_hip::check(clm4_mvm_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(), qu, su, a,
+                                                 t.dev_values_wo(), t.dev_scales_wo(), qu, su, nullptr, nullptr),
+                          "CloverMatrix4::mvm_scaleAndAdd");
+#else
+        mvm(x, t);
+        u.scaleAndAdd(t, a);
+#endif
+    }
 
     /* mixed precision: fp32 vector in, fp32 vector out (CloverMatrix4.h:1451-1547; _parallel :2397-2505) */
     void mvm(const CloverVector32 &productVector, CloverVector32 &resultVector)
