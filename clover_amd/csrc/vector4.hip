@@ -58,29 +58,41 @@ __global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x
 // ------------------------------------------------------------------------------------------------
 // restore: CloverVector4.h:1027-1093.  x = (scale / 7.0f) * q  (division first, then one multiply)
 // ------------------------------------------------------------------------------------------------
+// lane -> output float4: every store instruction of a wave writes one contiguous KiB (two lanes share an input dword,
+// each converts the half it needs); 4 such stores per step
 template <bool NT>
 __global__ __launch_bounds__(256) void k_v4_restore(const uint32_t *__restrict__ q, const float *__restrict__ s,
                                                     f32x4 *__restrict__ x, uint64_t nwords, uint64_t words_per_wave)
 {
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    const int half = lane & 1, sub = lane >> 1;
     const uint64_t w0 = wave * words_per_wave;
-    const uint64_t w1 = (w0 + words_per_wave) < nwords ? (w0 + words_per_wave) : nwords;
-    for (uint64_t w = w0; w < w1; w += 64) {
-        const uint64_t i = w + lane;
-        if (i >= w1) break;
-        const uint32_t wd = q[i];
-        const float sc = s[i >> 3] / 7.0f;
-        float v[8];
+    const uint64_t w1 = (w0 + words_per_wave) < nwords ? (w0 + words_per_wave) : nwords;      // spans are multiples of 64 words
+    for (uint64_t w = w0; w < w1; w += 128) {
+        uint32_t wd[4];
+        float sc[4];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = (float)unpack1(wd, e) * sc;
-        const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-        if (NT) {                                  // output larger than the Infinity Cache: stream it past the caches
-            __builtin_nontemporal_store(lo, &x[2 * i]);
-            __builtin_nontemporal_store(hi, &x[2 * i + 1]);
-        } else {
-            x[2 * i] = lo;
-            x[2 * i + 1] = hi;
+        for (int h = 0; h < 4; h++) {
+            const uint64_t i = w + 32 * h + sub;
+            const uint64_t ic = i < w1 ? i : w0;
+            wd[h] = q[ic];
+            sc[h] = s[ic >> 3];
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint64_t i = w + 32 * h + sub;
+            const uint32_t hw = wd[h] >> (16 * half);           // the 4 nibbles of this half: elements 4*half .. 4*half+3
+            const float k = sc[h] / 7.0f;
+            f32x4 v;
+            v.x = (float)(((int)(hw << 24)) >> 28) * k;         // element 0 of the half: high nibble of byte 0
+            v.y = (float)(((int)(hw << 28)) >> 28) * k;
+            v.z = (float)(((int)(hw << 16)) >> 28) * k;
+            v.w = (float)(((int)(hw << 20)) >> 28) * k;
+            if (i < w1) {
+                if (NT) __builtin_nontemporal_store(v, &x[2 * i + half]);      // output larger than the Infinity Cache: stream it past the caches
+                else x[2 * i + half] = v;
+            }
         }
     }
 }
