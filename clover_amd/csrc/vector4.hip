@@ -27,8 +27,30 @@ __device__ __forceinline__ void quantize_word(const f32x4 a, const f32x4 b, uint
     if ((i & 7) == 0) s[i >> 3] = m;
 }
 
-// Every wave walks its own contiguous span (good DRAM page locality), 4 words per lane and step with all
-// eight 16-byte loads issued before the first use: 8 KiB per wave in flight.
+// maximum over the 16 lanes of a DPP row (rotations inside the row), result in every lane
+__device__ __forceinline__ float row16_max(float m)
+{
+#define ROR_MAX(n) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x120 + n, 0xF, 0xF, false)))
+    ROR_MAX(8);
+    ROR_MAX(4);
+    ROR_MAX(2);
+    ROR_MAX(1);
+#undef ROR_MAX
+    return m;
+}
+
+// the 4 nibbles of half h of an output dword (elements 4h..4h+3 -> bytes 2h, 2h+1, even elements in the high nibble)
+__device__ __forceinline__ uint32_t quant_pack4(const f32x4 v, float k)
+{
+    const uint32_t h = (((uint32_t)quant1_det(v.x, k) & 0xFu) << 4) | ((uint32_t)quant1_det(v.y, k) & 0xFu) |
+                       (((uint32_t)quant1_det(v.z, k) & 0xFu) << 12) | (((uint32_t)quant1_det(v.w, k) & 0xFu) << 8);
+    return k < __builtin_inff() ? h : 0u;       // see quant_pack8
+}
+
+// Every wave walks its own contiguous span (good DRAM page locality).  Main loop: lane -> float4, so each of the eight
+// 16-byte load instructions of a step reads one contiguous KiB; a 64-element block is then exactly one DPP row of 16
+// lanes (maximum by row rotations), a lane quantises half an output dword and lane pairs swap halves so that even
+// lanes store the dwords of load j and odd lanes those of load j+1.  8 KiB per wave in flight.
 #define VQ_UNROLL 4
 __global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x, uint32_t *__restrict__ q,
                                                      float *__restrict__ s, uint64_t nwords, uint64_t words_per_wave)
@@ -38,16 +60,26 @@ __global__ __launch_bounds__(256) void k_v4_quantize(const f32x4 *__restrict__ x
     const uint64_t w0 = wave * words_per_wave;
     const uint64_t w1 = (w0 + words_per_wave) < nwords ? (w0 + words_per_wave) : nwords;     // multiples of 64
     uint64_t w = w0;
+    const int odd = lane & 1, sub = lane >> 1;
     for (; w + 64 * VQ_UNROLL <= w1; w += 64 * VQ_UNROLL) {
-        f32x4 a[VQ_UNROLL], b[VQ_UNROLL];
+        f32x4 v[2 * VQ_UNROLL];
 #pragma unroll
-        for (int u = 0; u < VQ_UNROLL; u++) {
-            const uint64_t i = w + 64 * u + lane;
-            a[u] = __builtin_nontemporal_load(&x[2 * i]);
-            b[u] = __builtin_nontemporal_load(&x[2 * i + 1]);
+        for (int j = 0; j < 2 * VQ_UNROLL; j++) v[j] = __builtin_nontemporal_load(&x[2 * w + 64 * j + lane]);
+        uint32_t half[2 * VQ_UNROLL];
+#pragma unroll
+        for (int j = 0; j < 2 * VQ_UNROLL; j++) {
+            float m = fmaxf(fmaxf(__builtin_fabsf(v[j].x), __builtin_fabsf(v[j].y)), fmaxf(__builtin_fabsf(v[j].z), __builtin_fabsf(v[j].w)));
+            m = fix_zero_max(row16_max(m));
+            half[j] = quant_pack4(v[j], 7.0f / m);            // IEEE-correct fp32 division (CloverVector4.h:668)
+            if ((lane & 15) == 0) s[(w >> 3) + 4 * j + (lane >> 4)] = m;
         }
 #pragma unroll
-        for (int u = 0; u < VQ_UNROLL; u++) quantize_word(a[u], b[u], w + 64 * u + lane, q, s);
+        for (int j = 0; j < 2 * VQ_UNROLL; j += 2) {
+            const uint32_t give = odd ? half[j] : half[j + 1];
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+            const uint32_t word = odd ? (recv | (half[j + 1] << 16)) : (half[j] | (recv << 16));
+            __builtin_nontemporal_store(word, &q[w + 32 * (j + odd) + sub]);
+        }
     }
     for (; w < w1; w += 64) {
         const uint64_t i = w + lane;                 // nwords is a multiple of 16: whole 8-lane blocks are in or out
