@@ -148,12 +148,20 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CLOVER_BENCH_DEBUG_ONE_GPU=1: rehearsal of the N>1 control flow on a box with ONE GPU -- every rank uses device 0 and the
+    # exchange goes through gloo and the host.  Never a measurement: the output says so.
+    debug_one_gpu = world > 1 and os.environ.get("CLOVER_BENCH_DEBUG_ONE_GPU") == "1"
+    dev_index = 0 if debug_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = torch.device("cpu") if debug_one_gpu else dev          # where the tiny timing all-reduces live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if debug_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    hip = CloverHip(device=local_rank)               # raises if libclover_hip.so is missing: no fallback
+    hip = CloverHip(device=dev_index)                # raises if libclover_hip.so is missing: no fallback
     lib = hip.lib
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -186,8 +194,8 @@ def main() -> None:
         hip.check(lib.clm4_mvm(A.data_ptr(), sA.data_ptr(), rows, cols, x.data_ptr(), sx.data_ptr(), r_ptr, sr_ptr, None, stream))
         if i is not None:
             ev[i][1].record()
-        if world > 1:
-            gather_packed(res, rows_total)        # RCCL all-gather of [nibbles | scales] from every rank
+        if world > 1:                             # RCCL all-gather of [nibbles | scales] from every rank
+            gather_packed(res.cpu() if debug_one_gpu else res, rows_total)
 
     for _ in range(args.warmup):
         step(None)
@@ -201,17 +209,30 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    kt = torch.tensor([kern_avg_ms], dtype=torch.float64, device=dev)
+    kt = torch.tensor([kern_avg_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kern_avg_ms = float(kt.item())
+
+    # outside the timed region: every rank finds its own shard, bit for bit, at its place in the gathered vector
+    gather_ok = None
+    if world > 1:
+        from clover_amd.sharding import unpack_gathered
+        g = gather_packed(res.cpu() if debug_one_gpu else res, rows_total)
+        nib, sc = unpack_gathered(g, rows_total, world)
+        mine = res.cpu() if debug_one_gpu else res
+        ok = bool(torch.equal(nib[rank * rows // 2: (rank + 1) * rows // 2], mine[: rows // 2])) and \
+            bool(torch.equal(sc[rank * rows // 64: (rank + 1) * rows // 64], mine[rows // 2:].view(torch.float32)))
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        gather_ok = bool(okt.item())
 
     if rank != 0:
         if world > 1:
@@ -233,6 +254,8 @@ def main() -> None:
             "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 (BASELINE configs[2] per GPU), x and result CloverVector4, "
                         f"STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
             "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of packed result" if world > 1 else ""),
+            **({"gathered_result_verified": gather_ok} if world > 1 else {}),
+            **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all ranks on one GPU, gloo through the host -- not a measurement"} if debug_one_gpu else {}),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_step": bytes_total,
             "arithmetic": "int4 x int4 products summed exactly per 32-bit word (v_dot8_i32_i4), fp32 per-block scale + fma chains in reference order",
