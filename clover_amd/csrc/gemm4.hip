@@ -21,7 +21,7 @@
 //   pattern of 12582912.0f = 1.5 * 2^23, where one ulp is 1), so its int32 result, read as fp32, IS the float
 //   12582912 + 256*S_b exactly (|256*S_b| <= 802816 < 2^20 keeps the exponent).  One exact v_sub_f32 replaces
 //   the half-rate v_cvt_f32_i32 (measured on this chip: cvt 4.3 cycles, fma/sub 2.8 cycles per wave64), then
-//   v_fma_f32 folds it in: 8 full-rate VALU per MFMA instead of 4 half-rate + 4 full-rate.
+//   an fma folds it in; both as packed fp32 pairs (fold4): 4 VALU per MFMA instead of 4 half-rate + 4 full-rate.
 #include "common.h"
 
 #include <stdlib.h>
@@ -34,6 +34,19 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // exact (float)(raw - bias) for a biased MFMA result
 __device__ __forceinline__ float unbias(int raw) { return __int_as_float(raw) - GM_BIAS_F; }
+
+// fold the 4 results one lane holds of a 16x16 MFMA tile: acc[t] = fma(c8, raw[t] - bias, acc[t]) as two packed-fp32
+// pairs (v_pk_add_f32 + v_pk_fma_f32: 4 VALU instructions per MFMA instead of 8, each component IEEE-exact as before)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fold4(float (&acc)[4], const i32x4 raw, float c8)
+{
+    const f32x2 bias = {GM_BIAS_F, GM_BIAS_F}, cc = {c8, c8};
+    const f32x2 lo = {__int_as_float(raw.x), __int_as_float(raw.y)}, hi = {__int_as_float(raw.z), __int_as_float(raw.w)};
+    f32x2 a0 = {acc[0], acc[1]}, a1 = {acc[2], acc[3]};
+    a0 = __builtin_elementwise_fma(cc, lo - bias, a0);
+    a1 = __builtin_elementwise_fma(cc, hi - bias, a1);
+    acc[0] = a0.x; acc[1] = a0.y; acc[2] = a1.x; acc[3] = a1.y;
+}
 
 #define GM_TILE 128
 
@@ -161,8 +174,7 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
                 for (int b = 0; b < 2; b++) {
                     const i32x4 prev = Sp[a][b];
                     Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, unbias(prev[t]), acc[a][b][t]);
+                    fold4(acc[a][b], prev, c8);
                 }
         } else {
 #pragma unroll
@@ -206,9 +218,7 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c8, unbias(S0[a][b][t]), acc[a][b][t]);
+                for (int b = 0; b < 2; b++) fold4(acc[a][b], S0[a][b], c8);
         } else {
 #pragma unroll
             for (int a = 0; a < 4; a++)
