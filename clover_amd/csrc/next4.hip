@@ -74,43 +74,99 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
     for (int rr = 0; rr < Sh::ROUNDS; rr++) {
         if (lane < 4 * S) st = gen_blocks(st, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
-        uint32_t wu[Sh::STEPS], wv[Sh::STEPS];
-        float fu[Sh::STEPS], fv[Sh::STEPS];
+        if constexpr (S == 1) {
+            // small vectors: lane = one dword, 8 blocks per wave
+            uint32_t wu[Sh::STEPS], wv[Sh::STEPS];
+            float fu[Sh::STEPS], fv[Sh::STEPS];
 #pragma unroll
-        for (int u = 0; u < Sh::STEPS; u++) {                 // all loads of the round first (r may alias qu: loads precede stores per block)
-            const uint64_t blk = Sh::block(blk0, rr, 8 * u + (lane >> 3));
-            const uint64_t b = blk < nblocks ? blk : 0;
-            wu[u] = qu[b * 8 + rho];
-            wv[u] = qv[b * 8 + rho];
-            fu[u] = su[b];
-            fv[u] = sv[b];
-        }
-#pragma unroll
-        for (int u = 0; u < Sh::STEPS; u++) {
-            const int bl = 8 * u + (lane >> 3);
-            const uint64_t blk = Sh::block(blk0, rr, bl);
-            float v[8];
-            saa_values(wu[u], wv[u], fu[u] / 7.0f, (fv[u] * a) / 7.0f, v);
-            float m = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
-            m = fmaxf(m, __shfl_xor(m, 1));
-            m = fmaxf(m, __shfl_xor(m, 2));
-            m = fmaxf(m, __shfl_xor(m, 4));
-            m = fix_zero_max(m);
-            const float kq = 7.0f / m;
-            const uint32_t *W32 = reinterpret_cast<const uint32_t *>(raw + (size_t)(bl * 2) * 4);
-            const uint32_t Wd[2] = {W32[rho], W32[8 + rho]};          // W[j = rho] of draw 0 and draw 1
-            float nz[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int g = e ^ 1;
-                nz[e] = noise_of(Wd[g >> 2], g & 3);
+            for (int u = 0; u < Sh::STEPS; u++) {                 // all loads of the round first (r may alias qu: loads precede stores per block)
+                const uint64_t blk = Sh::block(blk0, rr, 8 * u + (lane >> 3));
+                const uint64_t b = blk < nblocks ? blk : 0;
+                wu[u] = qu[b * 8 + rho];
+                wv[u] = qv[b * 8 + rho];
+                fu[u] = su[b];
+                fv[u] = sv[b];
             }
-            const uint32_t packed = quant_pack8(v, kq, nz);
-            if (blk < nblocks) {
-                r[blk * 8 + rho] = packed;
-                if (rho == 0) sr[blk] = m;
+#pragma unroll
+            for (int u = 0; u < Sh::STEPS; u++) {
+                const int bl = 8 * u + (lane >> 3);
+                const uint64_t blk = Sh::block(blk0, rr, bl);
+                float v[8];
+                saa_values(wu[u], wv[u], fu[u] / 7.0f, (fv[u] * a) / 7.0f, v);
+                float m = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+                m = fmaxf(m, __shfl_xor(m, 1));
+                m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, __shfl_xor(m, 4));
+                m = fix_zero_max(m);
+                const float kq = 7.0f / m;
+                const uint32_t *W32 = reinterpret_cast<const uint32_t *>(raw + (size_t)(bl * 2) * 4);
+                const uint32_t Wd[2] = {W32[rho], W32[8 + rho]};          // W[j = rho] of draw 0 and draw 1
+                float nz[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int g = e ^ 1;
+                    nz[e] = noise_of(Wd[g >> 2], g & 3);
+                }
+                const uint32_t packed = quant_pack8(v, kq, nz);
+                if (blk < nblocks) {
+                    r[blk * 8 + rho] = packed;
+                    if (rho == 0) sr[blk] = m;
+                }
+            }
+        } else {
+            // lane = 4 dwords (half a block), 32 blocks per step: 16-byte loads and stores
+            constexpr int STEPS4 = Sh::NBR / 32 > 0 ? Sh::NBR / 32 : 1;
+            const int half = lane & 1;
+            u32x4 wu[STEPS4], wv[STEPS4];
+            float fu[STEPS4], fv[STEPS4];
+#pragma unroll
+            for (int u = 0; u < STEPS4; u++) {
+                const uint64_t blk = Sh::block(blk0, rr, 32 * u + (lane >> 1));
+                const uint64_t b = blk < nblocks ? blk : 0;
+                wu[u] = reinterpret_cast<const u32x4 *>(qu)[b * 2 + half];
+                wv[u] = reinterpret_cast<const u32x4 *>(qv)[b * 2 + half];
+                fu[u] = su[b];
+                fv[u] = sv[b];
+            }
+#pragma unroll
+            for (int u = 0; u < STEPS4; u++) {
+                const int bl = 32 * u + (lane >> 1);
+                const uint64_t blk = Sh::block(blk0, rr, bl);
+                const float su7 = fu[u] / 7.0f, sv7 = (fv[u] * a) / 7.0f;
+                float v[4][8];
+                saa_values(wu[u].x, wv[u].x, su7, sv7, v[0]);
+                saa_values(wu[u].y, wv[u].y, su7, sv7, v[1]);
+                saa_values(wu[u].z, wv[u].z, su7, sv7, v[2]);
+                saa_values(wu[u].w, wv[u].w, su7, sv7, v[3]);
+                float m = 0.0f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[q4][e]));
+                m = fmaxf(m, __shfl_xor(m, 1));
+                m = fix_zero_max(m);
+                const float kq = 7.0f / m;
+                // W[j] of draw 0 and draw 1 for this lane's words j = 4 half .. 4 half + 3
+                const u32x4 *W4 = reinterpret_cast<const u32x4 *>(raw + (size_t)(bl * 2) * 4);
+                const u32x4 Wa = W4[half], Wb = W4[2 + half];
+                const uint32_t W0[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, W1[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    float nz[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int g = e ^ 1;
+                        nz[e] = noise_of((g >> 2) ? W1[q4] : W0[q4], g & 3);
+                    }
+                    o[q4] = quant_pack8(v[q4], kq, nz);
+                }
+                if (blk < nblocks) {
+                    reinterpret_cast<u32x4 *>(r)[blk * 2 + half] = u32x4{o[0], o[1], o[2], o[3]};
+                    if (half == 0) sr[blk] = m;
+                }
             }
         }
         if (rr + 1 < Sh::ROUNDS) __syncthreads();
