@@ -42,6 +42,25 @@ __device__ __forceinline__ void mvm_steps(const u32x4 *__restrict__ Ap, const u3
     }
 }
 
+// 8 lanes per row (lane e owns chains 2e, 2e+1 and loads 8 bytes per step): twice the waves per workgroup, for
+// matrices with too few 64-row groups to fill the chip with 4-wave workgroups
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int U, bool NT>
+__device__ __forceinline__ void mvm_steps8(const u32x2 *__restrict__ Ap, const u32x2 *xs, const float *cs, int e, uint32_t t0, float &a0,
+                                           float &a1)
+{
+    u32x2 a[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) a[u] = NT ? __builtin_nontemporal_load(&Ap[8 * (t0 + u) + e]) : Ap[8 * (t0 + u) + e];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const u32x2 xv = xs[8 * (t0 + u) + e];
+        const float c = cs[2 * (t0 + u) + (e >> 2)];
+        a0 = __builtin_fmaf(c, (float)sdot8(a[u].x, xv.x, 0), a0);
+        a1 = __builtin_fmaf(c, (float)sdot8(a[u].y, xv.y, 0), a1);
+    }
+}
+
 // re-quantise 64 values held one per lane of a full wave (CloverMatrix4.h:919-1080); returns this lane's nibble value,
 // *scale = the block maximum.  r_words / sr may be NULL (result not stored).
 __device__ __forceinline__ int requantize_wave(float d, float noise, uint32_t *r_words, float *sr, float *scale)
@@ -78,8 +97,8 @@ struct MvmFuse {
 // group g of AVX lane j lands on row 8j+g: row l uses group g = l&7 (draw g>>2, byte g&3) of word W[l>>3].
 // With FUSE the scaleAndAdd draws follow ALL the mvm draws in the stream, as in the two separate calls: row group rb
 // then uses draws 2G + 2rb, 2G + 2rb + 1 (G = number of row groups), with the scaleAndAdd lane map 8j + (g ^ 1).
-template <int U, bool NT, bool ST, bool FUSE>
-__global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A, const float *__restrict__ sA,
+template <int U, bool NT, bool ST, bool FUSE, int L = 4>
+__global__ __launch_bounds__(64 * L) void k_m4_mvm64(const uint8_t *__restrict__ A, const float *__restrict__ sA,
                                                   uint64_t cols, const uint8_t *__restrict__ x, const float *__restrict__ sx,
                                                   float *__restrict__ d_out, uint32_t *r, float *sr,
                                                   uint64_t *rng_state, uint64_t seq, const uint64_t *__restrict__ pow_rows, MvmFuse fuse)
@@ -106,10 +125,12 @@ __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A,
         fuse_s = fuse.su[blockIdx.x];
     }
 
+    static_assert(L == 4 || (L == 8 && !ST), "the stochastic epilogue assumes 4 waves");
+    constexpr int THREADS = 64 * L;
     const uint64_t rb = blockIdx.x;
     const int tid = threadIdx.x;
-    const int q = tid & 3;
-    const int rho = tid >> 2;
+    const int q = tid & (L - 1);                    // L == 4: quarter (chains 4q..4q+3);  L == 8: eighth (chains 2q, 2q+1)
+    const int rho = tid / L;
     const uint64_t row = rb * 64 + rho;
     const u32x4 *Arow = reinterpret_cast<const u32x4 *>(A + row * (cols / 2));
     const float *sArow = sA + rb * (cols / 64);
@@ -123,23 +144,23 @@ __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A,
         // unrolled loads instead of a runtime-trip-count loop, which hipcc turns into load-wait-store chains.
         const u32x4 *xg = reinterpret_cast<const u32x4 *>(x + c0 / 2);
         {
-            constexpr int NX = MVM_CHUNK / 32 / 256;          // 8 x 16 B per thread
-            constexpr int NC = MVM_CHUNK / 64 / 256;          // 4 factors per thread
+            constexpr int NX = MVM_CHUNK / 32 / THREADS;      // 8 x 16 B per thread (L == 4)
+            constexpr int NC = MVM_CHUNK / 64 / THREADS;      // 4 factors per thread
             u32x4 xr[NX];
             float sa[NC], sv[NC];
             const uint32_t nx = cw / 32, nc = cw / 64;
 #pragma unroll
-            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; xr[k] = xg[i < nx ? i : 0]; }
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + THREADS * k; xr[k] = xg[i < nx ? i : 0]; }
 #pragma unroll
             for (int k = 0; k < NC; k++) {
-                const uint32_t i = tid + 256 * k, ii = i < nc ? i : 0;
+                const uint32_t i = tid + THREADS * k, ii = i < nc ? i : 0;
                 sa[k] = sArow[c0 / 64 + ii];
                 sv[k] = sx[c0 / 64 + ii];
             }
 #pragma unroll
-            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) xs[i] = xr[k]; }
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + THREADS * k; if (i < nx) xs[i] = xr[k]; }
 #pragma unroll
-            for (int k = 0; k < NC; k++) { const uint32_t i = tid + 256 * k; if (i < nc) cs[i] = (sa[k] * CLV_RCP49) * sv[k]; }
+            for (int k = 0; k < NC; k++) { const uint32_t i = tid + THREADS * k; if (i < nc) cs[i] = (sa[k] * CLV_RCP49) * sv[k]; }
         }
         __syncthreads();
 
@@ -148,8 +169,15 @@ __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A,
         const u32x4 *Ap = Arow + c0 / 32;
         const uint32_t npairs = cw / 128;
         uint32_t t = 0;
-        for (; t + U <= npairs; t += U) mvm_steps<U, NT>(Ap, xs, cs, q, t, a0, a1, a2, a3);
-        for (; t < npairs; t++) mvm_steps<1, NT>(Ap, xs, cs, q, t, a0, a1, a2, a3);
+        if constexpr (L == 4) {
+            for (; t + U <= npairs; t += U) mvm_steps<U, NT>(Ap, xs, cs, q, t, a0, a1, a2, a3);
+            for (; t < npairs; t++) mvm_steps<1, NT>(Ap, xs, cs, q, t, a0, a1, a2, a3);
+        } else {
+            const u32x2 *Ap8 = reinterpret_cast<const u32x2 *>(Ap);
+            const u32x2 *xs8 = reinterpret_cast<const u32x2 *>(xs);
+            for (; t + U <= npairs; t += U) mvm_steps8<U, NT>(Ap8, xs8, cs, q, t, a0, a1);
+            for (; t < npairs; t++) mvm_steps8<1, NT>(Ap8, xs8, cs, q, t, a0, a1);
+        }
     }
 
     // chain (4q+i): accumulator a = q>>1, AVX lane w = 4(q&1)+i.  Fixed tree of CloverBase.h:149-157:
@@ -161,7 +189,15 @@ __global__ __launch_bounds__(256) void k_m4_mvm64(const uint8_t *__restrict__ A,
     const float x1 = v1 + __shfl_xor(v1, 1);
     const float x2 = v2 + __shfl_xor(v2, 1);
     const float x3 = v3 + __shfl_xor(v3, 1);
-    const float dot = (x0 + x2) + (x1 + x3);
+    float dot = (x0 + x2) + (x1 + x3);
+    if constexpr (L == 8) {
+        // chain 2q+i: accumulator a = q>>2, AVX lane w = 2(q&3)+i.  Same tree: acc[0][w]+acc[1][w] (lanes q, q^4), then
+        // v[w]+v[w+4] (q, q^2) gives x[2(q&1)+i], then (x0+x2)+(x1+x3) (q, q^1)
+        const float u0 = a0 + __shfl_xor(a0, 4), u1 = a1 + __shfl_xor(a1, 4);
+        const float y0 = u0 + __shfl_xor(u0, 2), y1 = u1 + __shfl_xor(u1, 2);
+        const float z0 = y0 + __shfl_xor(y0, 1), z1 = y1 + __shfl_xor(y1, 1);       // x0+x2, x1+x3
+        dot = z0 + z1;
+    }
 
     if (q == 0) {
         dsh[rho] = dot;
@@ -294,7 +330,17 @@ static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t 
     // Streaming (nt) loads win once the matrix cannot live in the 256 MiB Infinity Cache (+14 % at 2 GiB); below
     // that, default-policy loads keep it cache-resident across calls (8192^2: 7.3 vs 11.9 us) -- measured, r01.
     const bool streaming = rows * (cols / 2) > (256ull << 20);
-    if (streaming) {
+    // few row groups (<= 2 per CU) of a matrix that streams from HBM: 8 lanes per row double the waves in flight
+    // (32768^2: 92 -> 89 us); measured no better anywhere else (r01 microbench variants 7-10)
+    const bool wide = streaming && !rng && rows / 64 <= 2ull * (uint64_t)clv_cu_count();
+    if (wide) {
+        if (fuse)
+            hipLaunchKernelGGL((k_m4_mvm64<16, true, false, true, 8>), grid, dim3(512), lds, st, (const uint8_t *)A, sA, cols,
+                               (const uint8_t *)x, sx, d, (uint32_t *)r, sr, rng, seq, T.pow_rows, *fuse);
+        else
+            hipLaunchKernelGGL((k_m4_mvm64<16, true, false, false, 8>), grid, dim3(512), lds, st, (const uint8_t *)A, sA, cols,
+                               (const uint8_t *)x, sx, d, (uint32_t *)r, sr, rng, seq, T.pow_rows, no_fuse);
+    } else if (streaming) {
         if (rng) MVM_LAUNCH(true, true); else MVM_LAUNCH(true, false);
     } else {
         if (rng) MVM_LAUNCH(false, true); else MVM_LAUNCH(false, false);
@@ -348,6 +394,15 @@ extern "C" int clvx_mvm_variant(int variant, const int8_t *A, const float *sA, u
     case 4: CLVX_LAUNCH(2, true); break;
     case 5: CLVX_LAUNCH(16, false); break;
     case 6: CLVX_LAUNCH(32, false); break;
+#define CLVX_LAUNCH8(U, NT)                                                                                                       \
+    hipLaunchKernelGGL((k_m4_mvm64<U, NT, false, false, 8>), grid, dim3(512), lds, st, (const uint8_t *)A, sA, cols, (const uint8_t *)x, \
+                       sx, (float *)nullptr, (uint32_t *)r, sr, (uint64_t *)nullptr, 0ull, (const uint64_t *)nullptr,                 \
+                       MvmFuse{nullptr, nullptr, 0.0f, nullptr, nullptr})
+    case 7: CLVX_LAUNCH8(8, false); break;
+    case 8: CLVX_LAUNCH8(16, false); break;
+    case 9: CLVX_LAUNCH8(8, true); break;
+    case 10: CLVX_LAUNCH8(16, true); break;
+#undef CLVX_LAUNCH8
     default: clv_set_error("clvx_mvm_variant: unknown variant %d", variant); return CLV_ERR_INVALID;
     }
 #undef CLVX_LAUNCH

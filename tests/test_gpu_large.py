@@ -89,6 +89,29 @@ def test_c3_mvm_65536_sampled_and_sharded(hip, oracle):
     assert same(np.concatenate(parts_r), r_h) and same(np.concatenate(parts_s), sr_h)
 
 
+def test_mvm_few_row_groups_streaming_matrix(hip, oracle):
+    """a matrix that streams from HBM (> 256 MiB) but has only 16 row groups takes the 8-lanes-per-row kernel; 11 LDS chunks
+    of columns; plain and fused-with-scaleAndAdd, against the whole oracle result"""
+    rows, cols = 1024, 655360 + 128
+    A, sA, x, sx = _device_matrix(hip, rows, cols, 0x51)
+    qA, sAh, qx, sxh = A.download(np.uint8), sA.download(np.float32), x.download(np.uint8), sx.download(np.float32)
+    ro, sro = oracle.m4_mvm(qA, sAh, rows, cols, qx, sxh)
+    r, sr = hip.alloc(rows // 2), hip.alloc(rows // 64 * 4)
+    hip.check(hip.lib.clm4_mvm(A.ptr, sA.ptr, rows, cols, x.ptr, sx.ptr, r.ptr, sr.ptr, None, None))
+    assert same(r.download(np.uint8), ro) and same(sr.download(np.float32), sro)
+    rng = np.random.default_rng(5)
+    qu = rng.integers(0, 256, rows // 2).astype(np.uint8)
+    qu[(qu >> 4) == 8] ^= 0x80
+    qu[(qu & 0xF) == 8] ^= 0x08
+    su = rng.uniform(0.5, 2, rows // 64).astype(np.float32)
+    du, dsu = hip.to_device(qu), hip.to_device(su)
+    r2, sr2 = hip.alloc(rows // 2), hip.alloc(rows // 64 * 4)
+    hip.check(hip.lib.clm4_mvm_scale_and_add(A.ptr, sA.ptr, rows, cols, x.ptr, sx.ptr, du.ptr, dsu.ptr, 0.25, None, None,
+                                             r2.ptr, sr2.ptr, None, None))
+    r2o, sr2o = oracle.v4_scale_and_add(qu, su, ro, sro, 0.25)
+    assert same(r2.download(np.uint8), r2o) and same(sr2.download(np.float32), sr2o)
+
+
 def test_gemm_2048_sampled(hip, oracle):
     M = N = K = 2048
     kb = K // 64
