@@ -111,6 +111,26 @@ __device__ __forceinline__ uint32_t quant_pack8(const float v[8], float k, const
     return k < __builtin_inff() ? pack8(q) : 0u;
 }
 
+// maximum over the 16 lanes of a DPP row (rotations inside the row), result in every lane
+__device__ __forceinline__ float row16_max(float m)
+{
+#define ROR_MAX(n) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x120 + n, 0xF, 0xF, false)))
+    ROR_MAX(8);
+    ROR_MAX(4);
+    ROR_MAX(2);
+    ROR_MAX(1);
+#undef ROR_MAX
+    return m;
+}
+
+// the 4 nibbles of half h of an output dword (elements 4h..4h+3 -> bytes 2h, 2h+1, even elements in the high nibble)
+__device__ __forceinline__ uint32_t quant_pack4(const f32x4 v, float k)
+{
+    const uint32_t h = (((uint32_t)quant1_det(v.x, k) & 0xFu) << 4) | ((uint32_t)quant1_det(v.y, k) & 0xFu) |
+                       (((uint32_t)quant1_det(v.z, k) & 0xFu) << 12) | (((uint32_t)quant1_det(v.w, k) & 0xFu) << 8);
+    return k < __builtin_inff() ? h : 0u;       // see quant_pack8
+}
+
 // signed nibble e of word w
 __device__ __forceinline__ int unpack1(uint32_t w, int e)
 {

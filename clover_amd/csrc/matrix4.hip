@@ -236,6 +236,48 @@ __global__ __launch_bounds__(64 * L) void k_m4_mvm64(const uint8_t *__restrict__
 // workgroup = one 64x64 tile (256 threads); thread = (row r = tid>>3 [+32 on the second pass],
 // octet o = tid&7) holds 8 consecutive values = one output dword.  Pass 1 reduces the tile maximum
 // (registers -> wave shuffle -> LDS); pass 2 quantises from the registers, nothing is re-read.
+// workgroup = 64 rows x 256 columns = 4 tiles side by side (256 threads, 64 floats each).  A wave-instruction reads
+// one contiguous KiB of a row (lane = float4); lanes 16t..16t+15 -- one DPP row -- belong to tile t, so the tile maximum
+// is a per-lane maximum over the wave's 16 rows, a row rotation reduce and a 4-wave combine in LDS.  A lane quantises
+// half a dword; lane pairs swap halves between two consecutive rows so that every lane stores a whole dword and a row
+// receives 128 contiguous bytes.  Columns beyond `cols` (cols is a multiple of 128, not of 256) are masked.
+__global__ __launch_bounds__(256) void k_m4_quantize_strip(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
+                                                           float *__restrict__ s, uint32_t strips_x, uint32_t tiles_x)
+{
+    __shared__ float sh[4][4];
+    const uint32_t sj = blockIdx.x % strips_x;
+    const uint64_t bi = blockIdx.x / strips_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t col = (uint64_t)sj * 256 + 4 * lane;
+    const bool live = col < cols;
+    const uint64_t row0 = bi * 64 + wave * 16;
+
+    f32x4 v[16];
+    float m = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        v[r] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(A + (row0 + r) * cols + col)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v[r].x), __builtin_fabsf(v[r].y)), fmaxf(__builtin_fabsf(v[r].z), __builtin_fabsf(v[r].w))));
+    }
+    m = row16_max(m);
+    if ((lane & 15) == 0) sh[wave][lane >> 4] = m;
+    __syncthreads();
+    const int t = lane >> 4;
+    m = fix_zero_max(fmaxf(fmaxf(sh[0][t], sh[1][t]), fmaxf(sh[2][t], sh[3][t])));
+    const float k = 7.0f / m;
+    if (wave == 0 && (lane & 15) == 0 && live) s[bi * tiles_x + sj * 4 + t] = m;
+    const int odd = lane & 1;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t h0 = quant_pack4(v[r], k), h1 = quant_pack4(v[r + 1], k);
+        const uint32_t give = odd ? h0 : h1;
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        const uint32_t word = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
+        // even lanes hold the dword of row r, odd lanes that of row r+1; dword index inside the row = (col of the pair) / 8
+        if (live) __builtin_nontemporal_store(word, &q[((row0 + r + odd) * cols + (col & ~7ull)) / 8]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_m4_quantize(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
                                                      float *__restrict__ s, uint32_t tiles_x)
 {
@@ -464,6 +506,14 @@ extern "C" int clm4_quantize(const float *A, uint64_t rows, uint64_t cols, int8_
     const uint64_t tiles = (rows / 64) * (cols / 64);
     CLV_REQUIRE(tiles <= 0x7FFFFFFFull, "clm4_quantize: too many tiles");
     if (rng_state_dev) return clm4_quantize_stochastic(A, rows, cols, q, s, rng_state_dev, as_stream(stream));
+    static const bool tile_kernel = getenv("CLV_M4Q_TILE") != nullptr;       // A/B switch: the older one-tile-per-workgroup kernel
+    if (!tile_kernel) {
+        const uint32_t strips_x = (uint32_t)((cols + 255) / 256);
+        hipLaunchKernelGGL(k_m4_quantize_strip, dim3((unsigned)((rows / 64) * strips_x)), dim3(256), 0, as_stream(stream), A, cols,
+                           (uint32_t *)q, s, strips_x, (uint32_t)(cols / 64));
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
     hipLaunchKernelGGL(k_m4_quantize, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), A, cols, (uint32_t *)q, s,
                        (uint32_t)(cols / 64));
     CLV_LAUNCH_CHECK();

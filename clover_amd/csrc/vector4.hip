@@ -27,26 +27,6 @@ __device__ __forceinline__ void quantize_word(const f32x4 a, const f32x4 b, uint
     if ((i & 7) == 0) s[i >> 3] = m;
 }
 
-// maximum over the 16 lanes of a DPP row (rotations inside the row), result in every lane
-__device__ __forceinline__ float row16_max(float m)
-{
-#define ROR_MAX(n) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x120 + n, 0xF, 0xF, false)))
-    ROR_MAX(8);
-    ROR_MAX(4);
-    ROR_MAX(2);
-    ROR_MAX(1);
-#undef ROR_MAX
-    return m;
-}
-
-// the 4 nibbles of half h of an output dword (elements 4h..4h+3 -> bytes 2h, 2h+1, even elements in the high nibble)
-__device__ __forceinline__ uint32_t quant_pack4(const f32x4 v, float k)
-{
-    const uint32_t h = (((uint32_t)quant1_det(v.x, k) & 0xFu) << 4) | ((uint32_t)quant1_det(v.y, k) & 0xFu) |
-                       (((uint32_t)quant1_det(v.z, k) & 0xFu) << 12) | (((uint32_t)quant1_det(v.w, k) & 0xFu) << 8);
-    return k < __builtin_inff() ? h : 0u;       // see quant_pack8
-}
-
 // Every wave walks its own contiguous span (good DRAM page locality).  Main loop: lane -> float4, so each of the eight
 // 16-byte load instructions of a step reads one contiguous KiB; a 64-element block is then exactly one DPP row of 16
 // lanes (maximum by row rotations), a lane quantises half an output dword and lane pairs swap halves so that even
