@@ -184,6 +184,77 @@ __global__ __launch_bounds__(256) void k_m4_quantize_st(const float *__restrict_
     }
 }
 
+// strip form of the same (see k_m4_quantize_strip, matrix4.hip): workgroup = 64 rows x 4 tiles side by side.  Wave w
+// generates the draws of tile bj = 4 sj + w -- stream position t = bj * tiles_y + bi, all four generator lanes -- and
+// every lane then reads the 16 bytes of noise words its four elements of a row need.
+__device__ __forceinline__ uint32_t quant_pack4_st(const f32x4 v, float k, const u32x4 W, int sh)
+{
+    const uint32_t h = (((uint32_t)quant1_st(v.x, k, noise_of(W.x, sh)) & 0xFu) << 4) | ((uint32_t)quant1_st(v.y, k, noise_of(W.y, sh)) & 0xFu) |
+                       (((uint32_t)quant1_st(v.z, k, noise_of(W.z, sh)) & 0xFu) << 12) |
+                       (((uint32_t)quant1_st(v.w, k, noise_of(W.w, sh)) & 0xFu) << 8);
+    return k < __builtin_inff() ? h : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_m4_quantize_strip_st(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
+                                                              float *__restrict__ s, uint32_t strips_x, uint32_t tiles_x, uint64_t tiles_y,
+                                                              uint64_t *state, uint64_t seq, RngTables T)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t raw[4][64 * 2 * 4];       // per tile: 64 rows x 2 draws x 4 lanes
+    __shared__ float sh[4][4];
+    const uint32_t sj = blockIdx.x % strips_x;
+    const uint64_t bi = blockIdx.x / strips_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t col = (uint64_t)sj * 256 + 4 * lane;
+    const bool live = col < cols;
+    const uint64_t row0 = bi * 64 + wave * 16;
+
+    // the loads first: the generator work below overlaps their latency
+    f32x4 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        v[r] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(A + (row0 + r) * cols + col)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    SegRows<8> segs;
+    segs.load(T.seg_rows, 0);
+    const int slot = rng_read_slot(state, seq);
+    uint64_t a0[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a0[k] = state[slot * RNG_SLOT_WORDS + 4 + k];
+    const uint64_t bj = (uint64_t)sj * 4 + wave;                      // this wave's tile (may lie beyond the matrix: then unused)
+    const uint64_t t = bj * tiles_y + bi;
+#pragma unroll
+    for (int k = 0; k < 4; k++) b[k] = wave_pow_apply(T.pow_rows, a0[k], bj < tiles_x ? t : 0, 7);      // tile = 64 rows = 2^7 draws
+    const uint64_t st = segs.starts_from(b);
+    if (lane < 32) gen_blocks(st, 8, raw[wave] + (size_t)(8 * (lane >> 2)) * 8, lane & 3);
+    const uint64_t a0w = wave == 0 ? a0[0] : wave == 1 ? a0[1] : wave == 2 ? a0[2] : a0[3];
+    rng_commit(state, seq, slot, T.pow_rows, a0w, (uint64_t)tiles_x * tiles_y * 128);
+
+    float m = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v[r].x), __builtin_fabsf(v[r].y)), fmaxf(__builtin_fabsf(v[r].z), __builtin_fabsf(v[r].w))));
+    m = row16_max(m);
+    if ((lane & 15) == 0) sh[wave][lane >> 4] = m;
+    __syncthreads();                                               // tile maxima and every tile's draws are in LDS
+    const int tl = lane >> 4;
+    m = fix_zero_max(fmaxf(fmaxf(sh[0][tl], sh[1][tl]), fmaxf(sh[2][tl], sh[3][tl])));
+    const float k = 7.0f / m;
+    if (wave == 0 && (lane & 15) == 0 && live) s[bi * tiles_x + sj * 4 + tl] = m;
+    // elements 4c..4c+3 of a tile row (c = lane & 15): noise group g = c >> 1 (draw g >> 2, byte g & 3), words W[4 (c & 1) .. +3]
+    const int c = lane & 15, g = c >> 1;
+    const u32x4 *noise = reinterpret_cast<const u32x4 *>(raw[tl]) + (g >> 2) * 2 + (c & 1);     // + 4 per tile row
+    const int odd = lane & 1;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const int tr = wave * 16 + r;                              // tile row = stream block within the tile
+        const uint32_t h0 = quant_pack4_st(v[r], k, noise[4 * tr], g & 3), h1 = quant_pack4_st(v[r + 1], k, noise[4 * (tr + 1)], g & 3);
+        const uint32_t give = odd ? h0 : h1;
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        const uint32_t word = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
+        if (live) __builtin_nontemporal_store(word, &q[((row0 + r + odd) * cols + (col & ~7ull)) / 8]);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 // segments (of 8 blocks) per wave for the vector kernels.  The choice never changes results, only speed;
 // clvx_set_st_segments (tests, experiments; not in the public header) or CLV_ST_SEGMENTS=1|4|16 force one shape.
@@ -228,6 +299,14 @@ int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_
     int rc = clv_rng_tables(&T);
     if (rc) return rc;
     const uint64_t tiles = (rows / 64) * (cols / 64);
+    static const bool tile_kernel = getenv("CLV_M4Q_TILE") != nullptr;       // A/B switch: the older one-tile-per-workgroup kernel
+    if (!tile_kernel) {
+        const uint32_t strips_x = (uint32_t)((cols + 255) / 256);
+        hipLaunchKernelGGL(k_m4_quantize_strip_st, dim3((unsigned)((rows / 64) * strips_x)), dim3(256), 0, st, A, cols, (uint32_t *)q, s,
+                           strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_next_seq(), T);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
     hipLaunchKernelGGL(k_m4_quantize_st, dim3((unsigned)tiles), dim3(256), 0, st, A, cols, (uint32_t *)q, s, (uint32_t)(cols / 64),
                        rows / 64, rng, clv_rng_next_seq(), T);
     CLV_LAUNCH_CHECK();

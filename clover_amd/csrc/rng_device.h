@@ -112,21 +112,16 @@ __device__ __forceinline__ uint64_t gen_blocks(uint64_t a, int nblk, uint64_t *r
     return a;
 }
 
-// Start-of-kernel step for 256-thread workgroups whose 4 waves map to the 4 generator lanes:
-// lds_base[k] = T^(index << shift)(a0[k]); workgroup 0 also writes the state after `total` (>= 1) draws
-// (part2 = T^total(a0), part1 = T^(total-1)(a0), exactly what `total` sequential draws leave behind).
-// Ends with a barrier: call from uniform control flow.  Returns a0 of this wave's generator lane.
-__device__ __forceinline__ uint64_t rng_workgroup_begin(uint64_t *state, uint64_t seq, const uint64_t *__restrict__ pow_rows,
-                                                    uint64_t index, int shift, uint64_t total, uint64_t *lds_base)
+// workgroup 0 writes the state after `total` (>= 1) draws into the other slot: wave k (0..3) advances generator lane k
+// from a0k (part2 = T^total(a0), part1 = T^(total-1)(a0), exactly what `total` sequential draws leave behind).
+// Contains a barrier that EVERY workgroup executes: call from uniform control flow.
+__device__ __forceinline__ void rng_commit(uint64_t *state, uint64_t seq, int slot, const uint64_t *__restrict__ pow_rows, uint64_t a0k,
+                                           uint64_t total)
 {
     const int k = threadIdx.x >> 6;
-    const int slot = rng_read_slot(state, seq);
-    const uint64_t a0 = state[slot * RNG_SLOT_WORDS + 4 + k];
-    const uint64_t b = wave_pow_apply(pow_rows, a0, index, shift);
-    if ((threadIdx.x & 63) == 0) lds_base[k] = b;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         uint64_t *next = state + (slot ^ 1) * RNG_SLOT_WORDS;
-        const uint64_t f = wave_pow_apply(pow_rows, a0, total - 1, 0);
+        const uint64_t f = wave_pow_apply(pow_rows, a0k, total - 1, 0);
         if ((threadIdx.x & 63) == 0) {
             next[k] = f;
             next[4 + k] = xs_T(f);
@@ -139,6 +134,20 @@ __device__ __forceinline__ uint64_t rng_workgroup_begin(uint64_t *state, uint64_
     } else {
         __syncthreads();
     }
+}
+
+// Start-of-kernel step for 256-thread workgroups whose 4 waves map to the 4 generator lanes:
+// lds_base[k] = T^(index << shift)(a0[k]), then rng_commit.  Ends with a barrier: call from uniform control flow.
+// Returns a0 of this wave's generator lane.
+__device__ __forceinline__ uint64_t rng_workgroup_begin(uint64_t *state, uint64_t seq, const uint64_t *__restrict__ pow_rows,
+                                                        uint64_t index, int shift, uint64_t total, uint64_t *lds_base)
+{
+    const int k = threadIdx.x >> 6;
+    const int slot = rng_read_slot(state, seq);
+    const uint64_t a0 = state[slot * RNG_SLOT_WORDS + 4 + k];
+    const uint64_t b = wave_pow_apply(pow_rows, a0, index, shift);
+    if ((threadIdx.x & 63) == 0) lds_base[k] = b;
+    rng_commit(state, seq, slot, pow_rows, a0, total);
     return a0;
 }
 
@@ -156,10 +165,15 @@ struct SegRows {
     }
     __device__ __forceinline__ uint64_t starts(const uint64_t *lds_base) const
     {
-        const int lane = threadIdx.x & 63;
         uint64_t b[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) b[k] = uniform64(lds_base[k]);
+        return starts_from(b);
+    }
+    // b[k]: wave-uniform base of generator lane k
+    __device__ __forceinline__ uint64_t starts_from(const uint64_t (&b)[4]) const
+    {
+        const int lane = threadIdx.x & 63;
         uint64_t a = 0;
 #pragma unroll
         for (int s = 0; s < NSEG; s++) {

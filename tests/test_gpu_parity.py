@@ -217,14 +217,16 @@ def test_stochastic_vector_ops_every_kernel_shape(hip, oracle, segments):
         hip.lib.clvx_set_st_segments(0)
 
 
-def test_stochastic_matrix_quantize_and_mvm_same_stream(hip, oracle):
-    rng = np.random.default_rng(8)
-    M, N = 256, 384
+@pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 640), (192 * 2, 1280)])
+def test_stochastic_matrix_quantize_and_mvm_same_stream(hip, oracle, shape):
+    M, N = shape
+    rng = np.random.default_rng(8 + M + N)
     A = rng.normal(size=(M, N)).astype(np.float32)
     st, o = hip.new_rng(445560390295639063, 2935984234003016713), oracle.rng(445560390295639063, 2935984234003016713)
-    qA, sA = hip.m4_quantize(A, rng=st)
-    qAo, sAo = oracle.m4_quantize(A, o)
-    assert same(qA, qAo) and same(sA, sAo)
+    for _ in range(2):                       # the second call continues the stream
+        qA, sA = hip.m4_quantize(A, rng=st)
+        qAo, sAo = oracle.m4_quantize(A, o)
+        assert same(qA, qAo) and same(sA, sAo)
     qx = oracle.v4_quantize(rng.normal(size=N).astype(np.float32))
     r, sr = hip.m4_mvm(qA, sA, M, N, *qx, rng=st)
     ro, sro = oracle.m4_mvm(qA, sA, M, N, *qx, o)
