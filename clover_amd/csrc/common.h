@@ -56,6 +56,7 @@ __device__ __forceinline__ int sdot8(uint32_t a, uint32_t b, int c)
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int dot32(const u32x4 &a, const u32x4 &b)

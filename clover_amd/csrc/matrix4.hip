@@ -44,7 +44,6 @@ __device__ __forceinline__ void mvm_steps(const u32x4 *__restrict__ Ap, const u3
 
 // 8 lanes per row (lane e owns chains 2e, 2e+1 and loads 8 bytes per step): twice the waves per workgroup, for
 // matrices with too few 64-row groups to fill the chip with 4-wave workgroups
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <int U, bool NT>
 __device__ __forceinline__ void mvm_steps8(const u32x2 *__restrict__ Ap, const u32x2 *xs, const float *cs, int e, uint32_t t0, float &a0,
                                            float &a1)

@@ -1,0 +1,397 @@
+// mixed8.hip -- mixed precision: 4-bit matrix x 8-bit vector ("mixed 4b x 8b is what the paper's
+// best-accuracy runs use").  CloverVector8 (CloverVector8.h:35-140): int8 values in natural order, one fp32 scale per
+// 64 elements, value = q * scale / 127.  Here: its quantize / restore and CloverMatrix4::mvm(CloverVector8, CloverVector8)
+// (CloverMatrix4.h:1093-1441), bit-exact in the reference's SIMD order.
+#include "rng_device.h"
+
+// =================================================================================================
+// CloverVector8::quantize (CloverVector8.h:393-606), rounding disabled: lane = one float4 in, 4 bytes out; a
+// 64-element block is one DPP row of 16 lanes.  Algorithmic bytes: 4 + 1 + 1/16 per element.
+// =================================================================================================
+#define V8_LOADS 8
+__global__ __launch_bounds__(256) void k_v8_quantize(const f32x4 *__restrict__ x, uint32_t *__restrict__ q, float *__restrict__ s,
+                                                     uint64_t nquads)
+{
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint64_t f0 = wave * (64 * V8_LOADS);                 // first float4 of this wave's chunk
+    f32x4 v[V8_LOADS];
+#pragma unroll
+    for (int j = 0; j < V8_LOADS; j++) {
+        const uint64_t f = f0 + 64 * j + lane;
+        v[j] = __builtin_nontemporal_load(&x[f < nquads ? f : 0]);       // nquads is a multiple of 32: whole 16-lane blocks are in or out
+    }
+#pragma unroll
+    for (int j = 0; j < V8_LOADS; j++) {
+        const uint64_t f = f0 + 64 * j + lane;
+        float m = fmaxf(fmaxf(__builtin_fabsf(v[j].x), __builtin_fabsf(v[j].y)), fmaxf(__builtin_fabsf(v[j].z), __builtin_fabsf(v[j].w)));
+        m = fix_zero_max(row16_max(m));
+        const float k = 127.0f / m;                             // CloverVector8.h:455
+        const uint32_t w = ((uint32_t)quant1_det(v[j].x, k) & 0xFFu) | (((uint32_t)quant1_det(v[j].y, k) & 0xFFu) << 8) |
+                           (((uint32_t)quant1_det(v[j].z, k) & 0xFFu) << 16) | (((uint32_t)quant1_det(v[j].w, k) & 0xFFu) << 24);
+        if (f < nquads) {
+            __builtin_nontemporal_store(k < __builtin_inff() ? w : 0u, &q[f]);      // k == inf: see quant_pack8 (common.h)
+            if ((lane & 15) == 0) s[f >> 4] = m;
+        }
+    }
+}
+
+// stochastic: the same segment walk as k_v4_quantize_st (rng4.hip): lane = 8 elements = 8 bytes out;
+// noise group g = element/8 (draw g>>2, byte g&3), word W[element%8] (CloverVector8.h:472-520, 546-553)
+template <int S>
+__global__ __launch_bounds__(256) void k_v8_quantize_st(const f32x4 *__restrict__ x, u32x2 *__restrict__ q, float *__restrict__ s,
+                                                        uint64_t nblocks, uint64_t *state, uint64_t seq, RngTables T)
+{
+    typedef StShape<S> Sh;
+    __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][Sh::NBR * 2 * 4];
+    __shared__ uint64_t base[4];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    SegRows<S> segs;
+    segs.load(T.seg_rows, wave * S);
+    rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
+    uint64_t *raw = raw_all[wave];
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
+    const int seg = lane >> 2, k = lane & 3;
+    uint64_t a = segs.starts(base);
+    const int rho = lane & 7;
+
+    for (int r = 0; r < Sh::ROUNDS; r++) {
+        if (lane < 4 * S) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+        __syncthreads();
+        f32x4 lo[Sh::STEPS], hi[Sh::STEPS];
+#pragma unroll
+        for (int u = 0; u < Sh::STEPS; u++) {
+            const uint64_t blk = Sh::block(blk0, r, 8 * u + (lane >> 3));
+            const uint64_t i = blk < nblocks ? blk * 8 + rho : 0;
+            lo[u] = __builtin_nontemporal_load(&x[2 * i]);
+            hi[u] = __builtin_nontemporal_load(&x[2 * i + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < Sh::STEPS; u++) {
+            const int bl = 8 * u + (lane >> 3);
+            const uint64_t blk = Sh::block(blk0, r, bl);
+            const float v[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            float m = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            m = fix_zero_max(m);
+            const float kq = 127.0f / m;
+            const u32x4 *Wp = reinterpret_cast<const u32x4 *>(raw + (size_t)(bl * 2 + (rho >> 2)) * 4);
+            const u32x4 W0 = Wp[0], W1 = Wp[1];
+            const uint32_t W[8] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
+            uint32_t b[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) b[e] = (uint32_t)quant1_st(v[e], kq, noise_of(W[e], rho & 3)) & 0xFFu;
+            u32x2 out;
+            out.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            out.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            if (!(kq < __builtin_inff())) out.x = out.y = 0u;
+            if (blk < nblocks) {
+                q[blk * 8 + rho] = out;
+                if (rho == 0) s[blk] = m;
+            }
+        }
+        if (r + 1 < Sh::ROUNDS) __syncthreads();
+    }
+}
+
+// CloverVector8::restore (CloverVector8.h:835-909): x = (float)q * (scale / 127.0f); lane = one dword in, one float4 out
+template <bool NT>
+__global__ __launch_bounds__(256) void k_v8_restore(const uint32_t *__restrict__ q, const float *__restrict__ s, f32x4 *__restrict__ x,
+                                                    uint64_t nquads)
+{
+    const uint64_t f0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 256;
+    const int lane = threadIdx.x & 63;
+    uint32_t w[4];
+    float sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t f = f0 + 64 * j + lane, fc = f < nquads ? f : 0;
+        w[j] = q[fc];
+        sc[j] = s[fc >> 4];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t f = f0 + 64 * j + lane;
+        const float k = sc[j] / 127.0f;
+        f32x4 v;
+        v.x = (float)((int)(w[j] << 24) >> 24) * k;
+        v.y = (float)((int)(w[j] << 16) >> 24) * k;
+        v.z = (float)((int)(w[j] << 8) >> 24) * k;
+        v.w = (float)((int)w[j] >> 24) * k;
+        if (f < nquads) {
+            if (NT) __builtin_nontemporal_store(v, &x[f]);
+            else x[f] = v;
+        }
+    }
+}
+
+// =================================================================================================
+// CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &)  (CloverMatrix4.h:1093-1441)
+//
+// Arithmetic fixed by the reference: per row 8 sequential fp32 fma chains (the 8 AVX lanes of dot_product_acc); chain L
+// takes, from every 64-column block b, the exact integer I = sum of q4*q8 over elements 4L..4L+3 and 32+4L..32+4L+3, and
+// does acc = fma(c_b, (float)I, acc) with c_b = f32(f32(sA*1/7) * f32(sx*1/127)); then ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)).
+// Mapping: workgroup = 64 output rows (256 threads) with the 8-bit re-quantisation fused; lane = (row, m) owns chains
+// 2m and 2m+1.  Per step the four lanes of a row load 64 contiguous bytes of it (two blocks, one dwordx4 each) and
+// transpose the 4x4 dwords inside the quad (two DPP exchanges) so that lane m ends up with the dwords holding ITS
+// chains' nibbles: word m and word 4+m of either block.  A nibble dword becomes two int8 dwords ((w & 0xF0F0F0F0) and
+// ((w << 4) & 0xF0F0F0F0): 16*q, no sign extension), v_perm_b32 puts elements e..e+3 next to each other, v_dot4_i32_i8
+// against the natural-order int8 of x from LDS gives 16*I.  x (int8) and c_b are staged in LDS per 32768-column chunk.
+// Algorithmic bytes per call: rows*cols/2 + 4*(rows/64)*(cols/64) + 1.0625*(rows + cols).
+// =================================================================================================
+#define MVM8_CHUNK 32768u
+
+__device__ __forceinline__ void quad_transpose4(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3, int m)
+{
+    {   // bit 0: (lane j, comp i) <-> (lane j^1, comp i^1) where the low bits differ
+        const bool b = m & 1;
+        const uint32_t s0 = b ? v0 : v1, s1 = b ? v2 : v3;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+        v0 = b ? r0 : v0; v1 = b ? v1 : r0; v2 = b ? r1 : v2; v3 = b ? v3 : r1;
+    }
+    {   // bit 1
+        const bool b = m & 2;
+        const uint32_t s0 = b ? v0 : v2, s1 = b ? v1 : v3;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0x4E, 0xF, 0xF, false);
+        v0 = b ? r0 : v0; v1 = b ? r1 : v1; v2 = b ? v2 : r0; v3 = b ? v3 : r1;
+    }
+}
+
+// 8 nibbles of a dword (elements e0..e7) -> int8 dwords {e0..e3} and {e4..e7}, each value times 16
+__device__ __forceinline__ void widen8(uint32_t w, uint32_t &d03, uint32_t &d47)
+{
+    const uint32_t lo = w & 0xF0F0F0F0u;                 // bytes [e0, e2, e4, e6] * 16
+    const uint32_t hi = (w << 4) & 0xF0F0F0F0u;          // bytes [e1, e3, e5, e7] * 16
+    d03 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);    // [lo.b0, hi.b0, lo.b1, hi.b1]
+    d47 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);    // [lo.b2, hi.b2, lo.b3, hi.b3]
+}
+
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+
+// one block (64 columns) for lane m: w_first = word m, w_second = word 4+m of the block, xb = the block's 64 int8 in LDS
+__device__ __forceinline__ void mvm8_block(uint32_t w_first, uint32_t w_second, const u32x2 *xb, int m, float c, float &a_even, float &a_odd)
+{
+    uint32_t f03, f47, s03, s47;
+    widen8(w_first, f03, f47);
+    widen8(w_second, s03, s47);
+    const u32x2 x0 = xb[m], x1 = xb[4 + m];          // elements 8m..8m+7 and 32+8m..32+8m+7
+    const int ie = sdot4(s03, x1.x, sdot4(f03, x0.x, 0)) >> 4;      // chain 2m   (exact: the sum is a multiple of 16)
+    const int io = sdot4(s47, x1.y, sdot4(f47, x0.y, 0)) >> 4;      // chain 2m+1
+    a_even = __builtin_fmaf(c, (float)ie, a_even);
+    a_odd = __builtin_fmaf(c, (float)io, a_odd);
+}
+
+template <int U, bool NT, bool ST>
+__global__ __launch_bounds__(256) void k_m4_mvm8(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
+                                                 const int8_t *__restrict__ x, const float *__restrict__ sx, float *__restrict__ d_out,
+                                                 int8_t *__restrict__ r, float *__restrict__ sr, uint64_t *rng_state, uint64_t seq,
+                                                 const uint64_t *__restrict__ pow_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 *xs = reinterpret_cast<u32x4 *>(smem);                         // MVM8_CHUNK bytes of int8
+    float *cs = reinterpret_cast<float *>(smem + MVM8_CHUNK);            // MVM8_CHUNK/64 floats
+    float *dsh = cs + MVM8_CHUNK / 64;                                   // 64 floats
+    uint64_t *rbase = reinterpret_cast<uint64_t *>(dsh + 64);            // ST: 4 lane bases, 8 raw draws
+    uint64_t *raw = rbase + 4;
+    if (ST) rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, 2ull * gridDim.x, rbase);
+
+    const uint64_t rb = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int m = tid & 3;
+    const int rho = tid >> 2;
+    const uint64_t row = rb * 64 + rho;
+    const u32x4 *Arow = reinterpret_cast<const u32x4 *>(A + row * (cols / 2));
+    const float *sArow = sA + rb * (cols / 64);
+    float a_even = 0.0f, a_odd = 0.0f;
+
+    for (uint64_t c0 = 0; c0 < cols; c0 += MVM8_CHUNK) {
+        const uint32_t cw = (uint32_t)((cols - c0) < MVM8_CHUNK ? (cols - c0) : MVM8_CHUNK);
+        if (c0) __syncthreads();
+        {
+            constexpr int NX = MVM8_CHUNK / 16 / 256;         // 8 x 16 B per thread
+            constexpr int NC = MVM8_CHUNK / 64 / 256;         // 2 factors per thread
+            const u32x4 *xg = reinterpret_cast<const u32x4 *>(x + c0);
+            u32x4 xr[NX];
+            float sa[NC], sv[NC];
+            const uint32_t nx = cw / 16, nc = cw / 64;
+#pragma unroll
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; xr[k] = xg[i < nx ? i : 0]; }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const uint32_t i = tid + 256 * k, ii = i < nc ? i : 0;
+                sa[k] = sArow[c0 / 64 + ii];
+                sv[k] = sx[c0 / 64 + ii];
+            }
+#pragma unroll
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) xs[i] = xr[k]; }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const uint32_t i = tid + 256 * k;
+                if (i < nc) cs[i] = (sa[k] * (1.0f / 7.0f)) * (sv[k] * (1.0f / 127.0f));           // CloverMatrix4.h:1147-1149
+            }
+        }
+        __syncthreads();
+
+        const u32x4 *Ap = Arow + c0 / 32;
+        const u32x2 *xq = reinterpret_cast<const u32x2 *>(xs);
+        const uint32_t nsteps = cw / 128;                     // two blocks per step
+        uint32_t t = 0;
+        for (; t + U <= nsteps; t += U) {
+            u32x4 a[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) a[u] = NT ? __builtin_nontemporal_load(&Ap[4 * (t + u) + m]) : Ap[4 * (t + u) + m];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                uint32_t w0 = a[u].x, w1 = a[u].y, w2 = a[u].z, w3 = a[u].w;
+                quad_transpose4(w0, w1, w2, w3, m);           // now: word m, word 4+m of block 2(t+u); word m, word 4+m of the next
+                const uint32_t b = 2 * (t + u);
+                mvm8_block(w0, w1, xq + 8 * b, m, cs[b], a_even, a_odd);
+                mvm8_block(w2, w3, xq + 8 * (b + 1), m, cs[b + 1], a_even, a_odd);
+            }
+        }
+        for (; t < nsteps; t++) {
+            const u32x4 av = NT ? __builtin_nontemporal_load(&Ap[4 * t + m]) : Ap[4 * t + m];
+            uint32_t w0 = av.x, w1 = av.y, w2 = av.z, w3 = av.w;
+            quad_transpose4(w0, w1, w2, w3, m);
+            const uint32_t b = 2 * t;
+            mvm8_block(w0, w1, xq + 8 * b, m, cs[b], a_even, a_odd);
+            mvm8_block(w2, w3, xq + 8 * (b + 1), m, cs[b + 1], a_even, a_odd);
+        }
+    }
+
+    // chain 2m / 2m+1 in lane m.  CloverMatrix4.h:1229-1234: h[L] = a[L+4] + a[L]; (h0 + h2) + (h1 + h3)
+    const float he = a_even + __shfl_xor(a_even, 2), ho = a_odd + __shfl_xor(a_odd, 2);      // m = 0,2: h0, h1;  m = 1,3: h2, h3
+    const float ge = he + __shfl_xor(he, 1), go = ho + __shfl_xor(ho, 1);                    // h0 + h2,  h1 + h3
+    const float dot = ge + go;
+
+    if (m == 0) {
+        dsh[rho] = dot;
+        if (d_out) d_out[row] = dot;
+    }
+    if (ST && tid < 4) gen_blocks(rbase[tid], 1, raw, tid);
+    __syncthreads();
+    if (r && tid < 64) {
+        // re-quantise the 64 row dots to 8 bits (:1246-1440); noise group g = l>>3 (draw g>>2, byte g&3), word W[l&7]
+        const float d = dsh[tid];
+        float noise = 0.0f;
+        if (ST) {
+            const int g = tid >> 3, j = tid & 7;
+            noise = noise_of(reinterpret_cast<const uint32_t *>(raw + (size_t)(g >> 2) * 4)[j], g & 3);
+        }
+        float mx = wave_max(__builtin_fabsf(d));
+        mx = fix_zero_max(mx);
+        const float k = 127.0f / mx;
+        r[rb * 64 + tid] = (int8_t)quant1(d, k, noise);
+        if (tid == 0) sr[rb] = mx;
+    }
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int clv8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream)
+{
+    CLV_REQUIRE(x && q && s, "clv8_quantize: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv8_quantize: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    if (!n_pad) return CLV_OK;
+    hipStream_t st = as_stream(stream);
+    if (!rng_state_dev) {
+        const uint64_t nquads = n_pad / 4, waves = (nquads + 64 * V8_LOADS - 1) / (64 * V8_LOADS);
+        hipLaunchKernelGGL(k_v8_quantize, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const f32x4 *)x, (uint32_t *)q, s, nquads);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
+    RngTables T;
+    int rc = clv_rng_tables(&T);
+    if (rc) return rc;
+    const uint64_t nb = n_pad / 64;
+    const uint64_t seq = clv_rng_next_seq();
+#define Q8_LAUNCH(S)                                                                                                           \
+    hipLaunchKernelGGL(k_v8_quantize_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const f32x4 *)x, \
+                       (u32x2 *)q, s, nb, rng_state_dev, seq, T)
+    switch (clv_st_segments(nb)) {
+    case 1: Q8_LAUNCH(1); break;
+    case 4: Q8_LAUNCH(4); break;
+    default: Q8_LAUNCH(16); break;
+    }
+#undef Q8_LAUNCH
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clv8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, void *stream)
+{
+    CLV_REQUIRE(x && q && s, "clv8_restore: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv8_restore: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    if (!n_pad) return CLV_OK;
+    const uint64_t nquads = n_pad / 4, waves = (nquads + 255) / 256;
+    if (n_pad * sizeof(float) > (256ull << 20))
+        hipLaunchKernelGGL(k_v8_restore<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), (const uint32_t *)q, s,
+                           (f32x4 *)x, nquads);
+    else
+        hipLaunchKernelGGL(k_v8_restore<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), (const uint32_t *)q, s,
+                           (f32x4 *)x, nquads);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d,
+                       int8_t *r, float *sr, uint64_t *rng, hipStream_t st)
+{
+    const size_t lds = MVM8_CHUNK + (MVM8_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 128;
+    const dim3 grid((unsigned)(rows / 64)), block(256);
+    RngTables T = {nullptr, nullptr};
+    uint64_t seq = 0;
+    if (rng) {
+        int rc = clv_rng_tables(&T);
+        if (rc) return rc;
+        seq = clv_rng_next_seq();
+    }
+    const bool streaming = rows * (cols / 2) > (256ull << 20);
+#define M8_LAUNCH(NT, ST)                                                                                                              \
+    hipLaunchKernelGGL((k_m4_mvm8<8, NT, ST>), grid, block, lds, st, (const uint8_t *)A, sA, cols, x, sx, d, r, sr, rng, seq, T.pow_rows)
+    if (streaming) {
+        if (rng) M8_LAUNCH(true, true); else M8_LAUNCH(true, false);
+    } else {
+        if (rng) M8_LAUNCH(false, true); else M8_LAUNCH(false, false);
+    }
+#undef M8_LAUNCH
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+static int check_mvm8_args(const char *fn, const void *A, const void *sA, uint64_t rows, uint64_t cols, const void *x, const void *sx)
+{
+    CLV_REQUIRE(A && sA && x && sx, "%s: null pointer", fn);
+    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "%s: rows=%llu cols=%llu must be multiples of 128", fn, (unsigned long long)rows,
+                (unsigned long long)cols);
+    CLV_REQUIRE(rows / 64 <= 0x7FFFFFFFull, "%s: too many rows", fn);
+    return CLV_OK;
+}
+
+extern "C" int clm4_mvm_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, int8_t *r,
+                           float *sr, uint64_t *rng_state_dev, void *stream)
+{
+    int rc = check_mvm8_args("clm4_mvm_v8", A, sA, rows, cols, x, sx);
+    if (rc) return rc;
+    CLV_REQUIRE(r && sr, "clm4_mvm_v8: null result pointer");
+    if (!rows) return CLV_OK;
+    return launch_mvm8(A, sA, rows, cols, x, sx, nullptr, r, sr, rng_state_dev, as_stream(stream));
+}
+
+extern "C" int clm4_rowdots_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d,
+                               void *stream)
+{
+    int rc = check_mvm8_args("clm4_rowdots_v8", A, sA, rows, cols, x, sx);
+    if (rc) return rc;
+    CLV_REQUIRE(d, "clm4_rowdots_v8: null result pointer");
+    if (!rows) return CLV_OK;
+    return launch_mvm8(A, sA, rows, cols, x, sx, d, nullptr, nullptr, nullptr, as_stream(stream));
+}

@@ -56,6 +56,10 @@ SIGNATURES = {
     "clm4_gemm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
     "clv4_scale_and_add": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _u64, _vp, _vp, _vp, _vp]),
     "clm4_mvm_scale_and_add": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clv8_quantize": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
+    "clv8_restore": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "clm4_mvm_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clm4_rowdots_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clv4_threshold_workspace_bytes": (_u64, [_u64]),
     "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "clm4_transpose": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
@@ -249,6 +253,32 @@ class CloverHip:
                                                    rng.ptr if rng else None, None))
         t = (dt.download(np.uint8, rows // 2), dst.download(np.float32, rows // 64)) if want_t else (None, None)
         return t[0], t[1], dr.download(np.uint8, rows // 2), dsr.download(np.float32, rows // 64)
+
+    # -- mixed precision (CloverVector8) ----------------------------------------------------------
+    def v8_quantize(self, x: np.ndarray, rng: DevBuf | None = None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size
+        dx, dq, ds = self.to_device(x), self.alloc(max(n, 1)), self.alloc(max(n // 16, 4))
+        self.check(self.lib.clv8_quantize(dx.ptr, n, dq.ptr, ds.ptr, rng.ptr if rng else None, None))
+        return dq.download(np.int8, n), ds.download(np.float32, n // 64)
+
+    def v8_restore(self, q, s) -> np.ndarray:
+        n = q.size
+        dq, ds, dx = self.to_device(q), self.to_device(s), self.alloc(max(4 * n, 4))
+        self.check(self.lib.clv8_restore(dq.ptr, ds.ptr, n, dx.ptr, None))
+        return dx.download(np.float32, n)
+
+    def m4_mvm_v8(self, qA, sA, rows, cols, qx, sx, rng: DevBuf | None = None):
+        b = [self.to_device(a) for a in (qA, sA, qx, sx)]
+        dr, dsr = self.alloc(max(rows, 1)), self.alloc(max(rows // 16, 4))
+        self.check(self.lib.clm4_mvm_v8(b[0].ptr, b[1].ptr, rows, cols, b[2].ptr, b[3].ptr, dr.ptr, dsr.ptr, rng.ptr if rng else None, None))
+        return dr.download(np.int8, rows), dsr.download(np.float32, rows // 64)
+
+    def m4_rowdots_v8(self, qA, sA, rows, cols, qx, sx) -> np.ndarray:
+        b = [self.to_device(a) for a in (qA, sA, qx, sx)]
+        d = self.alloc(max(rows * 4, 4))
+        self.check(self.lib.clm4_rowdots_v8(b[0].ptr, b[1].ptr, rows, cols, b[2].ptr, b[3].ptr, d.ptr, None))
+        return d.download(np.float32, rows)
 
     def v4_threshold(self, q, s, n: int, k: int) -> np.ndarray:
         dq, ds = self.to_device(q), self.to_device(s)

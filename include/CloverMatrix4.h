@@ -19,6 +19,7 @@
 
 #include "CloverMatrix32.h"
 #include "CloverVector4.h"
+#include "CloverVector8.h"
 
 class CloverMatrix4 {
 protected:
@@ -126,6 +127,20 @@ public:
         u.scaleAndAdd(t, a);
 #endif
     }
+
+    /* mixed precision: 8-bit vector in, 8-bit vector out (CloverMatrix4.h:1093-1441; _parallel :2017-2387; _scalar :402-413) */
+    void mvm(const CloverVector8 &productVector, CloverVector8 &resultVector)
+    {
+        if (productVector.size() != getCols() || resultVector.size_pad() != getRows()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        clover_hip::check(clm4_mvm_v8(dev_values(), dev_scales(), rows, cols, productVector.dev_values_ro(), productVector.dev_scales_ro(),
+                                      resultVector.dev_values_wo(), resultVector.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
+                          "CloverMatrix4::mvm");
+    }
+    void mvm_parallel(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
+    void mvm_scalar(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
 
     /* mixed precision: fp32 vector in, fp32 vector out (CloverMatrix4.h:1451-1547; _parallel :2397-2505) */
     void mvm(const CloverVector32 &productVector, CloverVector32 &resultVector)

@@ -1,0 +1,144 @@
+/*
+ * CloverVector8.h -- 8-bit quantized vector, MI355X-backed: the operand type of the mixed-precision
+ * CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &).
+ *
+ * Same class name, constructors, data format and element accessors as the reference's include/CloverVector8.h
+ * (int8 values in natural order, one fp32 absolute-max scale per 64 elements, value = q * scale / 127, values and
+ * scales in ONE allocation, :42-80), with
+ *
+ *   quantize / quantize_parallel / quantize_scalar  -> clv8_quantize  (CloverVector8.h:393-606, :607-833, :205-253)
+ *   restore / restore_scalar                        -> clv8_restore   (:835-909, :255-266)
+ *
+ * on the device.  The rest of the reference's 8-bit vector algebra (dot, scaleAndAdd, threshold: :911-1850) belongs to
+ * the 8-bit containers' own path and is not part of this backend.
+ */
+#ifndef CLOVER_VECTOR8_H
+#define CLOVER_VECTOR8_H
+
+#include "CloverVector32.h"
+
+class CloverVector8 {
+protected:
+    const uint64_t length;
+    const uint64_t length_pad;
+    mutable clover_hip::Mirror mem;            /* [length_pad value bytes][scales] */
+    mutable clover_hip::RandomState random;
+    uint64_t value_bytes;
+    mutable clover_hip::Mirror view_scales;    /* non-owning view: two unrelated pointers */
+    bool split_view;
+
+    void allocate()
+    {
+        const uint64_t blocks = length_pad / CLOVER_VECTOR_BLOCK;
+        const uint64_t blocks_pad = clover_hip::round_up(blocks, CLOVER_VECTOR_BLOCK);
+        value_bytes = length_pad;
+        mem.allocate(value_bytes + blocks_pad * sizeof(float));
+        split_view = false;
+        int8_t *v = reinterpret_cast<int8_t *>(mem.host_rw());
+        float *s = reinterpret_cast<float *>(v + value_bytes);
+        for (uint64_t i = length; i < length_pad; i++) v[i] = 0;                /* zeroed value padding  */
+        for (uint64_t i = length / 64; i < blocks; i++) s[i] = 1;               /* padding scales = 1.0  */
+    }
+
+public:
+    explicit CloverVector8(uint64_t s) : length(s), length_pad(clover_hip::round_up(s, CLOVER_VECTOR_SIZE_PAD)) { allocate(); }
+
+    /* non-owning view (CloverVector8.h:84-89) */
+    CloverVector8(uint64_t s, int8_t *data_values, float *data_scales)
+        : length(s), length_pad(clover_hip::round_up(s, CLOVER_VECTOR_SIZE_PAD))
+    {
+        value_bytes = length_pad;
+        mem.adopt(data_values, value_bytes);
+        view_scales.adopt(data_scales, (length_pad / 64) * sizeof(float));
+        split_view = true;
+    }
+
+    explicit CloverVector8(const CloverVector32 &other) : length(other.size()), length_pad(other.size_pad())
+    {
+        allocate();
+        quantize(other);
+    }
+
+    CloverVector8(const CloverVector8 &other) : length(other.length), length_pad(other.length_pad)
+    {
+        allocate();
+        memcpy(getData(), other.values_ro(), value_bytes);
+        memcpy(getScales(), other.scales_ro(), (length_pad / 64) * sizeof(float));
+    }
+
+    uint64_t size() const { return length; }
+    uint64_t size_pad() const { return length_pad; }
+    uint64_t getBitsLength() const { return 8; }
+    uint64_t getBytes() const { return length_pad + (length_pad / 64) * sizeof(float); }
+
+    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
+    float *getScales() const
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.host_rw());
+        return reinterpret_cast<float *>(mem.host_rw() + value_bytes);
+    }
+
+    /* CloverVector8.h:137-140 */
+    float get(uint64_t i) const { return values_ro()[i] * scales_ro()[i >> 6] / 127.0f; }
+    int8_t getBits(uint64_t i) const { return values_ro()[i]; }
+    void setBits(uint64_t i, int8_t bits) { getData()[i] = bits; }
+    void clear()
+    {
+        memset(getData(), 0, value_bytes);
+        float *s = getScales();
+        for (uint64_t b = 0; b < length_pad / 64; b++) s[b] = 1.0f;
+    }
+    std::string toString() const
+    {
+        std::stringstream sout;
+        for (uint64_t i = 0; i < length_pad; i++)
+            sout << std::setw(10) << i << " | " << std::setw(20) << std::fixed << std::setprecision(7) << get(i) << " | " << std::setw(20)
+                 << scales_ro()[i >> 6] << " | " << std::setw(5) << (int)values_ro()[i] << std::endl;
+        return sout.str();
+    }
+
+    void setRandomKeys(const uint64_t key1[4], const uint64_t key2[4]) { random.set(key1, key2); }
+    void seedRandomKeys(uint64_t key1, uint64_t key2) { random.seed(key1, key2); }
+
+    void quantize(const CloverVector32 &other)
+    {
+        if (other.size_pad() != length_pad) {
+            std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        clover_hip::check(clv8_quantize(other.device_ro(), length_pad, dev_values_wo(), dev_scales_wo(), clover_hip::rng_or_null(random),
+                                        nullptr), "CloverVector8::quantize");
+    }
+    void quantize_parallel(const CloverVector32 &other) { quantize(other); }
+    void quantize_scalar(const CloverVector32 &other) { quantize(other); }
+
+    void restore(CloverVector32 &other) const
+    {
+        clover_hip::check(clv8_restore(dev_values_ro(), dev_scales_ro(), length_pad, other.device_wo(), nullptr), "CloverVector8::restore");
+    }
+    void restore_scalar(CloverVector32 &other) const { restore(other); }
+
+    /* ---- device views, used by CloverMatrix4 ------------------------------------------------------ */
+    const int8_t *dev_values_ro() const { return reinterpret_cast<const int8_t *>(mem.dev_ro()); }
+    const float *dev_scales_ro() const
+    {
+        if (split_view) return reinterpret_cast<const float *>(view_scales.dev_ro());
+        return reinterpret_cast<const float *>(mem.dev_ro() + value_bytes);
+    }
+    int8_t *dev_values_wo() { return reinterpret_cast<int8_t *>(mem.dev_wo()); }
+    float *dev_scales_wo()
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.dev_wo());
+        return reinterpret_cast<float *>(mem.dev_wo() + value_bytes);
+    }
+
+private:
+    const int8_t *values_ro() const { return reinterpret_cast<const int8_t *>(mem.host_ro()); }
+    const float *scales_ro() const
+    {
+        if (split_view) return reinterpret_cast<const float *>(view_scales.host_ro());
+        return reinterpret_cast<const float *>(mem.host_ro() + value_bytes);
+    }
+};
+
+#endif

@@ -132,6 +132,20 @@ int  clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, con
 int  clm4_mvm_scale_and_add(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
                             const int8_t *qu, const float *su, float a, int8_t *t, float *st, int8_t *r, float *sr,
                             uint64_t *rng_state_dev, void *stream);
+/* ---- mixed precision: 4-bit matrix x 8-bit vector --------------------------------------------- */
+/* CloverVector8 (CloverVector8.h:35-140): n_pad int8 values in natural order + n_pad/64 fp32 scales, value = q*scale/127.
+ * clv8_quantize = CloverVector8::quantize (:393-606), clv8_restore = ::restore (:835-909); bit-identical, and with an
+ * rng the same XORShift stream positions and lane map as the reference (two draws per 64-block). */
+int  clv8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream);
+int  clv8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, void *stream);
+/* CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &) (CloverMatrix4.h:1093-1441; _parallel :2017-2387):
+ * x: cols int8 + cols/64 scales; r: rows int8 + rows/64 scales (re-quantised to 8 bits).  Bit-identical to the
+ * reference's SIMD path (8 fp32 fma chains per row) for either rounding mode. */
+int  clm4_mvm_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                 int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
+/* the fp32 row dots of that mvm before re-quantisation: d[rows] (CloverMatrix4.h:1120-1243) */
+int  clm4_rowdots_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                     float *d, void *stream);
 /* CloverVector4::threshold(K) (CloverVector4.h:1913-2060): keep the K largest |value| among the first n
  * elements, zero the other nibbles in place.  The surviving multiset of magnitudes equals the reference's;
  * among EQUAL magnitudes the lowest indices survive (the reference's choice depends on its heap order). */

@@ -142,6 +142,33 @@ class Oracle:
         self.L.orc_m4_mvm_f32(_p(qA, _u8p), _p(sA, _fp), _u64(rows), _u64(cols), _p(x, _fp), _p(r, _fp))
         return r
 
+    # -- mixed precision: CloverVector8 -------------------------------------------------------------
+    def v8_quantize(self, x: np.ndarray, rng: OrcRng | None = None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size
+        q = np.zeros(n, np.int8)
+        s = np.zeros(n // 64, np.float32)
+        self.L.orc_v8_quantize(_p(x, _fp), _u64(n), _p(q, C.POINTER(C.c_int8)), _p(s, _fp), C.byref(rng) if rng is not None else None)
+        return q, s
+
+    def v8_restore(self, q, s) -> np.ndarray:
+        x = np.zeros(q.size, np.float32)
+        self.L.orc_v8_restore(_p(q, C.POINTER(C.c_int8)), _p(s, _fp), _u64(q.size), _p(x, _fp))
+        return x
+
+    def m4_rowdots_v8(self, qA, sA, rows, cols, qx, sx, f64: bool = False) -> np.ndarray:
+        d = np.zeros(rows, np.float32)
+        fn = self.L.orc_m4_rowdots_v8_f64 if f64 else self.L.orc_m4_rowdots_v8
+        fn(_p(qA, _u8p), _p(sA, _fp), _u64(rows), _u64(cols), _p(qx, C.POINTER(C.c_int8)), _p(sx, _fp), _p(d, _fp))
+        return d
+
+    def m4_mvm_v8(self, qA, sA, rows, cols, qx, sx, rng: OrcRng | None = None):
+        r = np.zeros(rows, np.int8)
+        sr = np.zeros(rows // 64, np.float32)
+        self.L.orc_m4_mvm_v8(_p(qA, _u8p), _p(sA, _fp), _u64(rows), _u64(cols), _p(qx, C.POINTER(C.c_int8)), _p(sx, _fp),
+                             _p(r, C.POINTER(C.c_int8)), _p(sr, _fp), C.byref(rng) if rng is not None else None)
+        return r, sr
+
     def m4_gemm(self, qA, sA, M, K, qB, sB, N) -> np.ndarray:
         c = np.zeros(M * N, np.float32)
         self.L.orc_m4_gemm(_p(qA, _u8p), _p(sA, _fp), _u64(M), _u64(K), _p(qB, _u8p), _p(sB, _fp), _u64(N), _p(c, _fp))

@@ -497,6 +497,106 @@ void orc_m4_mvm_f32(const uint8_t *A, const float *sA, uint64_t rows, uint64_t c
 
 /* ------------------------------------------------------------------------------------------------ */
 /* GEMM (build-defined; see header)                                                                  */
+/* ================================================================================================
+ * mixed precision: CloverMatrix4 x CloverVector8
+ * ================================================================================================ */
+static void quant8_block64(const float *x, float k, const float *noise64, int8_t *q)
+{
+    for (int i = 0; i < 64; i++) q[i] = (int8_t)quant1(x[i], k, noise64 ? noise64[i] : 0.0f);     /* low byte, as the packing keeps it */
+}
+
+void orc_v8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, orc_rng *rng)
+{
+    const uint64_t nb = n_pad / 64;
+    for (uint64_t b = 0; b < nb; b++) {
+        const float *xb = x + 64 * b;
+        float m = 0.0f;
+        for (int i = 0; i < 64; i++) { const float a = fabsf(xb[i]); if (a > m) m = a; }
+        m = fix_zero_max(m);
+        s[b] = m;
+        const float k = 127.0f / m;                              /* CloverVector8.h:455 */
+        if (rng) {
+            float nz[8][8], flat[64];
+            orc_rng_block_noise(rng, nz);
+            for (int g = 0; g < 8; g++) for (int j = 0; j < 8; j++) flat[8 * g + j] = nz[g][j];     /* rnd_(g+1) meets u_(g+1) (:546-553) */
+            quant8_block64(xb, k, flat, q + 64 * b);
+        } else {
+            quant8_block64(xb, k, 0, q + 64 * b);
+        }
+    }
+}
+
+void orc_v8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x)
+{
+    for (uint64_t i = 0; i < n_pad; i++) x[i] = (float)q[i] * (s[i >> 6] / 127.0f);
+}
+
+static float dot_v8_simd_order(const uint8_t *arow, const float *sa, const int8_t *x, const float *sx, uint64_t hb)
+{
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t b = 0; b < hb; b++) {
+        const float su_scaled = sa[b] * (1.0f / 7.0f);           /* CloverMatrix4.h:1147-1149 */
+        const float sv_scaled = sx[b] * (1.0f / 127.0f);
+        const float c = su_scaled * sv_scaled;
+        const uint8_t *ab = arow + 32 * b;
+        const int8_t *xb = x + 64 * b;
+        for (int L = 0; L < 8; L++) {
+            int32_t I = 0;
+            for (int e = 4 * L; e < 4 * L + 4; e++) {
+                const int lo = (e & 1) ? nib_lo(ab[e >> 1]) : nib_hi(ab[e >> 1]);
+                const int e2 = 32 + e;
+                const int hi = (e2 & 1) ? nib_lo(ab[e2 >> 1]) : nib_hi(ab[e2 >> 1]);
+                I += lo * (int)xb[e] + hi * (int)xb[e2];
+            }
+            acc[L] = fmaf(c, (float)I, acc[L]);                  /* :1224 */
+        }
+    }
+    /* :1229-1234: (hi128 + lo128), then + movehl, then lanes 0 + 1 */
+    const float h0 = acc[4] + acc[0], h1 = acc[5] + acc[1], h2 = acc[6] + acc[2], h3 = acc[7] + acc[3];
+    return (h0 + h2) + (h1 + h3);
+}
+
+void orc_m4_rowdots_v8(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d)
+{
+    const uint64_t hb = cols >> 6;
+    for (uint64_t i = 0; i < rows; i++) d[i] = dot_v8_simd_order(A + i * (cols / 2), sA + (i >> 6) * hb, x, sx, hb);
+}
+
+void orc_m4_mvm_v8(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                   int8_t *r, float *sr, orc_rng *rng)
+{
+    const uint64_t hb = cols >> 6;
+    for (uint64_t i = 0; i < rows; i += 64) {
+        float d[64];
+        for (int k = 0; k < 64; k++) d[k] = dot_v8_simd_order(A + (i + k) * (cols / 2), sA + (i >> 6) * hb, x, sx, hb);
+        float m = 0.0f;
+        for (int k = 0; k < 64; k++) { const float a = fabsf(d[k]); if (a > m) m = a; }
+        m = fix_zero_max(m);
+        sr[i >> 6] = m;
+        const float kq = 127.0f / m;
+        if (rng) {
+            float nz[8][8], flat[64];
+            orc_rng_block_noise(rng, nz);
+            for (int g = 0; g < 8; g++) for (int j = 0; j < 8; j++) flat[8 * g + j] = nz[g][j];     /* rnd_(g+1) meets u_(g+1) = rows 8g.. (:1381-1388) */
+            quant8_block64(d, kq, flat, r + i);
+        } else {
+            quant8_block64(d, kq, 0, r + i);
+        }
+    }
+}
+
+void orc_m4_rowdots_v8_f64(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d)
+{
+    for (uint64_t i = 0; i < rows; i++) {
+        double sum = 0;
+        for (uint64_t j = 0; j < cols; j++) {
+            const float xv = (float)x[j] * sx[j >> 6] / 127.0f;           /* CloverVector8::get (:137-140): q * scale / 127 */
+            sum += (double)orc_m4_get(A, sA, rows, cols, i, j) * (double)xv;
+        }
+        d[i] = (float)sum;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 
 static inline int32_t block_isum(const uint8_t *u, const uint8_t *v)

@@ -86,6 +86,25 @@ void     orc_v4_threshold(uint8_t *q, const float *s, uint64_t n, uint64_t k);
  * then (acc1+acc2)+(acc3+acc4) per lane and the CloverBase.h:149-157 tree. */
 void     orc_m4_mvm_f32(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const float *x, float *r);
 
+/* ---- mixed precision, 4-bit matrix x 8-bit vector ---------------------------------------------
+ * CloverVector8 (CloverVector8.h:35-140): int8 values in natural order + one fp32 scale per 64 elements,
+ * value = q * scale / 127. */
+/* CloverVector8::quantize (CloverVector8.h:393-606; scalar :205-253): block max (0 -> 1.0), k = 127/max,
+ * q = sign(x) * trunc(fma(|x|, k, noise)); noise group g = element/8 (draw g>>2, byte g&3), word W[element%8] */
+void     orc_v8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, orc_rng *rng);
+/* CloverVector8::restore (CloverVector8.h:835-909): x = (float)q * (scale / 127.0f) */
+void     orc_v8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x);
+/* fp32 row dots of CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &) (CloverMatrix4.h:1093-1243) in SIMD order:
+ * 8 fp32 fma chains per row (chain L = elements 4L..4L+3 and 32+4L..32+4L+3 of every 64-block),
+ * c_b = f32(f32(sA*1/7) * f32(sx*1/127)), chain += c_b * (float)I exactly-summed, then ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) */
+void     orc_m4_rowdots_v8(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d);
+/* the whole mixed mvm: row dots, then 64 at a time re-quantised to 8 bits (CloverMatrix4.h:1246-1440);
+ * noise group g, word j lands on output row 8g + j */
+void     orc_m4_mvm_v8(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                       int8_t *r, float *sr, orc_rng *rng);
+/* mvm_scalar(CloverVector8) (CloverMatrix4.h:402-413): double accumulation of get(i,j) * x.get(j), cast to float */
+void     orc_m4_rowdots_v8_f64(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d);
+
 /*
  * GEMM -- no reference function exists; build-defined semantics:
  *   A is M x K, B is N x K (both CloverMatrix4 layouts), C = A * B^T, fp32, row-major M x N.

@@ -83,6 +83,24 @@ int main()
         qA.gemm(qA, C);
         printf("gemm_c00=0x%08x gemm_c_1_77=0x%08x\n", bits(C.get(0, 0)), bits(C.get(1, 77)));
     }
+    // ---- mixed precision: 4-bit matrix x 8-bit vector, KAT3's operands ------------------------
+    {
+        const int M = 128, N = 256;
+        CloverMatrix32 A(M, N);
+        CloverVector32 x(N), back(N);
+        for (int r = 0; r < M; r++)
+            for (int c = 0; c < N; c++) A.set(r, c, (float)(((31 * r + 17 * c) % 23) - 11));
+        for (int c = 0; c < N; c++) x.set(c, (float)(((13 * c) % 19) - 9) * 0.37f);
+        CloverMatrix4 qA(M, N);
+        qA.quantize(A);
+        CloverVector8 x8(x), r8(M);
+        qA.mvm(x8, r8);
+        hexdump("mixed_x8", x8.getData(), 64);
+        hexdump("mixed_r8", r8.getData(), 128);
+        printf("mixed_scales=0x%08x,0x%08x bytes8=%llu\n", bits(r8.getScales()[0]), bits(r8.getScales()[1]), (unsigned long long)x8.getBytes());
+        x8.restore(back);
+        printf("mixed_restore=0x%08x,0x%08x get=0x%08x\n", bits(back.get(1)), bits(back.get(255)), bits(x8.get(1)));
+    }
     // ---- next rows: one quantized IHT-style iteration, everything device-resident ------------------------
     {
         const int M = 256, N = 512, K = 32;

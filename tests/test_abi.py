@@ -11,13 +11,13 @@ from clover_amd.lib_binding import SIGNATURES, load_library
 def declared_symbols():
     text = (repo_root() / "include" / "clover_hip.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cl[vm]4?_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(cl[vm][48]?_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_expected_surface():
     syms = declared_symbols()
     for must in ("clv4_quantize", "clv4_restore", "clv4_dot", "clm4_quantize", "clm4_mvm", "clm4_gemm",
-                 "clv_last_error", "clv_malloc", "clv_rng_seed"):
+                 "clv_last_error", "clv_malloc", "clv_rng_seed", "clv8_quantize", "clm4_mvm_v8"):
         assert must in syms
 
 

@@ -26,7 +26,7 @@ def compile_example(out: Path, extra=()):
 def test_dropin_example_compiles_and_links(tmp_path):
     # host language of the reference is C++11 (CMakeLists.txt:44-76); the headers must build with it
     compile_example(tmp_path / "dropin")
-    for hdr in ("CloverVector32.h", "CloverVector4.h", "CloverMatrix32.h", "CloverMatrix4.h"):
+    for hdr in ("CloverVector32.h", "CloverVector4.h", "CloverVector8.h", "CloverMatrix32.h", "CloverMatrix4.h", "CloverIHT.h"):
         subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", f"-I{ROOT / 'include'}", str(ROOT / "include" / hdr)], check=True)
 
 
@@ -51,6 +51,17 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
     assert kv["kat3_r"] == KAT["KAT3"]["r_bytes_0_63"] and kv["kat3_r_parallel"] == KAT["KAT3"]["r_bytes_0_63"]
     assert kv["kat3_scales"].split(",") == KAT["KAT3"]["r_scale_bits"]
     np.testing.assert_allclose([float(v) for v in kv["kat3_get"].split(",")], KAT["KAT3"]["qA_get_0_0_3"], atol=1e-5)
+    # mixed precision: CloverVector8 + CloverMatrix4::mvm(CloverVector8, CloverVector8) against the oracle
+    A3, _ = kat3_inputs()
+    x3 = np.array([np.float32(float(((13 * c) % 19) - 9)) * np.float32(0.37) for c in range(256)], np.float32)
+    q4, s4 = oracle.m4_quantize(A3)
+    qx8, sx8 = oracle.v8_quantize(x3)
+    r8, sr8 = oracle.m4_mvm_v8(q4, s4, 128, 256, qx8, sx8)
+    assert kv["mixed_x8"] == qx8[:64].tobytes().hex() and kv["mixed_r8"] == r8.tobytes().hex()
+    assert [int(v, 16) for v in kv["mixed_scales"].split(",")] == [int(bits(sr8[0])), int(bits(sr8[1]))] and kv["bytes8"] == str(256 + 4 * 4)
+    back = oracle.v8_restore(qx8, sx8)
+    assert [int(v, 16) for v in kv["mixed_restore"].split(",")] == [int(bits(back[1])), int(bits(back[255]))]
+    assert int(kv["get"], 16) == int(bits(np.float32(np.float32(np.float32(qx8[1]) * sx8[0]) / np.float32(127.0))))
     # the IHT-style iteration built from the "next" rows
     assert kv["iht_transpose_ok"] == "1" and 0 < int(kv["iht_nonzeros"]) <= 32
     # Q_IHT / Q_GD (CloverIHT.h) against the same loops on the oracle.  Data = the C++ setRandomInteger streams.

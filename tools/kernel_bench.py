@@ -69,6 +69,9 @@ for logn in (24, 30):
     rec(f"dot_fast_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_FAST, out.ptr, None, None)))
     rec(f"scale_and_add_n2^{logn}", 1.6875 * n, lambda: hip.check(lib.clv4_scale_and_add(q.ptr, s.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, None, None)))
     rec(f"scale_and_add_stochastic_n2^{logn}", 1.6875 * n, lambda: hip.check(lib.clv4_scale_and_add(q.ptr, s.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, rng.ptr, None)))
+    q8 = hip.alloc(n)
+    rec(f"v8_quantize_n2^{logn}", 5.0625 * n, lambda: hip.check(lib.clv8_quantize(x.ptr, n, q8.ptr, s3.ptr, None, None)))
+    rec(f"v8_quantize_stochastic_n2^{logn}", 5.0625 * n, lambda: hip.check(lib.clv8_quantize(x.ptr, n, q8.ptr, s3.ptr, rng.ptr, None)))
     rec(f"restore_n2^{logn}", 4.5625 * n, lambda: hip.check(lib.clv4_restore(q.ptr, s.ptr, n, x.ptr, None)))
     if logn == 24:
         k = n // 4
@@ -76,7 +79,8 @@ for logn in (24, 30):
         rec(f"threshold_k25pct_n2^{logn}", 0.5625 * n * 5, lambda: hip.check(lib.clv4_threshold(q3.ptr, s.ptr, n, n, k, None, None)), reps=3,
             extra={"note": "5 passes over nibbles+scales (3 histogram, tie count, apply) + 4 tiny kernels"})
         rec(f"dot_exact_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2)
-    del x, q, s, q2, s2, q3, s3
+    rec(f"v8_restore_n2^{logn}", 5.0625 * n, lambda: hip.check(lib.clv8_restore(q8.ptr, s3.ptr, n, x.ptr, None)))
+    del x, q, s, q2, s2, q3, s3, q8
 
 # ---- matrix ops: 32768 x 32768 (4 GiB fp32 source, 512 MiB quantized)
 M = N = 32768
@@ -95,4 +99,10 @@ hip.check(lib.clv_fill_random_scales(sx.ptr, sx.nbytes // 4, 10, 0, None))
 mvb = M * N // 2 + 4 * (M // 64) * (N // 64) + (N // 2 + N // 16) + (M // 2 + M // 16)
 rec("mvm_32768^2", mvb, lambda: hip.check(lib.clm4_mvm(qA.ptr, sA.ptr, M, N, x.ptr, sx.ptr, r.ptr, sr.ptr, None, None)))
 rec("mvm_stochastic_32768^2", mvb, lambda: hip.check(lib.clm4_mvm(qA.ptr, sA.ptr, M, N, x.ptr, sx.ptr, r.ptr, sr.ptr, rngm.ptr, None)))
+# ---- mixed precision: 4-bit matrix x 8-bit vector
+x8, r8 = hip.alloc(N), hip.alloc(M)
+hip.check(lib.clv_fill_random_nibbles(x8.ptr, x8.nbytes, 11, 0, None))          # any bytes; 0x80 never occurs (nibbles are in [-7,7])
+mvb8 = M * N // 2 + 4 * (M // 64) * (N // 64) + (N + N // 16) + (M + M // 16)
+rec("mvm_v8_32768^2", mvb8, lambda: hip.check(lib.clm4_mvm_v8(qA.ptr, sA.ptr, M, N, x8.ptr, sx.ptr, r8.ptr, sr.ptr, None, None)))
+rec("mvm_v8_stochastic_32768^2", mvb8, lambda: hip.check(lib.clm4_mvm_v8(qA.ptr, sA.ptr, M, N, x8.ptr, sx.ptr, r8.ptr, sr.ptr, rngm.ptr, None)))
 print(json.dumps(res, indent=1))
