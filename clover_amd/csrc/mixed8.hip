@@ -189,7 +189,7 @@ __device__ __forceinline__ void mvm8_block(uint32_t w_first, uint32_t w_second, 
 }
 
 template <int U, bool NT, bool ST>
-__global__ __launch_bounds__(256) void k_m4_mvm8(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
+__global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
                                                  const int8_t *__restrict__ x, const float *__restrict__ sx, float *__restrict__ d_out,
                                                  int8_t *__restrict__ r, float *__restrict__ sr, uint64_t *rng_state, uint64_t seq,
                                                  const uint64_t *__restrict__ pow_rows)

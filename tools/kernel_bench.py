@@ -105,4 +105,20 @@ hip.check(lib.clv_fill_random_nibbles(x8.ptr, x8.nbytes, 11, 0, None))          
 mvb8 = M * N // 2 + 4 * (M // 64) * (N // 64) + (N + N // 16) + (M + M // 16)
 rec("mvm_v8_32768^2", mvb8, lambda: hip.check(lib.clm4_mvm_v8(qA.ptr, sA.ptr, M, N, x8.ptr, sx.ptr, r8.ptr, sr.ptr, None, None)))
 rec("mvm_v8_stochastic_32768^2", mvb8, lambda: hip.check(lib.clm4_mvm_v8(qA.ptr, sA.ptr, M, N, x8.ptr, sx.ptr, r8.ptr, sr.ptr, rngm.ptr, None)))
+# ---- the headline shape, 65536 x 65536 (2 GiB of nibbles): 4-bit and mixed mvm side by side
+del A, qT, sT
+M2 = N2 = 65536
+big, sbig = hip.alloc(M2 * N2 // 2), hip.alloc((M2 // 64) * (N2 // 64) * 4)
+hip.check(lib.clv_fill_random_nibbles(big.ptr, big.nbytes, 21, 0, None))
+hip.check(lib.clv_fill_random_scales(sbig.ptr, sbig.nbytes // 4, 22, 0, None))
+xb4, xb8, sxb = hip.alloc(N2 // 2), hip.alloc(N2), hip.alloc(N2 // 16)
+rb, srb = hip.alloc(M2), hip.alloc(M2 // 16)
+hip.check(lib.clv_fill_random_nibbles(xb8.ptr, xb8.nbytes, 23, 0, None))
+hip.check(lib.clv_fill_random_nibbles(xb4.ptr, xb4.nbytes, 24, 0, None))
+hip.check(lib.clv_fill_random_scales(sxb.ptr, sxb.nbytes // 4, 25, 0, None))
+base = M2 * N2 // 2 + 4 * (M2 // 64) * (N2 // 64)
+rec("mvm_65536^2", base + (N2 // 2 + N2 // 16) + (M2 // 2 + M2 // 16),
+    lambda: hip.check(lib.clm4_mvm(big.ptr, sbig.ptr, M2, N2, xb4.ptr, sxb.ptr, rb.ptr, srb.ptr, None, None)))
+rec("mvm_v8_65536^2", base + (N2 + N2 // 16) + (M2 + M2 // 16),
+    lambda: hip.check(lib.clm4_mvm_v8(big.ptr, sbig.ptr, M2, N2, xb8.ptr, sxb.ptr, rb.ptr, srb.ptr, None, None)))
 print(json.dumps(res, indent=1))
