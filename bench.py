@@ -388,12 +388,37 @@ def extras(hip, torch, dev, stream) -> dict:
         iht_call()
     g_ms = (time.perf_counter() - t0) / 3 / 100 * 1e3
     hip.check(lib.clv_stream_destroy(side))
+    # the reference's published "4-bit" IHT: CloverMatrix4 with CloverVector8 vectors (02_bit04.cpp:140), whole loop from C++
+    def vec8(n_, sd):
+        qv_ = torch.empty(n_, dtype=torch.uint8, device=dev)
+        sv_ = torch.empty(n_ // 64, dtype=torch.float32, device=dev)
+        hip.check(lib.clv_fill_random_nibbles(qv_.data_ptr(), qv_.numel(), sd, 0, stream))
+        hip.check(lib.clv_fill_random_scales(sv_.data_ptr(), sv_.numel(), sd + 1, 0, stream))
+        return qv_, sv_
+    (x8q, x8s), (y8q, y8s), (a8q, a8s), (b8q, b8s), (c8q, c8s) = vec8(nn, 61), vec8(m, 63), vec8(m, 65), vec8(m, 67), vec8(nn, 69)
+    side8 = C.c_void_p()
+    hip.check(lib.clv_stream_create(C.byref(side8)))
+
+    def iht8_call():
+        hip.check(lib.clm4_iht_v8(Phi.data_ptr(), sPhi.data_ptr(), PhiT.data_ptr(), sPhiT.data_ptr(), m, nn, x8q.data_ptr(), x8s.data_ptr(), nn,
+                                  y8q.data_ptr(), y8s.data_ptr(), a8q.data_ptr(), a8s.data_ptr(), b8q.data_ptr(), b8s.data_ptr(),
+                                  c8q.data_ptr(), c8s.data_ptr(), 100, m // 4, 1e-3, 1, None, side8))
+        hip.check(lib.clv_stream_sync(side8))
+    iht8_call()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        iht8_call()
+    g8_ms = (time.perf_counter() - t0) / 3 / 100 * 1e3
+    hip.check(lib.clv_stream_destroy(side8))
+    iht8_bytes = 2 * (m * nn // 2 + 4 * (m // 64) * (nn // 64)) + (2 * nn + 3 * m) * 17 // 16
     iht_bytes = 2 * (m * nn // 2 + 4 * (m // 64) * (nn // 64)) + (2 * nn + 3 * m) * 9 // 16
     iht = {"ms_per_iteration": round(i_ms, 5), "GB/s": round(iht_bytes / i_ms / 1e6, 1),
            "ms_per_iteration_stochastic": round(s_ms, 5), "GB/s_stochastic": round(iht_bytes / s_ms / 1e6, 1),
            "ms_per_iteration_clm4_iht": round(g_ms, 5), "GB/s_clm4_iht": round(iht_bytes / g_ms / 1e6, 1),
+           "ms_per_iteration_clm4_iht_v8": round(g8_ms, 5), "GB/s_clm4_iht_v8": round(iht8_bytes / g8_ms / 1e6, 1),
            "note": "Q_IHT step sequence (mvm, scaleAndAdd, mvm^T, scaleAndAdd, threshold) at N=8192 (4096x8192), bytes counted like "
-                   "01_measure.h:1117-1125; reference published 19.5 GB/s with 4 threads (performance.txt:581)"}
+                   "01_measure.h:1117-1125; _v8 = the published configuration (4-bit matrix, 8-bit vectors); reference published "
+                   "19.5 GB/s with 4 threads (performance.txt:581)"}
     return {
         "iht_iteration_N8192": iht,
         "gemm_8192^3": gemm,

@@ -131,6 +131,121 @@ __global__ __launch_bounds__(256) void k_v8_restore(const uint32_t *__restrict__
 }
 
 // =================================================================================================
+// CloverVector8::scaleAndAdd (CloverVector8.h:1063-1358): r = quantize8(u + a * v) per 64-block,
+//   val = fma((float)qv, f32(f32(sv*a)/127), (float)qu * f32(su/127)).  lane = 16 elements (one dwordx4 of u and of v), a block =
+//   4 lanes.  Algorithmic bytes: 3 * (1 + 1/16) per element.  r/sr may alias qu/su.
+// =================================================================================================
+__device__ __forceinline__ float byte_f(uint32_t w, int e) { return (float)((int)(w << (24 - 8 * e)) >> 24); }
+
+// the 16 values of one lane; returns their maximum magnitude
+__device__ __forceinline__ float saa8_values(const u32x4 wu, const u32x4 wv, float su_ps, float sv_ps, float v[16])
+{
+    const uint32_t U[4] = {wu.x, wu.y, wu.z, wu.w}, V[4] = {wv.x, wv.y, wv.z, wv.w};
+    float m = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float du = byte_f(U[d], e) * su_ps;
+            v[4 * d + e] = __builtin_fmaf(byte_f(V[d], e), sv_ps, du);
+            m = fmaxf(m, __builtin_fabsf(v[4 * d + e]));
+        }
+    return m;
+}
+
+// noise == nullptr <=> rounding disabled; noise[d] = the XORShift word whose byte e belongs to element 4d + e
+__device__ __forceinline__ u32x4 saa8_pack(const float v[16], float k, const uint32_t *noise)
+{
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int qv = noise ? quant1_st(v[4 * d + e], k, noise_of(noise[d], e)) : quant1_det(v[4 * d + e], k);
+            w |= ((uint32_t)qv & 0xFFu) << (8 * e);
+        }
+        o[d] = k < __builtin_inff() ? w : 0u;
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void k_v8_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
+                                                          const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nq16)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq16; i += stride) {
+        const uint64_t b = i >> 2;
+        const u32x4 wu = NT ? __builtin_nontemporal_load(qu + i) : qu[i];
+        const u32x4 wv = NT ? __builtin_nontemporal_load(qv + i) : qv[i];
+        float v[16];
+        float m = saa8_values(wu, wv, su[b] / 127.0f, (sv[b] * a) / 127.0f, v);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        m = fix_zero_max(m);
+        const u32x4 o = saa8_pack(v, 127.0f / m, nullptr);
+        if (NT) __builtin_nontemporal_store(o, r + i); else r[i] = o;
+        if ((i & 3) == 0) sr[b] = m;
+    }
+}
+
+// stochastic: the segment walk of the other vector kernels.  Element e of a block takes draw e>>5, byte e&3 of word (e&31)>>2
+// (CloverVector8.h:1104-1126, 1193-1229): lane c (= 16 elements) reads the four words W[4 (c & 1) ..] of draw c >> 1.
+template <int S>
+__global__ __launch_bounds__(256) void k_v8_scale_and_add_st(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
+                                                             const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nblocks,
+                                                             uint64_t *state, uint64_t seq, RngTables T)
+{
+    typedef StShape<S> Sh;
+    __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][Sh::NBR * 2 * 4];
+    __shared__ uint64_t base[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    SegRows<S> segs;
+    segs.load(T.seg_rows, wave * S);
+    rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
+    uint64_t *raw = raw_all[wave];
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
+    const int seg = lane >> 2, k = lane & 3, c = lane & 3;
+    uint64_t st = segs.starts(base);
+    constexpr int STEPS = Sh::NBR / 16 > 0 ? Sh::NBR / 16 : 1;           // 16 blocks (64 lanes x 16 elements) per step
+    for (int rr = 0; rr < Sh::ROUNDS; rr++) {
+        if (lane < 4 * S) st = gen_blocks(st, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+        __syncthreads();
+        u32x4 wu[STEPS], wv[STEPS];
+        float fu[STEPS], fv[STEPS];
+#pragma unroll
+        for (int u = 0; u < STEPS; u++) {                                 // loads of the round first (r may alias qu)
+            const int bl = 16 * u + (lane >> 2);
+            const uint64_t blk = bl < Sh::NBR ? Sh::block(blk0, rr, bl) : nblocks;
+            const uint64_t b = blk < nblocks ? blk : 0;
+            wu[u] = qu[b * 4 + c];
+            wv[u] = qv[b * 4 + c];
+            fu[u] = su[b];
+            fv[u] = sv[b];
+        }
+#pragma unroll
+        for (int u = 0; u < STEPS; u++) {
+            const int bl = 16 * u + (lane >> 2);
+            const uint64_t blk = bl < Sh::NBR ? Sh::block(blk0, rr, bl) : nblocks;
+            float v[16];
+            float m = saa8_values(wu[u], wv[u], fu[u] / 127.0f, (fv[u] * a) / 127.0f, v);
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fix_zero_max(m);
+            const u32x4 W = reinterpret_cast<const u32x4 *>(raw + (size_t)((bl < Sh::NBR ? bl : 0) * 2 + (c >> 1)) * 4)[c & 1];
+            const uint32_t Wn[4] = {W.x, W.y, W.z, W.w};
+            const u32x4 o = saa8_pack(v, 127.0f / m, Wn);
+            if (blk < nblocks) {
+                r[blk * 4 + c] = o;
+                if (c == 0) sr[blk] = m;
+            }
+        }
+        if (rr + 1 < Sh::ROUNDS) __syncthreads();
+    }
+}
+
+// =================================================================================================
 // CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &)  (CloverMatrix4.h:1093-1441)
 //
 // Arithmetic fixed by the reference: per row 8 sequential fp32 fma chains (the 8 AVX lanes of dot_product_acc); chain L
@@ -188,19 +303,42 @@ __device__ __forceinline__ void mvm8_block(uint32_t w_first, uint32_t w_second, 
     a_odd = __builtin_fmaf(c, (float)io, a_odd);
 }
 
-template <int U, bool NT, bool ST>
+// FUSE: the CloverVector8::scaleAndAdd that follows this mvm in the IHT / GD loops, done on the row group while it is still in
+// the wave: r2 = quantize8(u + a * quantize8(A x)); its draws follow ALL the mvm draws in the stream, as in two separate calls.
+struct Mvm8Fuse {
+    const int8_t *qu;        // u, one 64-element block per row group
+    const float *su;
+    float a;
+    int8_t *r2;              // may alias qu (the in-place overload)
+    float *sr2;
+};
+
+template <int U, bool NT, bool ST, bool FUSE>
 __global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
                                                  const int8_t *__restrict__ x, const float *__restrict__ sx, float *__restrict__ d_out,
-                                                 int8_t *__restrict__ r, float *__restrict__ sr, uint64_t *rng_state, uint64_t seq,
-                                                 const uint64_t *__restrict__ pow_rows)
+                                                 int8_t *r, float *sr, uint64_t *rng_state, uint64_t seq,
+                                                 const uint64_t *__restrict__ pow_rows, Mvm8Fuse fuse)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4 *xs = reinterpret_cast<u32x4 *>(smem);                         // MVM8_CHUNK bytes of int8
     float *cs = reinterpret_cast<float *>(smem + MVM8_CHUNK);            // MVM8_CHUNK/64 floats
     float *dsh = cs + MVM8_CHUNK / 64;                                   // 64 floats
-    uint64_t *rbase = reinterpret_cast<uint64_t *>(dsh + 64);            // ST: 4 lane bases, 8 raw draws
+    uint64_t *rbase = reinterpret_cast<uint64_t *>(dsh + 64);            // ST: 4 lane bases, 8 raw draws (twice with FUSE)
     uint64_t *raw = rbase + 4;
-    if (ST) rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, 2ull * gridDim.x, rbase);
+    uint64_t *rbase2 = raw + 8, *raw2 = rbase2 + 4;
+    if (ST) {
+        const uint64_t a0 = rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, (FUSE ? 4ull : 2ull) * gridDim.x, rbase);
+        if (FUSE) {
+            const uint64_t b2 = wave_pow_apply(pow_rows, a0, (uint64_t)gridDim.x + blockIdx.x, 1);
+            if ((threadIdx.x & 63) == 0) rbase2[threadIdx.x >> 6] = b2;
+        }
+    }
+    int fuse_q = 0;                                                     // FUSE: this row group's block of u, fetched early
+    float fuse_s = 0.0f;
+    if (FUSE && threadIdx.x < 64) {
+        fuse_q = fuse.qu[blockIdx.x * 64 + threadIdx.x];
+        fuse_s = fuse.su[blockIdx.x];
+    }
 
     const uint64_t rb = blockIdx.x;
     const int tid = threadIdx.x;
@@ -275,9 +413,12 @@ __global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ 
         dsh[rho] = dot;
         if (d_out) d_out[row] = dot;
     }
-    if (ST && tid < 4) gen_blocks(rbase[tid], 1, raw, tid);
+    if (ST && tid < 4) {
+        gen_blocks(rbase[tid], 1, raw, tid);
+        if (FUSE) gen_blocks(rbase2[tid], 1, raw2, tid);
+    }
     __syncthreads();
-    if (r && tid < 64) {
+    if ((r || FUSE) && tid < 64) {
         // re-quantise the 64 row dots to 8 bits (:1246-1440); noise group g = l>>3 (draw g>>2, byte g&3), word W[l&7]
         const float d = dsh[tid];
         float noise = 0.0f;
@@ -287,9 +428,21 @@ __global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ 
         }
         float mx = wave_max(__builtin_fabsf(d));
         mx = fix_zero_max(mx);
-        const float k = 127.0f / mx;
-        r[rb * 64 + tid] = (int8_t)quant1(d, k, noise);
-        if (tid == 0) sr[rb] = mx;
+        const int qv = quant1(d, 127.0f / mx, noise);
+        if (r) {
+            r[rb * 64 + tid] = (int8_t)qv;
+            if (tid == 0) sr[rb] = mx;
+        }
+        if (FUSE) {
+            // CloverVector8::scaleAndAdd on this block (CloverVector8.h:1089-1358); element l: draw l>>5, byte l&3, word (l&31)>>2
+            const float val = __builtin_fmaf((float)qv, (mx * fuse.a) / 127.0f, (float)fuse_q * (fuse_s / 127.0f));
+            float noise2 = 0.0f;
+            if (ST) noise2 = noise_of(reinterpret_cast<const uint32_t *>(raw2 + (size_t)(tid >> 5) * 4)[(tid & 31) >> 2], tid & 3);
+            float m2 = wave_max(__builtin_fabsf(val));
+            m2 = fix_zero_max(m2);
+            fuse.r2[rb * 64 + tid] = (int8_t)quant1(val, 127.0f / m2, noise2);
+            if (tid == 0) fuse.sr2[rb] = m2;
+        }
     }
 }
 
@@ -342,10 +495,48 @@ extern "C" int clv8_restore(const int8_t *q, const float *s, uint64_t n_pad, flo
     return CLV_OK;
 }
 
-static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d,
-                       int8_t *r, float *sr, uint64_t *rng, hipStream_t st)
+extern "C" int clv8_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad, int8_t *r,
+                                  float *sr, uint64_t *rng_state_dev, void *stream)
 {
-    const size_t lds = MVM8_CHUNK + (MVM8_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 128;
+    CLV_REQUIRE(qu && su && qv && sv && r && sr, "clv8_scale_and_add: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv8_scale_and_add: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    if (!n_pad) return CLV_OK;
+    hipStream_t st = as_stream(stream);
+    const uint64_t nb = n_pad / 64;
+    if (!rng_state_dev) {
+        const uint64_t nq16 = n_pad / 16;
+        const uint64_t want = (nq16 + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+        const dim3 grid((unsigned)(want < cap ? want : cap));
+        if (3 * n_pad > (256ull << 20))
+            hipLaunchKernelGGL(k_v8_scale_and_add<true>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a, (u32x4 *)r,
+                               sr, nq16);
+        else
+            hipLaunchKernelGGL(k_v8_scale_and_add<false>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a, (u32x4 *)r,
+                               sr, nq16);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
+    RngTables T;
+    int rc = clv_rng_tables(&T);
+    if (rc) return rc;
+    const uint64_t seq = clv_rng_next_seq();
+#define SAA8_LAUNCH(S)                                                                                                               \
+    hipLaunchKernelGGL(k_v8_scale_and_add_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const u32x4 *)qu, su, \
+                       (const u32x4 *)qv, sv, a, (u32x4 *)r, sr, nb, rng_state_dev, seq, T)
+    switch (clv_st_segments(nb)) {
+    case 1: SAA8_LAUNCH(1); break;
+    case 4: SAA8_LAUNCH(4); break;
+    default: SAA8_LAUNCH(16); break;
+    }
+#undef SAA8_LAUNCH
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d,
+                       int8_t *r, float *sr, uint64_t *rng, hipStream_t st, const Mvm8Fuse *fuse = nullptr)
+{
+    const size_t lds = MVM8_CHUNK + (MVM8_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 256;
     const dim3 grid((unsigned)(rows / 64)), block(256);
     RngTables T = {nullptr, nullptr};
     uint64_t seq = 0;
@@ -355,14 +546,22 @@ static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t
         seq = clv_rng_next_seq();
     }
     const bool streaming = rows * (cols / 2) > (256ull << 20);
-#define M8_LAUNCH(NT, ST)                                                                                                              \
-    hipLaunchKernelGGL((k_m4_mvm8<8, NT, ST>), grid, block, lds, st, (const uint8_t *)A, sA, cols, x, sx, d, r, sr, rng, seq, T.pow_rows)
+    const Mvm8Fuse no_fuse = {nullptr, nullptr, 0.0f, nullptr, nullptr};
+#define M8_LAUNCH_F(NT, ST, FUSE)                                                                                                      \
+    hipLaunchKernelGGL((k_m4_mvm8<8, NT, ST, FUSE>), grid, block, lds, st, (const uint8_t *)A, sA, cols, x, sx, d, r, sr, rng, seq,    \
+                       T.pow_rows, FUSE ? *fuse : no_fuse)
+#define M8_LAUNCH(NT, ST)                             \
+    do {                                              \
+        if (fuse) M8_LAUNCH_F(NT, ST, true);          \
+        else M8_LAUNCH_F(NT, ST, false);              \
+    } while (0)
     if (streaming) {
         if (rng) M8_LAUNCH(true, true); else M8_LAUNCH(true, false);
     } else {
         if (rng) M8_LAUNCH(false, true); else M8_LAUNCH(false, false);
     }
 #undef M8_LAUNCH
+#undef M8_LAUNCH_F
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -384,6 +583,50 @@ extern "C" int clm4_mvm_v8(const int8_t *A, const float *sA, uint64_t rows, uint
     CLV_REQUIRE(r && sr, "clm4_mvm_v8: null result pointer");
     if (!rows) return CLV_OK;
     return launch_mvm8(A, sA, rows, cols, x, sx, nullptr, r, sr, rng_state_dev, as_stream(stream));
+}
+
+extern "C" int clm4_mvm_v8_scale_and_add(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                                         const int8_t *qu, const float *su, float a, int8_t *t, float *st_, int8_t *r, float *sr,
+                                         uint64_t *rng_state_dev, void *stream)
+{
+    int rc = check_mvm8_args("clm4_mvm_v8_scale_and_add", A, sA, rows, cols, x, sx);
+    if (rc) return rc;
+    CLV_REQUIRE(qu && su && r && sr, "clm4_mvm_v8_scale_and_add: null pointer");
+    CLV_REQUIRE((t == nullptr) == (st_ == nullptr), "clm4_mvm_v8_scale_and_add: t and st must both be given or both be NULL");
+    CLV_REQUIRE((const void *)r != (const void *)x && (const void *)sr != (const void *)sx,
+                "clm4_mvm_v8_scale_and_add: the result must not alias the vector being multiplied");
+    if (!rows) return CLV_OK;
+    const Mvm8Fuse fuse = {qu, su, a, r, sr};
+    return launch_mvm8(A, sA, rows, cols, x, sx, nullptr, t, st_, rng_state_dev, as_stream(stream), &fuse);
+}
+
+// Q_IHT / Q_GD (test/performance/01_measure.h:923-946, 999-1021) as the reference runs them for "4-bit": CloverMatrix4 with
+// CloverVector8 vectors (02_bit04.cpp:140).  One call enqueues all iterations; 3 launches per iteration.
+__global__ void k_v8_clear(uint32_t *q, float *s, uint64_t nwords, uint64_t nblocks)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) q[i] = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks; i += stride) s[i] = 1.0f;
+}
+
+extern "C" int clm4_iht_v8(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n, int8_t *x,
+                           float *sx, uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1, int8_t *t2, float *st2,
+                           int8_t *t3, float *st3, uint64_t iterations, uint64_t K, float mu, int threshold, uint64_t *rng_state_dev,
+                           void *stream)
+{
+    CLV_REQUIRE(Phi && sPhi && PhiT && sPhiT && x && sx && y && sy && t1 && st1 && t2 && st2 && t3 && st3, "clm4_iht_v8: null pointer");
+    CLV_REQUIRE(m % 128 == 0 && n % 128 == 0 && x_len <= n, "clm4_iht_v8: m=%llu n=%llu x_len=%llu", (unsigned long long)m,
+                (unsigned long long)n, (unsigned long long)x_len);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_v8_clear, dim3(64), dim3(256), 0, st, (uint32_t *)x, sx, n / 4, n / 64);      // x.clear()
+    CLV_LAUNCH_CHECK();
+    for (uint64_t it = 0; it < iterations; it++) {
+        int rc = clm4_mvm_v8_scale_and_add(Phi, sPhi, m, n, x, sx, y, sy, -1.0f, t1, st1, t2, st2, rng_state_dev, stream);      // t1 = Phi x; t2 = y - t1
+        if (!rc) rc = clm4_mvm_v8_scale_and_add(PhiT, sPhiT, n, m, t2, st2, x, sx, mu, t3, st3, x, sx, rng_state_dev, stream);  // t3 = Phi' t2; x += mu t3
+        if (!rc && threshold) rc = clv8_threshold(x, sx, x_len, n, K, nullptr, stream);                                        // keep the K largest
+        if (rc) return rc;
+    }
+    return CLV_OK;
 }
 
 extern "C" int clm4_rowdots_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d,

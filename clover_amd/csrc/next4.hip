@@ -347,25 +347,42 @@ __device__ __forceinline__ uint32_t mag_key(uint32_t w, int e, float s7)
     return __float_as_uint(__builtin_fabsf(s7 * (float)unpack1(w, e)));
 }
 
+// The large-n kernels below serve both element widths.  BITS = 4: CloverVector4, 8 elements per word, |value| = |f32(s/7) * q|
+// (CloverVector4::get, :206-209).  BITS = 8: CloverVector8 (same algorithm, CloverVector8.h:1680-1740), 4 elements per word,
+// |value| = |f32((float)q * s) / 127| (CloverVector8::get, :137-140).
+template <int BITS>
+struct ThreshElems {
+    static constexpr int EPW = 32 / BITS;                                   // elements per 32-bit word
+    static constexpr int WPB = 64 / EPW;                                    // words per 64-element block
+    __device__ static __forceinline__ uint32_t mask(int e) { return BITS == 4 ? 0xFu << nib_shift(e) : 0xFFu << (8 * e); }
+    __device__ static __forceinline__ uint32_t key(uint32_t w, int e, float sc)
+    {
+        if (BITS == 4) return mag_key(w, e, sc / 7.0f);
+        const float q = (float)((int)(w << (24 - 8 * e)) >> 24);
+        return __float_as_uint(__builtin_fabsf(q * sc / 127.0f));
+    }
+};
+
 // level 0: bins = key >> 20 (4096); level 1: key>>20 == prefix, bins = (key >> 8) & 0xFFF; level 2:
 // key>>8 == prefix, bins = key & 0xFF
-template <int LEVEL>
+template <int LEVEL, int BITS>
 __global__ __launch_bounds__(256) void k_thresh_hist(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n,
                                                      const ThreshState *__restrict__ ts, uint32_t *__restrict__ hist)
 {
+    typedef ThreshElems<BITS> E;
     __shared__ uint32_t lh[4096];
     for (int i = threadIdx.x; i < 4096; i += 256) lh[i] = 0;
     __syncthreads();
     const uint32_t prefix = LEVEL ? ts->prefix : 0;
-    const uint64_t nwords = (n + 7) / 8;
+    const uint64_t nwords = (n + E::EPW - 1) / E::EPW;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
         const uint32_t w = q[i];
-        const float s7 = s[i >> 3] / 7.0f;
+        const float sc = s[i / E::WPB];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            if (i * 8 + e >= n) break;
-            const uint32_t key = mag_key(w, e, s7);
+        for (int e = 0; e < E::EPW; e++) {
+            if (i * E::EPW + e >= n) break;
+            const uint32_t key = E::key(w, e, sc);
             if (LEVEL == 0) atomicAdd(&lh[key >> 20], 1u);
             else if (LEVEL == 1) { if ((key >> 20) == prefix) atomicAdd(&lh[(key >> 8) & 0xFFF], 1u); }
             else { if ((key >> 8) == prefix) atomicAdd(&lh[key & 0xFF], 1u); }
@@ -408,9 +425,11 @@ __global__ __launch_bounds__(256) void k_thresh_select(uint32_t *__restrict__ hi
 // chunked (not grid-stride) so that index order = (block, thread, element)
 #define TH_WORDS_PER_BLOCK 2048      // 8 words per thread
 
+template <int BITS>
 __global__ __launch_bounds__(256) void k_thresh_count_ties(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n,
                                                            const ThreshState *__restrict__ ts, uint32_t *__restrict__ block_ties)
 {
+    typedef ThreshElems<BITS> E;
     __shared__ uint32_t cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
@@ -419,11 +438,11 @@ __global__ __launch_bounds__(256) void k_thresh_count_ties(const uint32_t *__res
     uint32_t c = 0;
     for (int k = 0; k < 8; k++) {
         const uint64_t i = w0 + k;
-        if (i * 8 >= n) break;
+        if (i * E::EPW >= n) break;
         const uint32_t w = q[i];
-        const float s7 = s[i >> 3] / 7.0f;
+        const float sc = s[i / E::WPB];
 #pragma unroll
-        for (int e = 0; e < 8; e++) if (i * 8 + e < n && mag_key(w, e, s7) == tau) c++;
+        for (int e = 0; e < E::EPW; e++) if (i * E::EPW + e < n && E::key(w, e, sc) == tau) c++;
     }
     if (c) atomicAdd(&cnt, c);
     __syncthreads();
@@ -455,9 +474,11 @@ __global__ __launch_bounds__(256) void k_thresh_scan(uint32_t *__restrict__ bloc
     }
 }
 
+template <int BITS>
 __global__ __launch_bounds__(256) void k_thresh_apply(uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n,
                                                       const ThreshState *__restrict__ ts, const uint32_t *__restrict__ block_ties)
 {
+    typedef ThreshElems<BITS> E;
     __shared__ uint32_t tcnt[256];
     const uint32_t tau = ts->tau, keep = ts->ties_keep;
     const uint64_t w0 = (uint64_t)blockIdx.x * TH_WORDS_PER_BLOCK + threadIdx.x * 8;
@@ -468,15 +489,15 @@ __global__ __launch_bounds__(256) void k_thresh_apply(uint32_t *__restrict__ q, 
         const uint64_t i = w0 + k;
         words[k] = 0;
         tie_mask[k] = 0;
-        if (i * 8 >= n) continue;
+        if (i * E::EPW >= n) continue;
         const uint32_t w = q[i];
-        const float s7 = s[i >> 3] / 7.0f;
+        const float sc = s[i / E::WPB];
         uint32_t outw = 0;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            if (i * 8 + e >= n) continue;
-            const uint32_t key = mag_key(w, e, s7);
-            if (key > tau) outw |= w & (0xFu << nib_shift(e));
+        for (int e = 0; e < E::EPW; e++) {
+            if (i * E::EPW + e >= n) continue;
+            const uint32_t key = E::key(w, e, sc);
+            if (key > tau) outw |= w & E::mask(e);
             else if (key == tau) { tie_mask[k] |= 1u << e; c++; }
         }
         words[k] = outw;
@@ -495,19 +516,19 @@ __global__ __launch_bounds__(256) void k_thresh_apply(uint32_t *__restrict__ q, 
     uint32_t rank = block_ties[blockIdx.x] + incl - c;
     for (int k = 0; k < 8; k++) {
         const uint64_t i = w0 + k;
-        if (i * 8 >= n) break;
+        if (i * E::EPW >= n) break;
         uint32_t outw = words[k];
         const uint32_t w = q[i];
 #pragma unroll
-        for (int e = 0; e < 8; e++)
+        for (int e = 0; e < E::EPW; e++)
             if (tie_mask[k] & (1u << e)) {
-                if (rank < keep) outw |= w & (0xFu << nib_shift(e));
+                if (rank < keep) outw |= w & E::mask(e);
                 rank++;
             }
         // elements at or beyond n (the padding) are left as they are, like the reference's loop to `length`
-        const uint64_t first = i * 8;
-        if (first + 8 > n) {
-            for (int e = 0; e < 8; e++) if (first + e >= n) outw |= w & (0xFu << nib_shift(e));
+        const uint64_t first = i * E::EPW;
+        if (first + E::EPW > n) {
+            for (int e = 0; e < E::EPW; e++) if (first + e >= n) outw |= w & E::mask(e);
         }
         q[i] = outw;
     }
@@ -691,9 +712,134 @@ static inline size_t thresh_small_lds(uint64_t n)
     return (1024 + 16 + 16 + 2 * nblocks + ((nblocks + 3) & ~3ull) + nwords) * sizeof(uint32_t);
 }
 
+// ---- single-workgroup path for CloverVector8 (n_pad <= 32768): element keys live in registers (8 words = 32 elements per
+// thread), radix select in four 8-bit levels straight over the elements (a block has up to 128 distinct magnitudes, so the
+// candidate trick of the 4-bit kernel does not pay), same DPP scans, same lowest-index tie rule.
+#define TS8_MAXW 8
+__global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restrict__ q, const float *__restrict__ s, uint32_t n, uint32_t k)
+{
+    typedef ThreshElems<8> E;
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t sel[2];
+    const int tid = threadIdx.x;
+    const uint32_t nwords = (n + 3) / 4;
+    const uint32_t W = (nwords + TS_THREADS - 1) / TS_THREADS;          // contiguous words per thread: index order = thread order
+    const uint32_t w0 = tid * W;
+    uint32_t words[TS8_MAXW], keys[TS8_MAXW][4];
+    uint32_t valid = 0;                                                // bit 4j+e: element e of word j exists (index < n)
+#pragma unroll
+    for (uint32_t j = 0; j < TS8_MAXW; j++) {
+        const uint32_t i = w0 + j;
+        const bool in = j < W && i < nwords;
+        words[j] = in ? q[i] : 0u;
+        const float sc = in ? s[i / E::WPB] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            keys[j][e] = E::key(words[j], e, sc);
+            if (in && i * 4 + e < n) valid |= 1u << (4 * j + e);
+        }
+    }
+    hist[tid] = 0;
+    __syncthreads();
+
+    uint32_t tau = 0x7F800000u, keep = 0;
+    if (k != 0) {
+        uint32_t prefix = 0, need = k;
+        for (int level = 0; level < 4; level++) {
+            const int shift = 24 - 8 * level;
+            uint32_t *h = hist + 256 * level;
+#pragma unroll
+            for (uint32_t j = 0; j < TS8_MAXW; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if ((valid >> (4 * j + e)) & 1u) {
+                        const uint32_t key = keys[j][e];
+                        if (level == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&h[(key >> shift) & 0xFFu], 1u);
+                    }
+            __syncthreads();
+            const uint32_t mine = tid < 256 ? h[255 - tid] : 0;           // select from the top: thread t < 256 owns bin 255 - t
+            uint32_t v = wave_scan_incl(mine);
+            if (tid < 256 && (tid & 63) == 63) wsum[tid >> 6] = v;
+            __syncthreads();
+            if (tid < 256) {
+                for (int w = 0; w < (tid >> 6); w++) v += wsum[w];
+                if (v >= need && v - mine < need) {
+                    sel[0] = 255u - tid;
+                    sel[1] = need - (v - mine);
+                }
+            }
+            __syncthreads();
+            prefix = (prefix << 8) | sel[0];
+            need = sel[1];
+        }
+        tau = prefix;
+        keep = need;
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < TS8_MAXW; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) c += ((valid >> (4 * j + e)) & 1u) && keys[j][e] == tau;
+    uint32_t rank = block_scan_incl(c, wsum) - c;               // ties in index order: the first `keep` of them survive
+#pragma unroll
+    for (uint32_t j = 0; j < TS8_MAXW; j++) {
+        const uint32_t i = w0 + j;
+        if (j < W && i < nwords) {
+            uint32_t outw = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t byte = words[j] & E::mask(e);
+                if (!((valid >> (4 * j + e)) & 1u)) { outw |= byte; continue; }          // padding is left alone
+                if (keys[j][e] > tau) outw |= byte;
+                else if (keys[j][e] == tau) { if (rank < keep) outw |= byte; rank++; }
+            }
+            q[i] = outw;
+        }
+    }
+}
+
+template <int BITS>
+static int threshold_large(uint32_t *q, const float *s, uint64_t n, uint64_t k, void *workspace, hipStream_t st)
+{
+    uint32_t *hist = (uint32_t *)workspace;
+    ThreshState *ts = (ThreshState *)(hist + 4096);
+    uint32_t *block_ties = (uint32_t *)((char *)ts + 256);
+    const uint64_t nwords = (n + ThreshElems<BITS>::EPW - 1) / ThreshElems<BITS>::EPW;
+    const uint32_t nblocks = (uint32_t)((nwords + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK);
+    CLV_HIP(hipMemsetAsync(hist, 0, 4096 * sizeof(uint32_t) + 256, st));
+    if (k == 0) {
+        // keep nothing: tau = +inf pattern beyond any finite magnitude, no ties kept
+        const ThreshState none = {0, 0, 0x7F800000u, 0};
+        CLV_HIP(hipMemcpyAsync(ts, &none, sizeof none, hipMemcpyHostToDevice, st));
+        CLV_HIP(hipStreamSynchronize(st));
+    } else {
+        const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 4;
+        const dim3 grid((unsigned)(want < cap ? want : cap));
+        hipLaunchKernelGGL((k_thresh_hist<0, BITS>), grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<0>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        hipLaunchKernelGGL((k_thresh_hist<1, BITS>), grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<1>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        hipLaunchKernelGGL((k_thresh_hist<2, BITS>), grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<2>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        CLV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_thresh_count_ties<BITS>, dim3(nblocks), dim3(256), 0, st, (const uint32_t *)q, s, n, ts, block_ties);
+    hipLaunchKernelGGL(k_thresh_scan, dim3(1), dim3(256), 0, st, block_ties, nblocks);
+    hipLaunchKernelGGL(k_thresh_apply<BITS>, dim3(nblocks), dim3(256), 0, st, q, s, n, ts, block_ties);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
 extern "C" uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad)
 {
     const uint64_t blocks = (n_pad / 8 + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK;
+    return 4096 * sizeof(uint32_t) + 256 + blocks * sizeof(uint32_t) + 256;
+}
+
+extern "C" uint64_t clv8_threshold_workspace_bytes(uint64_t n_pad)
+{
+    const uint64_t blocks = (n_pad / 4 + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK;
     return 4096 * sizeof(uint32_t) + 256 + blocks * sizeof(uint32_t) + 256;
 }
 
@@ -715,33 +861,27 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
         int rc = clv_internal_workspace(&workspace, clv4_threshold_workspace_bytes(n_pad));
         if (rc) return rc;
     }
-    uint32_t *hist = (uint32_t *)workspace;
-    ThreshState *ts = (ThreshState *)(hist + 4096);
-    uint32_t *block_ties = (uint32_t *)((char *)ts + 256);
-    const uint64_t nwords = (n + 7) / 8;
-    const uint32_t nblocks = (uint32_t)((nwords + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK);
-    CLV_HIP(hipMemsetAsync(hist, 0, 4096 * sizeof(uint32_t) + 256, st));
-    if (k == 0) {
-        // keep nothing: tau = +inf pattern beyond any finite magnitude, no ties kept
-        const ThreshState none = {0, 0, 0x7F800000u, 0};
-        CLV_HIP(hipMemcpyAsync(ts, &none, sizeof none, hipMemcpyHostToDevice, st));
-        CLV_HIP(hipStreamSynchronize(st));
-    } else {
-        const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 4;
-        const dim3 grid((unsigned)(want < cap ? want : cap));
-        hipLaunchKernelGGL(k_thresh_hist<0>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
-        hipLaunchKernelGGL(k_thresh_select<0>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
-        hipLaunchKernelGGL(k_thresh_hist<1>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
-        hipLaunchKernelGGL(k_thresh_select<1>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
-        hipLaunchKernelGGL(k_thresh_hist<2>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, ts, hist);
-        hipLaunchKernelGGL(k_thresh_select<2>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+    return threshold_large<4>((uint32_t *)q, s, n, k, workspace, st);
+}
+
+// CloverVector8::threshold(K) (CloverVector8.h:1680-1740): same algorithm and tie rule on |q * scale / 127|
+extern "C" int clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream)
+{
+    CLV_REQUIRE(q && s, "clv8_threshold: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0 && n <= n_pad, "clv8_threshold: n=%llu n_pad=%llu", (unsigned long long)n, (unsigned long long)n_pad);
+    CLV_REQUIRE(n < (1ull << 32), "clv8_threshold: vectors of 2^32 or more elements are not supported");
+    hipStream_t st = as_stream(stream);
+    if (k >= n || n == 0) return CLV_OK;
+    if (n_pad <= (uint64_t)TS_THREADS * TS8_MAXW * 4) {
+        hipLaunchKernelGGL(k_thresh8_small, dim3(1), dim3(TS_THREADS), 0, st, (uint32_t *)q, s, (uint32_t)n, (uint32_t)k);
         CLV_LAUNCH_CHECK();
+        return CLV_OK;
     }
-    hipLaunchKernelGGL(k_thresh_count_ties, dim3(nblocks), dim3(256), 0, st, (const uint32_t *)q, s, n, ts, block_ties);
-    hipLaunchKernelGGL(k_thresh_scan, dim3(1), dim3(256), 0, st, block_ties, nblocks);
-    hipLaunchKernelGGL(k_thresh_apply, dim3(nblocks), dim3(256), 0, st, (uint32_t *)q, s, n, ts, block_ties);
-    CLV_LAUNCH_CHECK();
-    return CLV_OK;
+    if (!workspace) {
+        int rc = clv_internal_workspace(&workspace, clv8_threshold_workspace_bytes(n_pad));
+        if (rc) return rc;
+    }
+    return threshold_large<8>((uint32_t *)q, s, n, k, workspace, st);
 }
 
 // =================================================================================================

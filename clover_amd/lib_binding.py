@@ -58,7 +58,13 @@ SIGNATURES = {
     "clm4_mvm_scale_and_add": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clv8_quantize": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
     "clv8_restore": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "clv8_scale_and_add": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _u64, _vp, _vp, _vp, _vp]),
+    "clv8_threshold_workspace_bytes": (_u64, [_u64]),
+    "clv8_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "clm4_mvm_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clm4_mvm_v8_scale_and_add": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clm4_iht_v8": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, C.c_float,
+                              C.c_int, _vp, _vp]),
     "clm4_rowdots_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clv4_threshold_workspace_bytes": (_u64, [_u64]),
     "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
@@ -267,6 +273,18 @@ class CloverHip:
         dq, ds, dx = self.to_device(q), self.to_device(s), self.alloc(max(4 * n, 4))
         self.check(self.lib.clv8_restore(dq.ptr, ds.ptr, n, dx.ptr, None))
         return dx.download(np.float32, n)
+
+    def v8_scale_and_add(self, qu, su, qv, sv, a: float, rng: DevBuf | None = None, in_place: bool = False):
+        n = qu.size
+        b = [self.to_device(x) for x in (qu, su, qv, sv)]
+        dr, dsr = (b[0], b[1]) if in_place else (self.alloc(max(n, 1)), self.alloc(max(n // 16, 4)))
+        self.check(self.lib.clv8_scale_and_add(b[0].ptr, b[1].ptr, b[2].ptr, b[3].ptr, a, n, dr.ptr, dsr.ptr, rng.ptr if rng else None, None))
+        return dr.download(np.int8, n), dsr.download(np.float32, n // 64)
+
+    def v8_threshold(self, q, s, n: int, k: int) -> np.ndarray:
+        dq, ds = self.to_device(q), self.to_device(s)
+        self.check(self.lib.clv8_threshold(dq.ptr, ds.ptr, n, q.size, k, None, None))
+        return dq.download(np.int8, q.size)
 
     def m4_mvm_v8(self, qA, sA, rows, cols, qx, sx, rng: DevBuf | None = None):
         b = [self.to_device(a) for a in (qA, sA, qx, sx)]

@@ -66,4 +66,28 @@ inline void Q_GD(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, Clov
     }
 }
 
+
+/* CloverMatrix4 with CloverVector8 vectors: the configuration the reference measures and publishes as the 4-bit IHT / GD
+ * (test/performance/02_bit04.cpp:140; "the 4-bit version uses the mixed precision MVM", doc/results/performance.txt:597-606) */
+inline void Q_IHT(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector8 &x, CloverVector8 &y, CloverVector8 &t1, CloverVector8 &t2,
+                  CloverVector8 &t3, const uint64_t iterations, const uint64_t K, const float mu)
+{
+    x.clear();
+    for (uint64_t i = 0; i < iterations; i += 1) {
+        Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);
+        PhiT.mvm_scaleAndAdd(t2, x, mu, t3);
+        x.threshold_parallel(K);
+    }
+}
+
+inline void Q_GD(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector8 &x, CloverVector8 &y, CloverVector8 &t1, CloverVector8 &t2,
+                 CloverVector8 &t3, const uint64_t iterations, const float mu)
+{
+    x.clear();
+    for (uint64_t i = 0; i < iterations; i += 1) {
+        Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);
+        PhiT.mvm_scaleAndAdd(t2, x, mu, t3);
+    }
+}
+
 #endif

@@ -141,6 +141,35 @@ public:
     }
     void mvm_parallel(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
     void mvm_scalar(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
+    /* the same pairing as mvm_scaleAndAdd above, for 8-bit vectors */
+    void mvm_scaleAndAdd(const CloverVector8 &x, const CloverVector8 &u, float a, CloverVector8 &t, CloverVector8 &r)
+    {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+        if (x.size() != getCols() || t.size_pad() != getRows()) { std::cout << "MVM can not be performed. Exiting ..." << std::endl; exit(1); }
+        if (u.size_pad() != getRows() || r.size_pad() != getRows()) { std::cout << "Vectors do not have the same size. Exiting ..." << std::endl; exit(1); }
+        clover_hip::check(clm4_mvm_v8_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(),
+                                                    u.dev_values_ro(), u.dev_scales_ro(), a, t.dev_values_wo(), t.dev_scales_wo(),
+                                                    r.dev_values_wo(), r.dev_scales_wo(), nullptr, nullptr), "CloverMatrix4::mvm_scaleAndAdd");
+#else
+        mvm(x, t);
+        const_cast<CloverVector8 &>(u).scaleAndAdd(t, a, r);
+#endif
+    }
+    void mvm_scaleAndAdd(const CloverVector8 &x, CloverVector8 &u, float a, CloverVector8 &t)
+    {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+        if (x.size() != getCols() || t.size_pad() != getRows()) { std::cout << "MVM can not be performed. Exiting ..." << std::endl; exit(1); }
+        if (u.size_pad() != getRows()) { std::cout << "Vectors do not have the same size. Exiting ..." << std::endl; exit(1); }
+        int8_t *qu = u.dev_values_rw();
+        float *su = u.dev_scales_rw();
+        clover_hip::check(clm4_mvm_v8_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(), qu, su, a,
+                                                    t.dev_values_wo(), t.dev_scales_wo(), qu, su, nullptr, nullptr),
+                          "CloverMatrix4::mvm_scaleAndAdd");
+#else
+        mvm(x, t);
+        u.scaleAndAdd(t, a);
+#endif
+    }
 
     /* mixed precision: fp32 vector in, fp32 vector out (CloverMatrix4.h:1451-1547; _parallel :2397-2505) */
     void mvm(const CloverVector32 &productVector, CloverVector32 &resultVector)

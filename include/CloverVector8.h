@@ -9,8 +9,12 @@
  *   quantize / quantize_parallel / quantize_scalar  -> clv8_quantize  (CloverVector8.h:393-606, :607-833, :205-253)
  *   restore / restore_scalar                        -> clv8_restore   (:835-909, :255-266)
  *
- * on the device.  The rest of the reference's 8-bit vector algebra (dot, scaleAndAdd, threshold: :911-1850) belongs to
- * the 8-bit containers' own path and is not part of this backend.
+ *   scaleAndAdd / _parallel / _scalar               -> clv8_scale_and_add (:1063-1358, :1360-1678, :311-391)
+ *   threshold / threshold_parallel                  -> clv8_threshold     (:1680-1740; lowest-index tie rule, see clover_hip.h)
+ *
+ * on the device: what Q_IHT / Q_GD need when they run with a CloverMatrix4 and CloverVector8 vectors, the configuration the
+ * reference publishes as "4-bit" (test/performance/02_bit04.cpp:140).  The 8-bit dot (:911-1061) and CloverMatrix8 belong to
+ * the 8-bit containers' own path and are not part of this backend.
  */
 #ifndef CLOVER_VECTOR8_H
 #define CLOVER_VECTOR8_H
@@ -118,6 +122,38 @@ public:
     }
     void restore_scalar(CloverVector32 &other) const { restore(other); }
 
+    /* this = quantize(this + a * other)   (CloverVector8.h:1063-1072) */
+    void scaleAndAdd(const CloverVector8 &other, float a)
+    {
+        same_size(other);
+        const int8_t *v = other.dev_values_ro();
+        const float *sv = other.dev_scales_ro();
+        int8_t *u = dev_values_rw();
+        float *su = dev_scales_rw();
+        clover_hip::check(clv8_scale_and_add(u, su, v, sv, a, length_pad, u, su, clover_hip::rng_or_null(random), nullptr),
+                          "CloverVector8::scaleAndAdd");
+    }
+    /* result = quantize(this + a * other) (CloverVector8.h:1074-1087) */
+    void scaleAndAdd(const CloverVector8 &other, float a, CloverVector8 &result)
+    {
+        same_size(other);
+        same_size(result);
+        clover_hip::check(clv8_scale_and_add(dev_values_ro(), dev_scales_ro(), other.dev_values_ro(), other.dev_scales_ro(), a, length_pad,
+                                             result.dev_values_wo(), result.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
+                          "CloverVector8::scaleAndAdd");
+    }
+    void scaleAndAdd_parallel(const CloverVector8 &other, float a) { scaleAndAdd(other, a); }
+    void scaleAndAdd_parallel(const CloverVector8 &other, float a, CloverVector8 &result) { scaleAndAdd(other, a, result); }
+    void scaleAndAdd_scalar(const CloverVector8 &other, float a) { scaleAndAdd(other, a); }
+    void scaleAndAdd_scalar(const CloverVector8 &other, float a, CloverVector8 &result) { scaleAndAdd(other, a, result); }
+
+    /* keep the k largest magnitudes, zero the rest (CloverVector8.h:1680-1740) */
+    void threshold(uint64_t k)
+    {
+        clover_hip::check(clv8_threshold(dev_values_rw(), dev_scales_ro(), length, length_pad, k, nullptr, nullptr), "CloverVector8::threshold");
+    }
+    void threshold_parallel(uint64_t k) { threshold(k); }
+
     /* ---- device views, used by CloverMatrix4 ------------------------------------------------------ */
     const int8_t *dev_values_ro() const { return reinterpret_cast<const int8_t *>(mem.dev_ro()); }
     const float *dev_scales_ro() const
@@ -132,7 +168,21 @@ public:
         return reinterpret_cast<float *>(mem.dev_wo() + value_bytes);
     }
 
+    int8_t *dev_values_rw() { return reinterpret_cast<int8_t *>(mem.dev_rw()); }
+    float *dev_scales_rw()
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.dev_rw());
+        return reinterpret_cast<float *>(mem.dev_rw() + value_bytes);
+    }
+
 private:
+    void same_size(const CloverVector8 &other) const
+    {
+        if (other.length_pad != length_pad) {
+            std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+    }
     const int8_t *values_ro() const { return reinterpret_cast<const int8_t *>(mem.host_ro()); }
     const float *scales_ro() const
     {

@@ -138,11 +138,29 @@ int  clm4_mvm_scale_and_add(const int8_t *A, const float *sA, uint64_t rows, uin
  * rng the same XORShift stream positions and lane map as the reference (two draws per 64-block). */
 int  clv8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream);
 int  clv8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, void *stream);
+/* CloverVector8::scaleAndAdd (CloverVector8.h:1063-1358) and ::threshold (:1680-1740): the vector steps of the quantized
+ * IHT / GD loops in the configuration the reference publishes for "4-bit" (CloverMatrix4 with CloverVector8 vectors,
+ * test/performance/02_bit04.cpp:140).  Same contracts as clv4_scale_and_add / clv4_threshold. */
+int  clv8_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
+                        int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
+uint64_t clv8_threshold_workspace_bytes(uint64_t n_pad);
+int  clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream);
 /* CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &) (CloverMatrix4.h:1093-1441; _parallel :2017-2387):
  * x: cols int8 + cols/64 scales; r: rows int8 + rows/64 scales (re-quantised to 8 bits).  Bit-identical to the
  * reference's SIMD path (8 fp32 fma chains per row) for either rounding mode. */
 int  clm4_mvm_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
                  int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
+/* clm4_mvm_v8 immediately followed by clv8_scale_and_add on its result, one launch (see clm4_mvm_scale_and_add):
+ * t = quantize8(A x) (stored if t/st != NULL), r = quantize8(u + a * t); r/sr may alias u/su, not x/sx. */
+int  clm4_mvm_v8_scale_and_add(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
+                               const int8_t *qu, const float *su, float a, int8_t *t, float *st, int8_t *r, float *sr,
+                               uint64_t *rng_state_dev, void *stream);
+/* Q_IHT / Q_GD with CloverMatrix4 and CloverVector8 vectors -- the reference's published "4-bit" IHT configuration
+ * (test/performance/02_bit04.cpp:140, doc/results/performance.txt:597-606).  Arguments as clm4_iht; vectors are 8-bit. */
+int  clm4_iht_v8(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n,
+                 int8_t *x, float *sx, uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1,
+                 int8_t *t2, float *st2, int8_t *t3, float *st3, uint64_t iterations, uint64_t K, float mu, int threshold,
+                 uint64_t *rng_state_dev, void *stream);
 /* the fp32 row dots of that mvm before re-quantisation: d[rows] (CloverMatrix4.h:1120-1243) */
 int  clm4_rowdots_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
                      float *d, void *stream);

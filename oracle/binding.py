@@ -156,6 +156,20 @@ class Oracle:
         self.L.orc_v8_restore(_p(q, C.POINTER(C.c_int8)), _p(s, _fp), _u64(q.size), _p(x, _fp))
         return x
 
+    def v8_scale_and_add(self, qu, su, qv, sv, a: float, rng: OrcRng | None = None):
+        n = qu.size
+        i8 = C.POINTER(C.c_int8)
+        r = np.zeros(n, np.int8)
+        sr = np.zeros(n // 64, np.float32)
+        self.L.orc_v8_scale_and_add(_p(qu, i8), _p(su, _fp), _p(qv, i8), _p(sv, _fp), C.c_float(a), _u64(n), _p(r, i8), _p(sr, _fp),
+                                    C.byref(rng) if rng is not None else None)
+        return r, sr
+
+    def v8_threshold(self, q, s, n: int, k: int) -> np.ndarray:
+        out = np.array(q, dtype=np.int8, copy=True)
+        self.L.orc_v8_threshold(_p(out, C.POINTER(C.c_int8)), _p(s, _fp), _u64(n), _u64(k))
+        return out
+
     def m4_rowdots_v8(self, qA, sA, rows, cols, qx, sx, f64: bool = False) -> np.ndarray:
         d = np.zeros(rows, np.float32)
         fn = self.L.orc_m4_rowdots_v8_f64 if f64 else self.L.orc_m4_rowdots_v8

@@ -585,6 +585,65 @@ void orc_m4_mvm_v8(const uint8_t *A, const float *sA, uint64_t rows, uint64_t co
     }
 }
 
+void orc_v8_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
+                          int8_t *r, float *sr, orc_rng *rng)
+{
+    const uint64_t nb = n_pad / 64;
+    for (uint64_t b = 0; b < nb; b++) {
+        const float su_ps = su[b] / 127.0f;                     /* CloverVector8.h:1145-1146 */
+        const float sva = sv[b] * a;                            /* :1095 */
+        const float sv_ps = sva / 127.0f;
+        float val[64];
+        for (int i = 0; i < 64; i++) {
+            const float du = (float)qu[64 * b + i] * su_ps;
+            val[i] = fmaf((float)qv[64 * b + i], sv_ps, du);
+        }
+        float m = 0.0f;
+        for (int i = 0; i < 64; i++) { const float x = fabsf(val[i]); if (x > m) m = x; }
+        m = fix_zero_max(m);
+        sr[b] = m;
+        const float k = 127.0f / m;
+        if (rng) {
+            /* register k-1 = g holds byte (g&3) of the dwords of half g>>2: lane j of it is element 32 (g>>2) + 4 j + (g&3) (:1104-1126) */
+            float nz[8][8], flat[64];
+            orc_rng_block_noise(rng, nz);
+            for (int g = 0; g < 8; g++) for (int j = 0; j < 8; j++) flat[32 * (g >> 2) + 4 * j + (g & 3)] = nz[g][j];
+            quant8_block64(val, k, flat, r + 64 * b);
+        } else {
+            quant8_block64(val, k, 0, r + 64 * b);
+        }
+    }
+}
+
+static inline float v8_abs(const int8_t *q, const float *s, uint64_t i)
+{
+    return fabsf((float)q[i] * s[i >> 6] / 127.0f);            /* getAbs -> get (:137-140) */
+}
+
+void orc_v8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t k)
+{
+    if (k == 0) { for (uint64_t i = 0; i < n; i++) q[i] = 0; return; }
+    if (k >= n) return;
+    heap_item *h = (heap_item *)malloc(k * sizeof(heap_item));
+    for (uint64_t i = 0; i < k; i++) {
+        h[i].value = v8_abs(q, s, i);
+        h[i].bits = q[i];
+        h[i].idx = i;
+        q[i] = 0;
+    }
+    make_heap_gt(h, k);
+    for (uint64_t i = k; i < n; i++) {
+        const float v = v8_abs(q, s, i);
+        if (v > h[0].value) {
+            h[0].value = v; h[0].idx = i; h[0].bits = q[i];
+            sift_min(h, 0, k);
+        }
+        q[i] = 0;
+    }
+    for (uint64_t i = 0; i < k; i++) q[h[i].idx] = (int8_t)h[i].bits;
+    free(h);
+}
+
 void orc_m4_rowdots_v8_f64(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d)
 {
     for (uint64_t i = 0; i < rows; i++) {

@@ -102,6 +102,12 @@ void     orc_m4_rowdots_v8(const uint8_t *A, const float *sA, uint64_t rows, uin
  * noise group g, word j lands on output row 8g + j */
 void     orc_m4_mvm_v8(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
                        int8_t *r, float *sr, orc_rng *rng);
+/* CloverVector8::scaleAndAdd (CloverVector8.h:1063-1358): r = quantize8(u + a*v) per 64-block,
+ * val = fma((float)qv, f32(f32(sv*a)/127), (float)qu * f32(su/127)); noise for element e: draw e>>5, byte e&3, word (e&31)>>2 */
+void     orc_v8_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
+                              int8_t *r, float *sr, orc_rng *rng);
+/* CloverVector8::threshold (CloverVector8.h:1680-1740): min-heap top-K on |q * scale / 127| over the first n elements */
+void     orc_v8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t k);
 /* mvm_scalar(CloverVector8) (CloverMatrix4.h:402-413): double accumulation of get(i,j) * x.get(j), cast to float */
 void     orc_m4_rowdots_v8_f64(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d);
 

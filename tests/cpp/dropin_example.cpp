@@ -131,6 +131,13 @@ int main()
         printf("qiht_scales=0x%08x,0x%08x\n", bits(x.getScales()[0]), bits(x.getScales()[7]));
         Q_GD(Phi, PhiT, x, y, t1, t2, t3, 2, 0.001f);
         hexdump("qgd_x", x.getData(), 256);
+        // the same loops in the reference's published "4-bit" configuration: CloverMatrix4 with CloverVector8 vectors
+        CloverVector8 x8(N), y8(y32), u1(M), u2(M), u3(N);
+        Q_IHT(Phi, PhiT, x8, y8, u1, u2, u3, 3, K, 0.001f);
+        hexdump("qiht8_x", x8.getData(), 512);
+        printf("qiht8_scales=0x%08x,0x%08x\n", bits(x8.getScales()[0]), bits(x8.getScales()[7]));
+        Q_GD(Phi, PhiT, x8, y8, u1, u2, u3, 2, 0.001f);
+        hexdump("qgd8_x", x8.getData(), 512);
     }
     return 0;
 }

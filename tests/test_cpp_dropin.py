@@ -105,6 +105,31 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
     assert kv["qiht_x"] == xi[0].tobytes().hex()
     assert kv["qiht_scales"].split(",") == [hex(bits(xi[1][0])), hex(bits(xi[1][7]))]
     assert kv["qgd_x"] == loop(2, False)[0].tobytes().hex()
+    # the mixed-precision loops (CloverMatrix4 + CloverVector8), same operands
+    y8 = oracle.v8_quantize(ints(M, 10, 9))
+
+    def threshold8_lowest_index(q, s, k):
+        mags = np.abs((q.astype(np.float32) * np.repeat(s, 64)) / np.float32(127.0))
+        tau = np.sort(mags)[::-1][k - 1]
+        keep = mags > tau
+        ties = np.flatnonzero(mags == tau)[: k - int(keep.sum())]
+        keep[ties] = True
+        return (q * keep).astype(np.int8)
+
+    def loop8(iters, thr):
+        x = (np.zeros(N, np.int8), np.ones(N // 64, np.float32))
+        for _ in range(iters):
+            t1 = oracle.m4_mvm_v8(*Phi, M, N, *x)
+            t2 = oracle.v8_scale_and_add(*y8, *t1, -1.0)
+            t3 = oracle.m4_mvm_v8(*PhiT, N, M, *t2)
+            x = oracle.v8_scale_and_add(*x, *t3, 0.001)
+            if thr:
+                x = (threshold8_lowest_index(x[0], x[1], K), x[1])
+        return x
+    x8 = loop8(3, True)
+    assert kv["qiht8_x"] == x8[0].tobytes().hex()
+    assert [int(v, 16) for v in kv["qiht8_scales"].split(",")] == [int(bits(x8[1][0])), int(bits(x8[1][7]))]
+    assert kv["qgd8_x"] == loop8(2, False)[0].tobytes().hex()
     # GEMM spot values vs the oracle's definition
     A, _ = kat3_inputs()
     qA, sA = oracle.m4_quantize(A)

@@ -145,3 +145,157 @@ def test_gpu_mixed_mvm_extreme_values(hip, oracle):
         ro, sro = oracle.m4_mvm_v8(qA, sA, M, N, qx, sx)
         assert same(r, ro) and same(sr, sro)
         assert abs(int(r[0])) == 127 and (int(r[0]) > 0) == ((a > 0) == (b > 0))
+
+
+# ---------------------------------------------------------------- the 8-bit vector steps of the mixed IHT / GD loops
+def _rand_v8(rng, n):
+    q = rng.integers(-127, 128, n).astype(np.int8)
+    s = rng.uniform(0.5, 2, n // 64).astype(np.float32)
+    return q, s
+
+
+def test_oracle_v8_scale_and_add_definition(oracle):
+    rng = np.random.default_rng(2)
+    n = 512
+    (qu, su), (qv, sv) = _rand_v8(rng, n), _rand_v8(rng, n)
+    a = np.float32(-0.625)
+    r, sr = oracle.v8_scale_and_add(qu, su, qv, sv, float(a))
+    want = oracle.v8_restore(qu, su).astype(np.float64) + float(a) * oracle.v8_restore(qv, sv).astype(np.float64)
+    got = oracle.v8_restore(r, sr)
+    assert np.all(np.abs(got - want) <= np.repeat(sr, 64) / 127.0 + 1e-5)
+    assert np.allclose(sr, np.abs(want.reshape(-1, 64)).max(axis=1), rtol=1e-5)
+
+
+def _threshold8_lowest_index(q, s, n, k):
+    mags = np.abs((q.astype(np.float32) * np.repeat(s, 64)) / np.float32(127.0))[:n]
+    out = q.copy()
+    if k < n:
+        tau = np.sort(mags)[::-1][k - 1] if k > 0 else np.inf
+        keep = mags > tau
+        ties = np.flatnonzero(mags == tau)[: max(k - int(keep.sum()), 0)]
+        keep[ties] = True
+        out[:n] = out[:n] * keep
+    return out
+
+
+@pytest.mark.parametrize("case", [(128, 128, 17), (1000, 1024, 100), (4096, 4096, 1024)])
+def test_oracle_v8_threshold_keeps_the_k_largest(oracle, case):
+    n, npad, k = case
+    rng = np.random.default_rng(n)
+    q, s = _rand_v8(rng, npad)
+    out = oracle.v8_threshold(q, s, n, k)
+    mags = np.abs((q.astype(np.float32) * np.repeat(s, 64)) / np.float32(127.0))
+    kept = (out[:n] != 0) | ((q[:n] == 0) & False)
+    ref = _threshold8_lowest_index(q, s, n, k)
+    assert np.array_equal(out[n:], q[n:])
+    assert np.array_equal(np.sort(mags[:n][kept]), np.sort(mags[:n][ref[:n] != 0]))     # same surviving multiset of magnitudes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 4096, 8192 + 384, (1 << 18) + 128, (1 << 22) + 256])
+def test_gpu_v8_scale_and_add_exact(hip, oracle, n):
+    rng = np.random.default_rng(n + 1)
+    (qu, su), (qv, sv) = _rand_v8(rng, n), _rand_v8(rng, n)
+    qu[:64] = 0
+    qv[:64] = 0
+    for a, in_place in ((-1.0, False), (0.001, True)):
+        r, sr = hip.v8_scale_and_add(qu, su, qv, sv, a, in_place=in_place)
+        ro, sro = oracle.v8_scale_and_add(qu, su, qv, sv, a)
+        assert same(r, ro) and same(sr, sro)
+    assert sr[0] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("segments", [1, 4, 16])
+def test_gpu_v8_scale_and_add_stochastic_every_kernel_shape(hip, oracle, segments):
+    n = 64 * (32 * segments * 5 + 7 * segments + 3)
+    n += (-n) % 128
+    rng = np.random.default_rng(segments + 40)
+    (qu, su), (qv, sv) = _rand_v8(rng, n), _rand_v8(rng, n)
+    assert hip.lib.clvx_set_st_segments(segments) == 0
+    try:
+        st, o = hip.new_rng(7, 8), oracle.rng(7, 8)
+        for in_place in (False, True):
+            r, sr = hip.v8_scale_and_add(qu, su, qv, sv, 0.75, rng=st, in_place=in_place)
+            ro, sro = oracle.v8_scale_and_add(qu, su, qv, sv, 0.75, o)
+            assert same(r, ro) and same(sr, sro)
+        assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
+    finally:
+        hip.lib.clvx_set_st_segments(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(128, 128, 64), (1000, 1024, 64), (2047, 2048, 300), (8192, 8192, 2048), (32768 - 3, 32768, 5000),
+                                  (32768 + 128, 32768 + 128, 999), ((1 << 20) + 77, (1 << 20) + 128, 262144), (512, 512, 0), (512, 512, 511)])
+def test_gpu_v8_threshold_top_k(hip, oracle, case):
+    n, npad, k = case
+    rng = np.random.default_rng(n + k)
+    x = np.zeros(npad, np.float32)
+    x[:n] = rng.integers(-40, 41, size=n)                    # the reference's test data (02_vector.cpp:460): many ties
+    q, s = oracle.v8_quantize(x)
+    out = hip.v8_threshold(q, s, n, k)
+    assert same(out, _threshold8_lowest_index(q, s, n, k))   # the whole output under the lowest-index tie rule
+    ref = oracle.v8_threshold(q, s, n, k)                     # and the reference's heap keeps the same multiset of magnitudes
+    mags = np.abs((q.astype(np.float32) * np.repeat(s, 64)) / np.float32(127.0))[:n]
+    assert np.array_equal(np.sort(mags[out[:n] != 0]), np.sort(mags[ref[:n] != 0]))
+    assert same(hip.v8_threshold(out, s, n, k), out)          # idempotent
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 32768 + 128)])
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_gpu_fused_mixed_mvm_scale_and_add_equals_the_two_calls(hip, oracle, shape, stochastic):
+    M, N = shape
+    rng = np.random.default_rng(M + N + stochastic)
+    qA, sA, x = _inputs(rng, M, N)
+    qx, sx = oracle.v8_quantize(x)
+    qu, su = _rand_v8(rng, M)
+    a = -0.37
+    st, o = (hip.new_rng(31, 41), oracle.rng(31, 41)) if stochastic else (None, None)
+    lib = hip.lib
+    d = [hip.to_device(v) for v in (qA, sA, qx, sx)]
+    for want_t, in_place in ((True, False), (False, False), (True, True)):
+        du, dsu = hip.to_device(qu), hip.to_device(su)
+        dt, dst = (hip.alloc(M), hip.alloc(M // 16)) if want_t else (None, None)
+        dr, dsr = (du, dsu) if in_place else (hip.alloc(M), hip.alloc(M // 16))
+        hip.check(lib.clm4_mvm_v8_scale_and_add(d[0].ptr, d[1].ptr, M, N, d[2].ptr, d[3].ptr, du.ptr, dsu.ptr, a,
+                                                dt.ptr if dt else None, dst.ptr if dst else None, dr.ptr, dsr.ptr,
+                                                st.ptr if st else None, None))
+        to, sto = oracle.m4_mvm_v8(qA, sA, M, N, qx, sx, o)
+        ro, sro = oracle.v8_scale_and_add(qu, su, to, sto, a, o)
+        if want_t:
+            assert same(dt.download(np.int8, M), to) and same(dst.download(np.float32, M // 64), sto)
+        assert same(dr.download(np.int8, M), ro) and same(dsr.download(np.float32, M // 64), sro)
+    if stochastic:
+        assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["iht", "gd", "iht_stochastic"])
+def test_gpu_mixed_iht_loop_matches_oracle_loop(hip, oracle, mode):
+    """clm4_iht_v8 = the reference's published 4-bit IHT / GD configuration (CloverMatrix4 + CloverVector8, 02_bit04.cpp:140)"""
+    rng = np.random.default_rng(12)
+    m, n, K, iters = 256, 512, 64, 4
+    Phi = oracle.m4_quantize(rng.uniform(-1, 1, size=(m, n)).astype(np.float32))
+    PhiT = oracle.m4_transpose(*Phi, m, n)
+    y = oracle.v8_quantize((rng.normal(size=m) * 3).astype(np.float32))
+    thr = mode != "gd"
+    st, o = (hip.new_rng(3, 5), oracle.rng(3, 5)) if mode == "iht_stochastic" else (None, None)
+    x = (np.zeros(n, np.int8), np.ones(n // 64, np.float32))
+    for _ in range(iters):
+        t1 = oracle.m4_mvm_v8(*Phi, m, n, *x, o)
+        t2 = oracle.v8_scale_and_add(*y, *t1, -1.0, o)
+        t3 = oracle.m4_mvm_v8(*PhiT, n, m, *t2, o)
+        x = oracle.v8_scale_and_add(*x, *t3, 0.01, o)
+        if thr:
+            x = (_threshold8_lowest_index(x[0], x[1], n, K), x[1])
+    d = [hip.to_device(v) for v in (*Phi, *PhiT, *y)]
+    bufs = [hip.alloc(k) for k in (n, n // 16, m, m // 16, m, m // 16, n, n // 16)]     # x, sx, t1, st1, t2, st2, t3, st3
+    hip.check(hip.lib.clv_memset(bufs[0].ptr, 0x55, n, None))                           # clm4_iht_v8 must clear x itself
+    hip.check(hip.lib.clm4_iht_v8(d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, m, n, bufs[0].ptr, bufs[1].ptr, n, d[4].ptr, d[5].ptr,
+                                  bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, bufs[5].ptr, bufs[6].ptr, bufs[7].ptr, iters, K, 0.01,
+                                  1 if thr else 0, st.ptr if st else None, None))
+    assert same(bufs[0].download(np.int8, n), x[0]) and same(bufs[1].download(np.float32, n // 64), x[1])
+    assert same(bufs[6].download(np.int8, n), t3[0]) and same(bufs[4].download(np.int8, m), t2[0])
+    if st:
+        assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
