@@ -716,20 +716,22 @@ static inline size_t thresh_small_lds(uint64_t n)
 // thread), radix select in four 8-bit levels straight over the elements (a block has up to 128 distinct magnitudes, so the
 // candidate trick of the 4-bit kernel does not pay), same DPP scans, same lowest-index tie rule.
 #define TS8_MAXW 8
+template <int TS8_W>          // words per thread, compile-time so that the unrolled loops carry no dead slots
 __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restrict__ q, const float *__restrict__ s, uint32_t n, uint32_t k)
 {
     typedef ThreshElems<8> E;
-    __shared__ uint32_t hist[1024];
+    constexpr int COPIES = 8;                      // private histograms by lane & 7: the keys of a vector crowd into a few bins
+    __shared__ uint32_t hist[4 * COPIES * 256];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t sel[2];
     const int tid = threadIdx.x;
     const uint32_t nwords = (n + 3) / 4;
-    const uint32_t W = (nwords + TS_THREADS - 1) / TS_THREADS;          // contiguous words per thread: index order = thread order
+    constexpr uint32_t W = TS8_W;                                     // contiguous words per thread: index order = thread order
     const uint32_t w0 = tid * W;
-    uint32_t words[TS8_MAXW], keys[TS8_MAXW][4];
+    uint32_t words[TS8_W], keys[TS8_W][4];
     uint32_t valid = 0;                                                // bit 4j+e: element e of word j exists (index < n)
 #pragma unroll
-    for (uint32_t j = 0; j < TS8_MAXW; j++) {
+    for (uint32_t j = 0; j < TS8_W; j++) {
         const uint32_t i = w0 + j;
         const bool in = j < W && i < nwords;
         words[j] = in ? q[i] : 0u;
@@ -740,7 +742,8 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
             if (in && i * 4 + e < n) valid |= 1u << (4 * j + e);
         }
     }
-    hist[tid] = 0;
+#pragma unroll
+    for (int i = 0; i < 4 * COPIES * 256 / TS_THREADS; i++) hist[tid + TS_THREADS * i] = 0;
     __syncthreads();
 
     uint32_t tau = 0x7F800000u, keep = 0;
@@ -748,17 +751,21 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
         uint32_t prefix = 0, need = k;
         for (int level = 0; level < 4; level++) {
             const int shift = 24 - 8 * level;
-            uint32_t *h = hist + 256 * level;
+            uint32_t *h = hist + COPIES * 256 * level;
+            uint32_t *hp = h + 256 * (tid & (COPIES - 1));
 #pragma unroll
-            for (uint32_t j = 0; j < TS8_MAXW; j++)
+            for (uint32_t j = 0; j < TS8_W; j++)
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     if ((valid >> (4 * j + e)) & 1u) {
                         const uint32_t key = keys[j][e];
-                        if (level == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&h[(key >> shift) & 0xFFu], 1u);
+                        if (level == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hp[(key >> shift) & 0xFFu], 1u);
                     }
             __syncthreads();
-            const uint32_t mine = tid < 256 ? h[255 - tid] : 0;           // select from the top: thread t < 256 owns bin 255 - t
+            uint32_t mine = 0;                                            // select from the top: thread t < 256 owns bin 255 - t
+            if (tid < 256)
+#pragma unroll
+                for (int cpy = 0; cpy < COPIES; cpy++) mine += h[256 * cpy + 255 - tid];
             uint32_t v = wave_scan_incl(mine);
             if (tid < 256 && (tid & 63) == 63) wsum[tid >> 6] = v;
             __syncthreads();
@@ -778,12 +785,12 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
     }
     uint32_t c = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < TS8_MAXW; j++)
+    for (uint32_t j = 0; j < TS8_W; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++) c += ((valid >> (4 * j + e)) & 1u) && keys[j][e] == tau;
     uint32_t rank = block_scan_incl(c, wsum) - c;               // ties in index order: the first `keep` of them survive
 #pragma unroll
-    for (uint32_t j = 0; j < TS8_MAXW; j++) {
+    for (uint32_t j = 0; j < TS8_W; j++) {
         const uint32_t i = w0 + j;
         if (j < W && i < nwords) {
             uint32_t outw = 0;
@@ -873,7 +880,13 @@ extern "C" int clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
     hipStream_t st = as_stream(stream);
     if (k >= n || n == 0) return CLV_OK;
     if (n_pad <= (uint64_t)TS_THREADS * TS8_MAXW * 4) {
-        hipLaunchKernelGGL(k_thresh8_small, dim3(1), dim3(TS_THREADS), 0, st, (uint32_t *)q, s, (uint32_t)n, (uint32_t)k);
+        const uint64_t w = ((n + 3) / 4 + TS_THREADS - 1) / TS_THREADS;
+#define T8_LAUNCH(W) hipLaunchKernelGGL(k_thresh8_small<W>, dim3(1), dim3(TS_THREADS), 0, st, (uint32_t *)q, s, (uint32_t)n, (uint32_t)k)
+        if (w <= 1) T8_LAUNCH(1);
+        else if (w <= 2) T8_LAUNCH(2);
+        else if (w <= 4) T8_LAUNCH(4);
+        else T8_LAUNCH(8);
+#undef T8_LAUNCH
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
