@@ -5,7 +5,8 @@
 
 One "step" = one mvm of a (N * rows_per_gpu) x cols 4-bit matrix with a 4-bit vector.  Each rank owns a
 contiguous row shard (a multiple of 64 rows) resident in HBM; N > 1 adds one RCCL all-gather of the packed
-result (nibbles + scales) per step -- the only exchange the path has.  Weak scaling: the
+result (nibbles + scales) per step -- the only exchange the path has; it runs on RCCL's stream and
+overlaps the next step's kernel (two result buffers), every step's gather is complete inside the timed region.  Weak scaling: the
 per-GPU shard is fixed (default 65536 x 65536 = BASELINE.json configs[2], "C3"); --rows-per-gpu 131072
 at N=8 is exactly configs[4] ("C5", 2^20 x 2^16).
 
@@ -139,7 +140,7 @@ def main() -> None:
     import torch.distributed as dist
 
     from clover_amd.lib_binding import DOT_EXACT, DOT_FAST, CloverHip
-    from clover_amd.sharding import gather_packed, packed_bytes, partition_rows
+    from clover_amd.sharding import gather_packed, gather_packed_async, packed_bytes, partition_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -183,28 +184,43 @@ def main() -> None:
 
     # packed result of this rank: [rows/2 nibble bytes | rows/64 fp32 scales]; gathered as one buffer
     assert partition_rows(rows_total, world, rank) == (rank * rows, rows)     # weak scaling: equal contiguous shards
-    res = torch.empty(packed_bytes(rows), dtype=torch.uint8, device=dev)
-    r_ptr, sr_ptr = res.data_ptr(), res.data_ptr() + rows // 2
+    # two result buffers: while the gather of step i is in flight on RCCL's stream, step i+1 writes the other one
+    res_bufs = [torch.empty(packed_bytes(rows), dtype=torch.uint8, device=dev) for _ in range(2)]
+    res = res_bufs[0]
+    pending = [None, None]
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step(i: int | None) -> None:
+    def step(i: int | None, n: int) -> None:
+        buf = res_bufs[n & 1]
+        if pending[n & 1] is not None:            # the gather that last read this buffer must be done before it is overwritten
+            pending[n & 1].wait()
+            pending[n & 1] = None
         if i is not None:
             ev[i][0].record()
-        hip.check(lib.clm4_mvm(A.data_ptr(), sA.data_ptr(), rows, cols, x.data_ptr(), sx.data_ptr(), r_ptr, sr_ptr, None, stream))
+        hip.check(lib.clm4_mvm(A.data_ptr(), sA.data_ptr(), rows, cols, x.data_ptr(), sx.data_ptr(), buf.data_ptr(),
+                               buf.data_ptr() + rows // 2, None, stream))
         if i is not None:
             ev[i][1].record()
-        if world > 1:                             # RCCL all-gather of [nibbles | scales] from every rank
-            gather_packed(res.cpu() if debug_one_gpu else res, rows_total)
+        if world > 1:                             # RCCL all-gather of [nibbles | scales] from every rank, overlapping the next step
+            pending[n & 1] = gather_packed_async(buf.cpu() if debug_one_gpu else buf, rows_total)
 
-    for _ in range(args.warmup):
-        step(None)
+    def drain() -> None:                          # every gather has landed (the stream waits; synchronize() follows)
+        for j in (0, 1):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+
+    for w_ in range(args.warmup):
+        step(None, w_)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -253,7 +269,7 @@ def main() -> None:
         "config": {
             "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 (BASELINE configs[2] per GPU), x and result CloverVector4, "
                         f"STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
-            "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of packed result" if world > 1 else ""),
+            "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of every step's packed result, overlapped with the next step" if world > 1 else ""),
             **({"gathered_result_verified": gather_ok} if world > 1 else {}),
             **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all ranks on one GPU, gloo through the host -- not a measurement"} if debug_one_gpu else {}),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),

@@ -26,22 +26,44 @@ def packed_bytes(rows: int) -> int:
     return rows // 2 + 4 * (rows // 64)
 
 
-def gather_packed(local: torch.Tensor, rows_total: int, group=None) -> torch.Tensor:
-    """All-gather the per-rank packed results (uint8 tensors, possibly of different length) in rank order."""
+class PendingGather:
+    """An all-gather in flight (async_op=True).  wait() orders the caller's stream behind it and returns the gathered
+    bytes in rank order; until then neither the input nor the output buffer may be reused."""
+
+    def __init__(self, work, out: torch.Tensor, sizes: list[int], keep_alive):
+        self._work, self._out, self._sizes, self._keep = work, out, sizes, keep_alive
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        mx = max(self._sizes)
+        if len(set(self._sizes)) == 1:
+            return self._out
+        return torch.cat([self._out[k * mx: k * mx + self._sizes[k]] for k in range(len(self._sizes))])
+
+
+def gather_packed_async(local: torch.Tensor, rows_total: int, group=None) -> PendingGather:
+    """Start the all-gather of the per-rank packed results (uint8 tensors, possibly of different length).  On the NCCL (RCCL)
+    backend the collective runs on the communicator's own stream behind the work already queued on the current stream, so
+    the next kernel on the current stream overlaps it."""
     world = dist.get_world_size(group)
     sizes = [packed_bytes(partition_rows(rows_total, world, k)[1]) for k in range(world)]
     assert local.numel() == sizes[dist.get_rank(group)]
-    if len(set(sizes)) == 1:
-        out = torch.empty(sizes[0] * world, dtype=torch.uint8, device=local.device)
-        dist.all_gather_into_tensor(out, local, group=group)
-        return out
-    # unequal shards (rows/64 not divisible by the world size): pad to the largest, gather, drop the pads
     mx = max(sizes)
-    padded = torch.zeros(mx, dtype=torch.uint8, device=local.device)
-    padded[: local.numel()] = local
+    src = local
+    if len(set(sizes)) != 1:
+        # unequal shards (rows/64 not divisible by the world size): pad to the largest, gather, drop the pads in wait()
+        src = torch.zeros(mx, dtype=torch.uint8, device=local.device)
+        src[: local.numel()] = local
     out = torch.empty(mx * world, dtype=torch.uint8, device=local.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
-    return torch.cat([out[k * mx: k * mx + sizes[k]] for k in range(world)])
+    work = dist.all_gather_into_tensor(out, src, group=group, async_op=True)
+    return PendingGather(work, out, sizes, src)
+
+
+def gather_packed(local: torch.Tensor, rows_total: int, group=None) -> torch.Tensor:
+    """All-gather the per-rank packed results in rank order (blocking form of gather_packed_async)."""
+    return gather_packed_async(local, rows_total, group).wait()
 
 
 def unpack_gathered(buf: torch.Tensor, rows_total: int, world: int) -> tuple[torch.Tensor, torch.Tensor]:
