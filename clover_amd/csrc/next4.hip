@@ -335,6 +335,21 @@ extern "C" int clm4_transpose(const int8_t *q, const float *s, uint64_t rows, ui
 //     The kept multiset of magnitudes is identical to the reference's; WHICH of several equal magnitudes
 //     survive is heap-order dependent there and lowest-index-first here.
 // =================================================================================================
+// inclusive scan over the 64 lanes of a wave with DPP moves (no LDS crossbar): Hillis-Steele inside each row of 16,
+// then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+#define DPP_ADD(ctrl, row_mask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xF, false)
+    DPP_ADD(0x111, 0xF);      // row_shr:1
+    DPP_ADD(0x112, 0xF);      // row_shr:2
+    DPP_ADD(0x114, 0xF);      // row_shr:4
+    DPP_ADD(0x118, 0xF);      // row_shr:8
+    DPP_ADD(0x142, 0xA);      // row_bcast:15 -> rows 1, 3
+    DPP_ADD(0x143, 0xC);      // row_bcast:31 -> rows 2, 3
+#undef DPP_ADD
+    return v;
+}
+
 struct ThreshState {
     uint32_t prefix;      // selected high bits so far
     uint32_t remaining;   // how many elements still to take inside the selected bin
@@ -393,33 +408,38 @@ __global__ __launch_bounds__(256) void k_thresh_hist(const uint32_t *__restrict_
     for (int i = threadIdx.x; i < nb; i += 256) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-// one WG: walk the histogram from the top until `remaining` is covered
+// one WG: find, from the top, the bin in which the cumulative count reaches `remaining`; leaves the histogram zeroed
 template <int LEVEL>
 __global__ __launch_bounds__(256) void k_thresh_select(uint32_t *__restrict__ hist, ThreshState *__restrict__ ts, uint32_t k)
 {
-    __shared__ uint32_t part[256];
-    const int nb = LEVEL == 2 ? 256 : 4096;
-    const int per = nb / 256;
+    __shared__ uint32_t wsum[4];
+    constexpr int nb = LEVEL == 2 ? 256 : 4096;
+    constexpr int per = nb / 256;
     const int t = threadIdx.x;
-    uint32_t sum = 0;
-    for (int i = 0; i < per; i++) sum += hist[(255 - t) * per + i];          // thread t owns the t-th chunk from the top
-    part[t] = sum;
+    const int top = (255 - t) * per + per - 1;                   // thread t owns the t-th run of `per` bins from the top
+    uint32_t bins[per], sum = 0;
+#pragma unroll
+    for (int i = 0; i < per; i++) { bins[i] = hist[top - i]; sum += bins[i]; }
+    uint32_t v = wave_scan_incl(sum);
+    if ((t & 63) == 63) wsum[t >> 6] = v;
     __syncthreads();
-    if (t == 0) {
-        const uint32_t need = LEVEL == 0 ? k : ts->remaining;
-        uint32_t above = 0;
-        int c = 0;
-        while (c < 255 && above + part[c] < need) { above += part[c]; c++; }
-        int bin = (255 - c) * per + per - 1;
-        while (bin > (255 - c) * per && above + hist[bin] < need) { above += hist[bin]; bin--; }
+    for (int w = 0; w < (t >> 6); w++) v += wsum[w];
+    const uint32_t need = LEVEL == 0 ? k : ts->remaining;
+    if (v >= need && v - sum < need) {
+        uint32_t above = v - sum;
+        int i = 0;
+#pragma unroll
+        for (int j = 0; j < per - 1; j++)
+            if (i == j && above + bins[j] < need) { above += bins[j]; i = j + 1; }
+        const uint32_t bin = (uint32_t)(top - i);
         const uint32_t prev = LEVEL == 0 ? 0 : ts->prefix;
-        const uint32_t prefix = LEVEL == 0 ? (uint32_t)bin : (LEVEL == 1 ? (prev << 12) | (uint32_t)bin : (prev << 8) | (uint32_t)bin);
+        const uint32_t prefix = LEVEL == 0 ? bin : (LEVEL == 1 ? (prev << 12) | bin : (prev << 8) | bin);
         ts->prefix = prefix;
         ts->remaining = need - above;
         if (LEVEL == 2) { ts->tau = prefix; ts->ties_keep = need - above; }
     }
-    __syncthreads();
-    for (int i = t; i < nb; i += 256) hist[i] = 0;                           // ready for the next level
+#pragma unroll
+    for (int i = 0; i < per; i++) hist[top - i] = 0;             // ready for the next level
 }
 
 // chunked (not grid-stride) so that index order = (block, thread, element)
@@ -452,25 +472,19 @@ __global__ __launch_bounds__(256) void k_thresh_count_ties(const uint32_t *__res
 __global__ __launch_bounds__(256) void k_thresh_scan(uint32_t *__restrict__ block_ties, uint32_t nblocks)
 {
     // exclusive scan by one WG (nblocks is n / 16384: small)
-    __shared__ uint32_t carry;
-    __shared__ uint32_t buf[256];
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    __shared__ uint32_t wsum[4];
+    const int t = threadIdx.x;
+    uint32_t carry = 0;
     for (uint32_t base = 0; base < nblocks; base += 256) {
-        const uint32_t i = base + threadIdx.x;
+        const uint32_t i = base + t;
         const uint32_t v = i < nblocks ? block_ties[i] : 0;
-        buf[threadIdx.x] = v;
+        uint32_t incl = wave_scan_incl(v);
+        __syncthreads();                                         // wsum of the previous round has been read
+        if ((t & 63) == 63) wsum[t >> 6] = incl;
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const uint32_t add = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (i < nblocks) block_ties[i] = carry + buf[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry += buf[255];
-        __syncthreads();
+        for (int w = 0; w < (t >> 6); w++) incl += wsum[w];
+        if (i < nblocks) block_ties[i] = carry + incl - v;
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
@@ -546,21 +560,6 @@ __global__ __launch_bounds__(256) void k_thresh_apply(uint32_t *__restrict__ q, 
 //    operations on the 32-bit word; there is no per-element float work after the selection.
 #define TS_THREADS 1024
 #define TS_MAXW 16
-
-// inclusive scan over the 64 lanes of a wave with DPP moves (no LDS crossbar): Hillis-Steele inside each row of 16,
-// then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
-{
-#define DPP_ADD(ctrl, row_mask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xF, false)
-    DPP_ADD(0x111, 0xF);      // row_shr:1
-    DPP_ADD(0x112, 0xF);      // row_shr:2
-    DPP_ADD(0x114, 0xF);      // row_shr:4
-    DPP_ADD(0x118, 0xF);      // row_shr:8
-    DPP_ADD(0x142, 0xA);      // row_bcast:15 -> rows 1, 3
-    DPP_ADD(0x143, 0xC);      // row_bcast:31 -> rows 2, 3
-#undef DPP_ADD
-    return v;
-}
 
 // inclusive block scan over 1024 threads (wave scan + 16 wave totals)
 __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *wsum)
@@ -806,6 +805,161 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
     }
 }
 
+// ---- large CloverVector4 vectors: the same weighted-candidate idea as k_thresh_small, across kernels ----------------------------
+// One pass turns every 64-element block into its 9 magnitude counts (8 bytes); the three radix levels then run over these
+// tables (12 bytes per block instead of 36 bytes of elements, 9 weighted histogram updates per block instead of 64), the tie
+// counts come from the tables as well, and only the final pass touches the elements again: 2 element passes instead of 5.
+__global__ __launch_bounds__(256) void k_th4_count(const u32x4 *__restrict__ q, uint64_t n, unsigned long long *__restrict__ cnt, uint64_t nblocks,
+                                                   uint32_t *hist, ThreshState *ts)
+{
+    if (blockIdx.x == 0) {                                         // also: a clean slate for the selection passes that follow
+        for (int i = threadIdx.x; i < 4096; i += 256) hist[i] = 0;
+        if (threadIdx.x == 0) *ts = ThreshState{0, 0, 0x7F800000u, 0};         // k == 0 keeps this: tau beyond any magnitude, no ties
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
+        const u32x4 lo = q[2 * b], hi = q[2 * b + 1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t ab = abs_nibbles(swap_nibbles(w[j]));
+            const uint64_t first = b * 64 + 8 * j;
+            const uint32_t valid = first >= n ? 0u : (n - first < 8 ? (uint32_t)(n - first) : 8u);
+#pragma unroll
+            for (uint32_t e = 0; e < 8; e++)
+                if (e < valid) acc += 1ull << (7u * ((ab >> (4 * e)) & 0xFu));
+        }
+        cnt[b] = acc;
+    }
+}
+
+// Radix level over the candidate tables: 12 + 12 + 8 bits (LEVEL 0 = most significant).  Few, fat workgroups: the fixed cost
+// per workgroup (16 KiB of LDS bins to clear and to flush with global atomics, which serialise per address at ~50 ns) is what
+// this kernel costs, not the 12 bytes per block it reads.  (A variant that let the last workgroup to finish do the selection,
+// to save the launches of k_thresh_select, was 6x slower: its one-ticket-per-workgroup atomic serialises the same way.)
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_th4_cand_hist(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
+                                                       const ThreshState *__restrict__ ts, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t lh[4096];
+    constexpr int NB = LEVEL == 2 ? 256 : 4096;
+    for (int i = threadIdx.x; i < NB; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t prefix = LEVEL ? ts->prefix : 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
+        const unsigned long long c = cnt[b];
+        const float s7 = s[b] / 7.0f;
+#pragma unroll
+        for (int m = 0; m <= 8; m++) {
+            const uint32_t wgt = (uint32_t)(c >> (7 * m)) & 0x7Fu;
+            if (wgt) {
+                const uint32_t key = cand_key(s7, m);
+                if (LEVEL == 0) atomicAdd(&lh[key >> 20], wgt);
+                else if (LEVEL == 1) { if ((key >> 20) == prefix) atomicAdd(&lh[(key >> 8) & 0xFFF], wgt); }
+                else { if ((key >> 8) == prefix) atomicAdd(&lh[key & 0xFF], wgt); }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += 256) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// elements of block b equal to tau, from its table
+__device__ __forceinline__ uint32_t th4_block_ties(unsigned long long c, float s7, uint32_t tau)
+{
+    uint32_t t = 0;
+#pragma unroll
+    for (int m = 0; m <= 8; m++) t += cand_key(s7, m) == tau ? (uint32_t)(c >> (7 * m)) & 0x7Fu : 0u;
+    return t;
+}
+
+// workgroup = 256 consecutive blocks = one chunk of k_th4_apply: tie count of the chunk
+__global__ __launch_bounds__(256) void k_th4_chunk_ties(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
+                                                        const ThreshState *__restrict__ ts, uint32_t *__restrict__ chunk_ties)
+{
+    __shared__ uint32_t wsum[4];
+    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t t = b < nblocks ? th4_block_ties(cnt[b], s[b] / 7.0f, ts->tau) : 0u;
+    t = wave_scan_incl(t);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_ties[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// thread = one 64-element block: survivors above tau and the first `keep` ties in index order, whole words at a time
+__global__ __launch_bounds__(256) void k_th4_apply(u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n, uint64_t nblocks,
+                                                   const unsigned long long *__restrict__ cnt, const ThreshState *__restrict__ ts,
+                                                   const uint32_t *__restrict__ chunk_ties)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t tau = ts->tau, keep = ts->ties_keep;
+    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = b < nblocks;
+    const float s7 = in ? s[b] / 7.0f : 1.0f;
+    const uint32_t mine = in ? th4_block_ties(cnt[b], s7, tau) : 0u;
+    const uint32_t incl = wave_scan_incl(mine);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t rank = chunk_ties[blockIdx.x] + incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) rank += wsum[w];
+    if (!in) return;
+    uint32_t lo_t = 0, hi_t = 0;                                   // magnitudes >= hi_t are above tau, [lo_t, hi_t) equal it
+#pragma unroll
+    for (int m = 0; m <= 8; m++) {
+        const uint32_t key = cand_key(s7, m);
+        lo_t += key < tau;
+        hi_t += key <= tau;
+    }
+    const u32x4 lo = q[2 * b], hi = q[2 * b + 1];
+    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t ab = abs_nibbles(swap_nibbles(w[j]));
+        const uint64_t first = b * 64 + 8 * j;
+        const uint32_t valid = first_nibbles(first >= n ? 0u : (n - first < 8 ? (uint32_t)(n - first) : 8u));
+        const uint32_t above = ge_nibbles(ab, hi_t);
+        uint32_t kb = above | (0x88888888u & ~valid);              // padding is left alone
+        uint32_t t = ge_nibbles(ab, lo_t) & ~above & valid;
+        const uint32_t nt = __popc(t), room = keep > rank ? keep - rank : 0;
+        if (room >= nt) kb |= t;
+        else for (uint32_t r = 0; r < room; r++) { kb |= t & (0u - t); t &= t - 1; }
+        rank += nt;
+        w[j] &= swap_nibbles((kb >> 3) * 0xFu);
+    }
+    q[2 * b] = u32x4{w[0], w[1], w[2], w[3]};
+    q[2 * b + 1] = u32x4{w[4], w[5], w[6], w[7]};
+}
+
+// workspace layout: [hist 4096 u32][ThreshState, 256 B][chunk_ties: nblocks/256 + 1 u32, padded to 256 B][cnt: nblocks u64]
+static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, hipStream_t st)
+{
+    const uint64_t nblocks = (n + 63) / 64;
+    const uint32_t nchunks = (uint32_t)((nblocks + 255) / 256);
+    uint32_t *hist = (uint32_t *)workspace;
+    ThreshState *ts = (ThreshState *)(hist + 4096);
+    uint32_t *chunk_ties = (uint32_t *)((char *)ts + 256);
+    unsigned long long *cnt = (unsigned long long *)((char *)chunk_ties + (((uint64_t)(n_pad / 64 / 256 + 1) * 4 + 255) & ~255ull));
+    const uint64_t want = (nblocks + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+    hipLaunchKernelGGL(k_th4_count, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const u32x4 *)q, n, cnt, nblocks, hist, ts);
+    if (k != 0) {
+        const uint64_t hcap = (uint64_t)clv_cu_count();             // one workgroup per CU: see k_th4_cand_hist
+        const dim3 grid((unsigned)(want < hcap ? want : hcap));
+        hipLaunchKernelGGL(k_th4_cand_hist<0>, grid, dim3(256), 0, st, cnt, s, nblocks, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<0>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        hipLaunchKernelGGL(k_th4_cand_hist<1>, grid, dim3(256), 0, st, cnt, s, nblocks, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<1>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        hipLaunchKernelGGL(k_th4_cand_hist<2>, grid, dim3(256), 0, st, cnt, s, nblocks, ts, hist);
+        hipLaunchKernelGGL(k_thresh_select<2>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+    }
+    hipLaunchKernelGGL(k_th4_chunk_ties, dim3(nchunks), dim3(256), 0, st, cnt, s, nblocks, ts, chunk_ties);
+    hipLaunchKernelGGL(k_thresh_scan, dim3(1), dim3(256), 0, st, chunk_ties, nchunks);
+    hipLaunchKernelGGL(k_th4_apply, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
 template <int BITS>
 static int threshold_large(uint32_t *q, const float *s, uint64_t n, uint64_t k, void *workspace, hipStream_t st)
 {
@@ -840,8 +994,8 @@ static int threshold_large(uint32_t *q, const float *s, uint64_t n, uint64_t k, 
 
 extern "C" uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad)
 {
-    const uint64_t blocks = (n_pad / 8 + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK;
-    return 4096 * sizeof(uint32_t) + 256 + blocks * sizeof(uint32_t) + 256;
+    const uint64_t chunk_bytes = ((n_pad / 64 / 256 + 1) * 4 + 255) & ~255ull;
+    return 4096 * sizeof(uint32_t) + 256 + chunk_bytes + (n_pad / 64) * sizeof(unsigned long long) + 256;
 }
 
 extern "C" uint64_t clv8_threshold_workspace_bytes(uint64_t n_pad)
@@ -868,7 +1022,7 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
         int rc = clv_internal_workspace(&workspace, clv4_threshold_workspace_bytes(n_pad));
         if (rc) return rc;
     }
-    return threshold_large<4>((uint32_t *)q, s, n, k, workspace, st);
+    return threshold4_large((uint32_t *)q, s, n, n_pad, k, workspace, st);
 }
 
 // CloverVector8::threshold(K) (CloverVector8.h:1680-1740): same algorithm and tie rule on |q * scale / 127|
