@@ -4,6 +4,8 @@
 // (CloverMatrix4.h:1093-1441), bit-exact in the reference's SIMD order.
 #include "rng_device.h"
 
+#include <stdlib.h>
+
 // =================================================================================================
 // CloverVector8::quantize (CloverVector8.h:393-606), rounding disabled: lane = one float4 in, 4 bytes out; a
 // 64-element block is one DPP row of 16 lanes.  Algorithmic bytes: 4 + 1 + 1/16 per element.
@@ -313,6 +315,73 @@ struct Mvm8Fuse {
     float *sr2;
 };
 
+// LDS tail shared by the two mvm kernels: 64 row dots, then the generator bases and raw draws (ST)
+struct Mvm8Tail {
+    float *dsh;
+    uint64_t *rbase, *raw, *rbase2, *raw2;
+    __device__ __forceinline__ explicit Mvm8Tail(float *p)
+        : dsh(p), rbase(reinterpret_cast<uint64_t *>(p + 64)), raw(rbase + 4), rbase2(raw + 8), raw2(rbase2 + 4) {}
+};
+#define MVM8_TAIL_BYTES (64 * sizeof(float) + 256)
+
+// generator bases for this row group (ST) and its block of u (FUSE), fetched before the streaming loop
+template <bool ST, bool FUSE>
+__device__ __forceinline__ void mvm8_prologue(const Mvm8Tail &t, uint64_t *rng_state, uint64_t seq, const uint64_t *__restrict__ pow_rows,
+                                              const Mvm8Fuse &fuse, int &fuse_q, float &fuse_s)
+{
+    if (ST) {
+        const uint64_t a0 = rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, (FUSE ? 4ull : 2ull) * gridDim.x, t.rbase);
+        if (FUSE) {
+            const uint64_t b2 = wave_pow_apply(pow_rows, a0, (uint64_t)gridDim.x + blockIdx.x, 1);
+            if ((threadIdx.x & 63) == 0) t.rbase2[threadIdx.x >> 6] = b2;
+        }
+    }
+    fuse_q = 0;
+    fuse_s = 0.0f;
+    if (FUSE && threadIdx.x < 64) {
+        fuse_q = fuse.qu[blockIdx.x * 64 + threadIdx.x];
+        fuse_s = fuse.su[blockIdx.x];
+    }
+}
+
+// t.dsh holds the 64 row dots of row group rb (written before the call, no barrier yet): re-quantise to 8 bits
+// (CloverMatrix4.h:1246-1440; noise group g = l>>3 (draw g>>2, byte g&3), word W[l&7]) and, with FUSE, scaleAndAdd
+template <bool ST, bool FUSE>
+__device__ __forceinline__ void mvm8_epilogue(const Mvm8Tail &t, uint64_t rb, int8_t *r, float *sr, const Mvm8Fuse &fuse, int fuse_q, float fuse_s)
+{
+    const int tid = threadIdx.x;
+    if (ST && tid < 4) {
+        gen_blocks(t.rbase[tid], 1, t.raw, tid);
+        if (FUSE) gen_blocks(t.rbase2[tid], 1, t.raw2, tid);
+    }
+    __syncthreads();
+    if ((r || FUSE) && tid < 64) {
+        const float d = t.dsh[tid];
+        float noise = 0.0f;
+        if (ST) {
+            const int g = tid >> 3, j = tid & 7;
+            noise = noise_of(reinterpret_cast<const uint32_t *>(t.raw + (size_t)(g >> 2) * 4)[j], g & 3);
+        }
+        float mx = wave_max(__builtin_fabsf(d));
+        mx = fix_zero_max(mx);
+        const int qv = quant1(d, 127.0f / mx, noise);
+        if (r) {
+            r[rb * 64 + tid] = (int8_t)qv;
+            if (tid == 0) sr[rb] = mx;
+        }
+        if (FUSE) {
+            // CloverVector8::scaleAndAdd on this block (CloverVector8.h:1089-1358); element l: draw l>>5, byte l&3, word (l&31)>>2
+            const float val = __builtin_fmaf((float)qv, (mx * fuse.a) / 127.0f, (float)fuse_q * (fuse_s / 127.0f));
+            float noise2 = 0.0f;
+            if (ST) noise2 = noise_of(reinterpret_cast<const uint32_t *>(t.raw2 + (size_t)(tid >> 5) * 4)[(tid & 31) >> 2], tid & 3);
+            float m2 = wave_max(__builtin_fabsf(val));
+            m2 = fix_zero_max(m2);
+            fuse.r2[rb * 64 + tid] = (int8_t)quant1(val, 127.0f / m2, noise2);
+            if (tid == 0) fuse.sr2[rb] = m2;
+        }
+    }
+}
+
 template <int U, bool NT, bool ST, bool FUSE>
 __global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
                                                  const int8_t *__restrict__ x, const float *__restrict__ sx, float *__restrict__ d_out,
@@ -322,23 +391,11 @@ __global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4 *xs = reinterpret_cast<u32x4 *>(smem);                         // MVM8_CHUNK bytes of int8
     float *cs = reinterpret_cast<float *>(smem + MVM8_CHUNK);            // MVM8_CHUNK/64 floats
-    float *dsh = cs + MVM8_CHUNK / 64;                                   // 64 floats
-    uint64_t *rbase = reinterpret_cast<uint64_t *>(dsh + 64);            // ST: 4 lane bases, 8 raw draws (twice with FUSE)
-    uint64_t *raw = rbase + 4;
-    uint64_t *rbase2 = raw + 8, *raw2 = rbase2 + 4;
-    if (ST) {
-        const uint64_t a0 = rng_workgroup_begin(rng_state, seq, pow_rows, blockIdx.x, 1, (FUSE ? 4ull : 2ull) * gridDim.x, rbase);
-        if (FUSE) {
-            const uint64_t b2 = wave_pow_apply(pow_rows, a0, (uint64_t)gridDim.x + blockIdx.x, 1);
-            if ((threadIdx.x & 63) == 0) rbase2[threadIdx.x >> 6] = b2;
-        }
-    }
-    int fuse_q = 0;                                                     // FUSE: this row group's block of u, fetched early
-    float fuse_s = 0.0f;
-    if (FUSE && threadIdx.x < 64) {
-        fuse_q = fuse.qu[blockIdx.x * 64 + threadIdx.x];
-        fuse_s = fuse.su[blockIdx.x];
-    }
+    const Mvm8Tail tail(cs + MVM8_CHUNK / 64);
+    float *dsh = tail.dsh;
+    int fuse_q;
+    float fuse_s;
+    mvm8_prologue<ST, FUSE>(tail, rng_state, seq, pow_rows, fuse, fuse_q, fuse_s);
 
     const uint64_t rb = blockIdx.x;
     const int tid = threadIdx.x;
@@ -413,37 +470,7 @@ __global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ 
         dsh[rho] = dot;
         if (d_out) d_out[row] = dot;
     }
-    if (ST && tid < 4) {
-        gen_blocks(rbase[tid], 1, raw, tid);
-        if (FUSE) gen_blocks(rbase2[tid], 1, raw2, tid);
-    }
-    __syncthreads();
-    if ((r || FUSE) && tid < 64) {
-        // re-quantise the 64 row dots to 8 bits (:1246-1440); noise group g = l>>3 (draw g>>2, byte g&3), word W[l&7]
-        const float d = dsh[tid];
-        float noise = 0.0f;
-        if (ST) {
-            const int g = tid >> 3, j = tid & 7;
-            noise = noise_of(reinterpret_cast<const uint32_t *>(raw + (size_t)(g >> 2) * 4)[j], g & 3);
-        }
-        float mx = wave_max(__builtin_fabsf(d));
-        mx = fix_zero_max(mx);
-        const int qv = quant1(d, 127.0f / mx, noise);
-        if (r) {
-            r[rb * 64 + tid] = (int8_t)qv;
-            if (tid == 0) sr[rb] = mx;
-        }
-        if (FUSE) {
-            // CloverVector8::scaleAndAdd on this block (CloverVector8.h:1089-1358); element l: draw l>>5, byte l&3, word (l&31)>>2
-            const float val = __builtin_fmaf((float)qv, (mx * fuse.a) / 127.0f, (float)fuse_q * (fuse_s / 127.0f));
-            float noise2 = 0.0f;
-            if (ST) noise2 = noise_of(reinterpret_cast<const uint32_t *>(raw2 + (size_t)(tid >> 5) * 4)[(tid & 31) >> 2], tid & 3);
-            float m2 = wave_max(__builtin_fabsf(val));
-            m2 = fix_zero_max(m2);
-            fuse.r2[rb * 64 + tid] = (int8_t)quant1(val, 127.0f / m2, noise2);
-            if (tid == 0) fuse.sr2[rb] = m2;
-        }
-    }
+    mvm8_epilogue<ST, FUSE>(tail, rb, r, sr, fuse, fuse_q, fuse_s);
 }
 
 // =================================================================================================
@@ -536,7 +563,7 @@ extern "C" int clv8_scale_and_add(const int8_t *qu, const float *su, const int8_
 static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx, float *d,
                        int8_t *r, float *sr, uint64_t *rng, hipStream_t st, const Mvm8Fuse *fuse = nullptr)
 {
-    const size_t lds = MVM8_CHUNK + (MVM8_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 256;
+    const size_t lds = MVM8_CHUNK + (MVM8_CHUNK / 64) * sizeof(float) + MVM8_TAIL_BYTES;
     const dim3 grid((unsigned)(rows / 64)), block(256);
     RngTables T = {nullptr, nullptr};
     uint64_t seq = 0;
@@ -555,6 +582,10 @@ static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t
         if (fuse) M8_LAUNCH_F(NT, ST, true);          \
         else M8_LAUNCH_F(NT, ST, false);              \
     } while (0)
+    // (A matrix-core variant for matrices with few row groups -- v_mfma_i32_16x16x64_i8 with x masked per fma chain in the B
+    //  columns, so that C[row][chain] is the chain's block integer -- was built and was bit-exact, but slower: 16.4 us against
+    //  11.2 us at 4096 x 8192.  hipcc copies every MFMA result out of the accumulation registers right behind the MFMA, which
+    //  serialises the blocks at MFMA latency; not worth hand-scheduling for this kernel.  r01.)
     if (streaming) {
         if (rng) M8_LAUNCH(true, true); else M8_LAUNCH(true, false);
     } else {
