@@ -145,7 +145,7 @@ def test_error_convention_and_layout_without_gpu(tmp_path):
     subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "error_behaviour.cpp"),
                     "-o", str(exe), f"-L{lib.parent}", "-lclover_hip", f"-Wl,-rpath,{lib.parent}", "-L/opt/rocm/lib",
                     "-Wl,-rpath,/opt/rocm/lib"], check=True)
-    for case, msg in (("mvm", "MVM can not be performed. Exiting ..."), ("quantize", "Matrices do not have the same size. Exiting ..."),
+    for case, msg in (("mvm", "MVM can not be performed. Exiting ..."), ("mvm8", "MVM can not be performed. Exiting ..."), ("quantize", "Matrices do not have the same size. Exiting ..."),
                       ("transpose", "Matrix can not be transposed. Exiting ...")):
         p = subprocess.run([str(exe), case], capture_output=True, text=True)
         assert p.returncode == 1 and msg in p.stdout and "not reached" not in p.stdout
