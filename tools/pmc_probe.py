@@ -26,5 +26,19 @@ for _ in range(3):
     hip.check(lib.clvx_read_bw(A.ptr, A.nbytes, 1, 16, out.ptr, None))
 for _ in range(5):
     hip.check(lib.clm4_mvm(A.ptr, sA.ptr, rows, cols, x.ptr, sx.ptr, r.ptr, sr.ptr, None, None))
+# the other streaming kernels at n = 2^30 / 32768^2, three launches each (same passes, traffic vs algorithmic bytes)
+n = 1 << 30
+xf = hip.alloc(4 * n)
+hip.check(lib.clv_fill_random_ints_f32(xf.ptr, n, 10, 5, 0, None))
+q4, s4, q8 = hip.alloc(n // 2), hip.alloc(n // 16), hip.alloc(n)
+x8 = hip.alloc(cols)
+hip.check(lib.clv_fill_random_nibbles(x8.ptr, x8.nbytes, 9, 0, None))
+r8 = hip.alloc(rows)
+for _ in range(3):
+    hip.check(lib.clv4_quantize(xf.ptr, n, q4.ptr, s4.ptr, None, None))
+    hip.check(lib.clm4_quantize(xf.ptr, 32768, 32768, q4.ptr, s4.ptr, None, None))
+    hip.check(lib.clv8_quantize(xf.ptr, n, q8.ptr, s4.ptr, None, None))
+    hip.check(lib.clv4_restore(q4.ptr, s4.ptr, n, xf.ptr, None))
+    hip.check(lib.clm4_mvm_v8(A.ptr, sA.ptr, rows, cols, x8.ptr, sx.ptr, r8.ptr, sr.ptr, None, None))
 hip.sync()
 print("pmc probe done")
