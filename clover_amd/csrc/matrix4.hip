@@ -340,6 +340,43 @@ __global__ __launch_bounds__(256) void k_m4_gemm_simple(const uint8_t *__restric
 }
 
 // ================================================================================================
+// restore  (CloverMatrix4::restore_scalar, CloverMatrix4.h:266-301):  A[i][j] = f32(s_tile / 7) * q
+// lane = one output float4 (two lanes share an input dword), as in k_v4_restore; the scale comes from the 64x64 tile
+// ================================================================================================
+template <bool NT>
+__global__ __launch_bounds__(256) void k_m4_restore(const uint32_t *__restrict__ q, const float *__restrict__ s, f32x4 *__restrict__ A,
+                                                    uint64_t nquads, uint64_t cols)
+{
+    const uint64_t f0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 256;
+    const int lane = threadIdx.x & 63;
+    const uint64_t tiles_x = cols / 64;
+    uint32_t wd[4];
+    float sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t f = f0 + 64 * j + lane, fc = f < nquads ? f : 0;
+        const uint64_t e = fc * 4, row = e / cols, col = e - row * cols;
+        wd[j] = q[fc >> 1];
+        sc[j] = s[(row >> 6) * tiles_x + (col >> 6)];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t f = f0 + 64 * j + lane;
+        const uint32_t hw = wd[j] >> (16 * (lane & 1));         // the 4 nibbles of this half (f and lane have the same parity)
+        const float k = sc[j] / 7.0f;
+        f32x4 v;
+        v.x = (float)(((int)(hw << 24)) >> 28) * k;
+        v.y = (float)(((int)(hw << 28)) >> 28) * k;
+        v.z = (float)(((int)(hw << 16)) >> 28) * k;
+        v.w = (float)(((int)(hw << 20)) >> 28) * k;
+        if (f < nquads) {
+            if (NT) __builtin_nontemporal_store(v, &A[f]);
+            else A[f] = v;
+        }
+    }
+}
+
+// ================================================================================================
 // C ABI
 // ================================================================================================
 int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng, hipStream_t st);
@@ -457,6 +494,24 @@ static int check_mvm_args(const char *fn, const void *A, const void *sA, uint64_
     CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "%s: rows=%llu cols=%llu must be multiples of 128", fn,
                 (unsigned long long)rows, (unsigned long long)cols);
     CLV_REQUIRE(rows / 64 <= 0x7FFFFFFFull, "%s: too many rows", fn);
+    return CLV_OK;
+}
+
+extern "C" int clm4_restore(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, float *A, void *stream)
+{
+    CLV_REQUIRE(A && q && s, "clm4_restore: null pointer");
+    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "clm4_restore: rows=%llu cols=%llu must be multiples of 128", (unsigned long long)rows,
+                (unsigned long long)cols);
+    if (!rows || !cols) return CLV_OK;
+    const uint64_t nquads = rows * cols / 4, waves = (nquads + 255) / 256;
+    CLV_REQUIRE((waves + 3) / 4 <= 0x7FFFFFFFull, "clm4_restore: matrix too large");
+    if (rows * cols * sizeof(float) > (256ull << 20))
+        hipLaunchKernelGGL(k_m4_restore<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), (const uint32_t *)q, s,
+                           (f32x4 *)A, nquads, cols);
+    else
+        hipLaunchKernelGGL(k_m4_restore<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), (const uint32_t *)q, s,
+                           (f32x4 *)A, nquads, cols);
+    CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "clv4_dot": (C.c_int, [_vp, _vp, _vp, _vp, _u64, C.c_int, _vp, _vp, _vp]),
     "clv4_word_isums": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "clm4_quantize": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "clm4_restore": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "clm4_mvm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clm4_rowdots": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clm4_gemm": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp]),
@@ -226,6 +227,11 @@ class CloverHip:
         dq, ds = self.alloc(max(rows * cols // 2, 1)), self.alloc(max((rows // 64) * (cols // 64) * 4, 4))
         self.check(self.lib.clm4_quantize(dA.ptr, rows, cols, dq.ptr, ds.ptr, rng.ptr if rng else None, None))
         return dq.download(np.uint8, rows * cols // 2), ds.download(np.float32, (rows // 64) * (cols // 64))
+
+    def m4_restore(self, q, s, rows, cols) -> np.ndarray:
+        dq, ds, dA = self.to_device(q), self.to_device(s), self.alloc(max(4 * rows * cols, 4))
+        self.check(self.lib.clm4_restore(dq.ptr, ds.ptr, rows, cols, dA.ptr, None))
+        return dA.download(np.float32, rows * cols).reshape(rows, cols)
 
     def m4_mvm(self, qA, sA, rows, cols, qx, sx, rng: DevBuf | None = None):
         b = [self.to_device(a) for a in (qA, sA, qx, sx)]

@@ -72,6 +72,17 @@ public:
     }
     void quantize_scalar(const CloverMatrix32 &m) { quantize(m); }
 
+    /* CloverMatrix4.h:266-301 (the reference has only the scalar variant) */
+    void restore_scalar(CloverMatrix32 &other) const
+    {
+        if (other.getRows() != rows || other.getCols() != cols) {
+            std::cout << "Matrices do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        clover_hip::check(clm4_restore(dev_values(), dev_scales(), rows, cols, other.device_wo(), nullptr), "CloverMatrix4::restore");
+    }
+    void restore(CloverMatrix32 &other) const { restore_scalar(other); }
+
     void mvm(const CloverVector4 &productVector, CloverVector4 &resultVector)
     {
         if (productVector.size() != getCols()) {

@@ -104,6 +104,8 @@ int  clv4_word_isums(const int8_t *qu, const int8_t *qv, uint64_t n_pad, int32_t
  * order (column-block outer, row-block inner, two draws per tile row). */
 int  clm4_quantize(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s,
                    uint64_t *rng_state_dev, void *stream);
+/* CloverMatrix4::restore_scalar (CloverMatrix4.h:266-301): A[i][j] = f32(s_tile/7) * q, rows*cols floats row-major */
+int  clm4_restore(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, float *A, void *stream);
 /* CloverMatrix4::mvm(const CloverVector4&, CloverVector4&) (CloverMatrix4.h:777-1083) and mvm_parallel
  * (:1681-2006; same results).  x: cols/2 bytes + cols/64 scales; r: rows/2 bytes + rows/64 scales
  * (the re-quantised result).  Bit-identical to the reference when rng_state_dev == NULL. */

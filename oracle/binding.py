@@ -121,6 +121,11 @@ class Oracle:
                                C.byref(rng) if rng is not None else None)
         return q, s
 
+    def m4_restore(self, q, s, rows, cols) -> np.ndarray:
+        A = np.zeros(rows * cols, np.float32)
+        self.L.orc_m4_restore(_p(q, _u8p), _p(s, _fp), _u64(rows), _u64(cols), _p(A, _fp))
+        return A.reshape(rows, cols)
+
     def m4_get(self, q, s, rows, cols, i, j) -> np.float32:
         return np.float32(self.L.orc_m4_get(_p(q, _u8p), _p(s, _fp), _u64(rows), _u64(cols), _u64(i), _u64(j)))
 

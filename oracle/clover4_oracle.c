@@ -276,6 +276,20 @@ void orc_m4_quantize(const float *A, uint64_t rows, uint64_t cols, uint8_t *q, f
     }
 }
 
+void orc_m4_restore(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, float *A)
+{
+    const uint64_t hb = cols >> 6;
+    for (uint64_t i = 0; i < rows; i++)
+        for (uint64_t b = 0; b < hb; b++) {
+            const float sc = s[(i >> 6) * hb + b] / 7.0f;                 /* :284 */
+            for (uint64_t k = 0; k < 32; k++) {
+                const uint8_t v = q[(i * cols + 64 * b) / 2 + k];
+                A[i * cols + 64 * b + 2 * k]     = sc * (float)nib_hi(v);
+                A[i * cols + 64 * b + 2 * k + 1] = sc * (float)nib_lo(v);
+            }
+        }
+}
+
 float orc_m4_get(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, uint64_t i, uint64_t j)
 {
     (void)rows;

@@ -57,6 +57,8 @@ double   orc_v4_dot_f64(const uint8_t *qu, const float *su, const uint8_t *qv, c
 /* CloverMatrix4::quantize (CloverMatrix4.h:512-766). Tile order for the rng: column-block outer. */
 void     orc_m4_quantize(const float *A, uint64_t rows, uint64_t cols, uint8_t *q, float *s, orc_rng *rng);
 /* CloverMatrix4::get (CloverMatrix4.h:123-139). */
+/* CloverMatrix4::restore_scalar (CloverMatrix4.h:266-301): A[i][j] = f32(s_tile / 7) * q */
+void     orc_m4_restore(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, float *A);
 float    orc_m4_get(const uint8_t *q, const float *s, uint64_t rows, uint64_t cols, uint64_t i, uint64_t j);
 /* fp32 row dots of mvm before the re-quantisation (CloverMatrix4.h:804-916): d[r], r=0..rows-1. */
 void     orc_m4_rowdots(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,

@@ -172,6 +172,20 @@ def test_gemm_bit_exact(hip, oracle, shape):
     assert same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N))
 
 
+@pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 640)])
+def test_matrix_restore_exact(hip, oracle, shape):
+    """CloverMatrix4::restore_scalar (CloverMatrix4.h:266-301)"""
+    M, N = shape
+    rng = np.random.default_rng(M + 3 * N)
+    qA, _ = random_packed(rng, M * N)
+    sA = rng.uniform(0.5, 2.0, size=(M // 64) * (N // 64)).astype(np.float32)
+    A = hip.m4_restore(qA, sA, M, N)
+    Ao = oracle.m4_restore(qA, sA, M, N)
+    assert same(A, Ao)
+    for (i, j) in ((0, 0), (63, 64), (64, 63), (M - 1, N - 1), (100, N - 127)):      # and the element accessor agrees (get: :123-139)
+        assert A[i, j] == oracle.m4_get(qA, sA, M, N, i, j)
+
+
 # ---------------------------------------------------------------- stochastic rounding: same XORShift stream
 @pytest.mark.parametrize("n", [128, 1024, 8192 + 128, (1 << 17) + 384])
 def test_stochastic_vector_quantize_same_stream(hip, oracle, n):
