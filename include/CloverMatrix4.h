@@ -46,6 +46,10 @@ public:
     uint64_t getBitsLength() const { return 4; }
     uint64_t getBytes() const { return value_bytes + (rows >> 6) * (cols >> 6) * sizeof(float); }
 
+    /* host views of the packed values and of the tile scales (the reference keeps them protected; exposed for interop) */
+    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
+    float *getScales() const { return reinterpret_cast<float *>(mem.host_rw() + value_bytes); }
+
     float get(uint64_t i, uint64_t j) const
     {
         const uint8_t *h = mem.host_ro();
@@ -193,6 +197,8 @@ public:
                           "CloverMatrix4::mvm");
     }
     void mvm_parallel(const CloverVector32 &productVector, CloverVector32 &resultVector) { mvm(productVector, resultVector); }
+    /* the reference's scalar variant accumulates in double (:423-432); the SIMD order is used here */
+    void mvm_scalar(const CloverVector32 &productVector, CloverVector32 &resultVector) { mvm(productVector, resultVector); }
 
     /* other = this^T  (CloverMatrix4.h:1549-1663; _parallel :2508-2640; _scalar :435-502) */
     void transpose(CloverMatrix4 &other) const
@@ -207,6 +213,7 @@ public:
     }
     void transpose_parallel(CloverMatrix4 &other) const { transpose(other); }
     void transpose_scalar(CloverMatrix4 &other) const { transpose(other); }
+    void transpose_scalar_faster(CloverMatrix4 &other) const { transpose(other); }      /* CloverMatrix4.h:2649-2799 */
 
     /* C = this * B^T, fp32: this is M x K, B is N x K, C is M x N (build-defined) */
     void gemm(const CloverMatrix4 &B, CloverMatrix32 &C) const
