@@ -132,6 +132,26 @@ __device__ __forceinline__ uint32_t quant_pack4(const f32x4 v, float k)
     return k < __builtin_inff() ? h : 0u;       // see quant_pack8
 }
 
+// 4x4 transpose of dwords inside every quad of lanes (m = lane & 3): lane m ends with component m of lanes 0..3, i.e. after four
+// lanes loaded 64 contiguous bytes as one dwordx4 each, lane m holds words m, 4+m, 8+m, 12+m.  Two DPP exchanges, 16 VALU.
+__device__ __forceinline__ void quad_transpose4(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3, int m)
+{
+    {   // bit 0: (lane j, comp i) <-> (lane j^1, comp i^1) where the low bits differ
+        const bool b = m & 1;
+        const uint32_t s0 = b ? v0 : v1, s1 = b ? v2 : v3;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+        v0 = b ? r0 : v0; v1 = b ? v1 : r0; v2 = b ? r1 : v2; v3 = b ? v3 : r1;
+    }
+    {   // bit 1
+        const bool b = m & 2;
+        const uint32_t s0 = b ? v0 : v2, s1 = b ? v1 : v3;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0x4E, 0xF, 0xF, false);
+        v0 = b ? r0 : v0; v1 = b ? r1 : v1; v2 = b ? v2 : r0; v3 = b ? v3 : r1;
+    }
+}
+
 // signed nibble e of word w
 __device__ __forceinline__ int unpack1(uint32_t w, int e)
 {

@@ -263,24 +263,6 @@ __global__ __launch_bounds__(256) void k_v8_scale_and_add_st(const u32x4 *qu, co
 // =================================================================================================
 #define MVM8_CHUNK 32768u
 
-__device__ __forceinline__ void quad_transpose4(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3, int m)
-{
-    {   // bit 0: (lane j, comp i) <-> (lane j^1, comp i^1) where the low bits differ
-        const bool b = m & 1;
-        const uint32_t s0 = b ? v0 : v1, s1 = b ? v2 : v3;
-        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
-        v0 = b ? r0 : v0; v1 = b ? v1 : r0; v2 = b ? r1 : v2; v3 = b ? v3 : r1;
-    }
-    {   // bit 1
-        const bool b = m & 2;
-        const uint32_t s0 = b ? v0 : v2, s1 = b ? v1 : v3;
-        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0x4E, 0xF, 0xF, false);
-        v0 = b ? r0 : v0; v1 = b ? r1 : v1; v2 = b ? v2 : r0; v3 = b ? v3 : r1;
-    }
-}
-
 // 8 nibbles of a dword (elements e0..e7) -> int8 dwords {e0..e3} and {e4..e7}, each value times 16
 __device__ __forceinline__ void widen8(uint32_t w, uint32_t &d03, uint32_t &d47)
 {

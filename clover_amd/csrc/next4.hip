@@ -1099,19 +1099,23 @@ extern "C" int clm4_iht(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
 // =================================================================================================
 // f4'  mixed precision CloverMatrix4::mvm(const CloverVector32 &, CloverVector32 &) (CloverMatrix4.h:1451-1547)
 //      fp32 vector in, fp32 row dots out.  The reference keeps 4 accumulators x 8 AVX lanes = 32 sequential
-//      fma chains per row; chain (e mod 32) takes elements e, e+32, ...  Lane = (row, a = word index mod 4):
-//      it owns the 8 chains of accumulator a and walks every fourth word of its row; x lives in LDS as fp32
-//      (16384-column chunks = 64 KiB).  Products are f32((float)q * f32(s/7)) * x with one fma, as there.
+//      fma chains per row; chain (e mod 32) takes elements e, e+32, ...  Lane = (row, a = word index mod 4) owns the 8
+//      chains of accumulator a.  The four lanes of a row load 64 contiguous bytes (one dwordx4 each) and transpose the
+//      4x4 dwords inside the quad, which leaves lane a with words a, 4+a, 8+a, 12+a: its next four words.  x lives in
+//      LDS as fp32 (16384-column chunks = 64 KiB) together with f32(s/7) per block.  Products are
+//      f32((float)q * f32(s/7)) * x with one fma, as there.
 // =================================================================================================
 #define MVF_CHUNK 16384u
 
-__global__ __launch_bounds__(256) void k_m4_mvm_f32(const uint32_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
+template <bool NT>
+__global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
                                                     const float *__restrict__ x, float *__restrict__ r)
 {
-    extern __shared__ __attribute__((aligned(16))) float mvf_x[];        // MVF_CHUNK floats
+    extern __shared__ __attribute__((aligned(16))) float mvf_x[];        // MVF_CHUNK floats of x, then MVF_CHUNK/64 block factors
+    float *s7 = mvf_x + MVF_CHUNK;
     const int tid = threadIdx.x, a = tid & 3, rho = tid >> 2;
     const uint64_t row = (uint64_t)blockIdx.x * 64 + rho;
-    const uint32_t *Arow = A + row * (cols / 8);
+    const u32x4 *Arow = A + row * (cols / 32);
     const float *su = sA + (uint64_t)blockIdx.x * (cols / 64);
     float acc[8];
 #pragma unroll
@@ -1119,27 +1123,44 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const uint32_t *__restrict__
     for (uint64_t c0 = 0; c0 < cols; c0 += MVF_CHUNK) {
         const uint32_t cw = (uint32_t)((cols - c0) < MVF_CHUNK ? (cols - c0) : MVF_CHUNK);
         if (c0) __syncthreads();
-        for (uint32_t i = tid; i < cw / 4; i += 256) reinterpret_cast<f32x4 *>(mvf_x)[i] = reinterpret_cast<const f32x4 *>(x + c0)[i];
-        __syncthreads();
-        const uint32_t nwords = cw / 8;                                   // this lane takes words a, a+4, a+8, ...
-        const uint32_t *Ap = Arow + c0 / 8;
-        for (uint32_t w0 = 0; w0 < nwords; w0 += 32) {                    // 8 words per lane and step (cw is a multiple of 128)
-            uint32_t wd[8];
+        {   // stage x and s/7: all loads first (one round trip), then the LDS writes
+            constexpr int NX = MVF_CHUNK / 4 / 256;                       // 16 x 16 B per thread
+            f32x4 xr[NX];
+            const uint32_t nx = cw / 4, nb = cw / 64;
 #pragma unroll
-            for (int u = 0; u < 8; u++) wd[u] = (w0 + 4 * u + a < nwords) ? Ap[w0 + 4 * u + a] : 0;
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; xr[k] = reinterpret_cast<const f32x4 *>(x + c0)[i < nx ? i : 0]; }
+            const float sv = su[c0 / 64 + (tid < nb ? tid : 0)];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t w = w0 + 4 * u + a;
-                if (w < nwords) {
-                    const float sc = su[(c0 + 8 * (uint64_t)w) >> 6] / 7.0f;
-                    const f32x4 xl = reinterpret_cast<const f32x4 *>(mvf_x)[2 * w];
-                    const f32x4 xh = reinterpret_cast<const f32x4 *>(mvf_x)[2 * w + 1];
-                    const float xv[8] = {xl.x, xl.y, xl.z, xl.w, xh.x, xh.y, xh.z, xh.w};
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(xv[j], (float)unpack1(wd[u], j) * sc, acc[j]);
-                }
-            }
+            for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) reinterpret_cast<f32x4 *>(mvf_x)[i] = xr[k]; }
+            if (tid < nb) s7[tid] = sv / 7.0f;
         }
+        __syncthreads();
+        const u32x4 *Ap = Arow + c0 / 32;
+        const uint32_t ngroups = cw / 128;                                // 16 words = 128 columns per quad and step
+        constexpr int U = 4;
+        auto group = [&](const u32x4 av, uint32_t g) {
+            uint32_t w[4] = {av.x, av.y, av.z, av.w};
+            quad_transpose4(w[0], w[1], w[2], w[3], a);                   // words a, 4+a, 8+a, 12+a of group g
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t wi = 16 * g + 4 * i + a;                   // word index inside the chunk
+                const float sc = s7[wi >> 3];
+                const f32x4 xl = reinterpret_cast<const f32x4 *>(mvf_x)[2 * wi];
+                const f32x4 xh = reinterpret_cast<const f32x4 *>(mvf_x)[2 * wi + 1];
+                const float xv[8] = {xl.x, xl.y, xl.z, xl.w, xh.x, xh.y, xh.z, xh.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(xv[j], (float)unpack1(w[i], j) * sc, acc[j]);     // rounded product first
+            }
+        };
+        uint32_t g = 0;
+        for (; g + U <= ngroups; g += U) {
+            u32x4 av[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) av[u] = NT ? __builtin_nontemporal_load(&Ap[4 * (g + u) + a]) : Ap[4 * (g + u) + a];
+#pragma unroll
+            for (int u = 0; u < U; u++) group(av[u], g + u);
+        }
+        for (; g < ngroups; g++) group(NT ? __builtin_nontemporal_load(&Ap[4 * g + a]) : Ap[4 * g + a], g);
     }
     // (acc1 + acc2) + (acc3 + acc4) per AVX lane j, then the CloverBase.h:149-157 tree over the 8 lanes
     float s3[8];
@@ -1159,8 +1180,15 @@ extern "C" int clm4_mvm_f32(const int8_t *A, const float *sA, uint64_t rows, uin
     CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0 && rows / 64 <= 0x7FFFFFFFull, "clm4_mvm_f32: rows=%llu cols=%llu must be multiples of 128",
                 (unsigned long long)rows, (unsigned long long)cols);
     if (!rows) return CLV_OK;
-    const size_t lds = MVF_CHUNK * sizeof(float);
-    hipLaunchKernelGGL(k_m4_mvm_f32, dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), (const uint32_t *)A, sA, cols, x, r);
+    const size_t lds = (MVF_CHUNK + MVF_CHUNK / 64) * sizeof(float);                     // 65 KiB
+    const dim3 grid((unsigned)(rows / 64));
+    if (rows * (cols / 2) > (256ull << 20)) {
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_mvm_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_m4_mvm_f32<true>, grid, dim3(256), lds, as_stream(stream), (const u32x4 *)A, sA, cols, x, r);
+    } else {
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_mvm_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_m4_mvm_f32<false>, grid, dim3(256), lds, as_stream(stream), (const u32x4 *)A, sA, cols, x, r);
+    }
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

@@ -105,6 +105,11 @@ hip.check(lib.clv_fill_random_nibbles(x8.ptr, x8.nbytes, 11, 0, None))          
 mvb8 = M * N // 2 + 4 * (M // 64) * (N // 64) + (N + N // 16) + (M + M // 16)
 rec("mvm_v8_32768^2", mvb8, lambda: hip.check(lib.clm4_mvm_v8(qA.ptr, sA.ptr, M, N, x8.ptr, sx.ptr, r8.ptr, sr.ptr, None, None)))
 rec("mvm_v8_stochastic_32768^2", mvb8, lambda: hip.check(lib.clm4_mvm_v8(qA.ptr, sA.ptr, M, N, x8.ptr, sx.ptr, r8.ptr, sr.ptr, rngm.ptr, None)))
+# ---- mixed precision: 4-bit matrix x fp32 vector (fp32 row dots out)
+xf32, rf32 = hip.alloc(4 * N), hip.alloc(4 * M)
+hip.check(lib.clv_fill_random_ints_f32(xf32.ptr, N, 10, 12, 0, None))
+rec("mvm_f32_32768^2", M * N // 2 + 4 * (M // 64) * (N // 64) + 4 * N + 4 * M,
+    lambda: hip.check(lib.clm4_mvm_f32(qA.ptr, sA.ptr, M, N, xf32.ptr, rf32.ptr, None)))
 # ---- the headline shape, 65536 x 65536 (2 GiB of nibbles): 4-bit and mixed mvm side by side
 del A, qT, sT
 M2 = N2 = 65536
