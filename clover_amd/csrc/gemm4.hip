@@ -63,7 +63,13 @@ __device__ __forceinline__ void unpack32(const u32x4 p, u32x4 &s0, u32x4 &s1)
 }
 
 // KBS = K-blocks per LDS stage (one barrier per stage), MINW = occupancy target in waves per SIMD
-template <int KBS, int MINW, bool PINGPONG>
+// PACKED: the LDS tile keeps the nibbles packed (32 bytes per row and K-block instead of 64): half the LDS write traffic
+// (the 13-cycle ds_write_b128 was as expensive as all fragment reads), 8-byte fragment reads, and the widening to int8 moves
+// behind the read (two ANDs and a shift per dword; K order inside a lane's 16 bytes = [e0 e2 e4 e6 | e1 e3 e5 e7 | ...],
+// the same for A and B).  8-byte slots are XOR-swizzled with bit 3 of the row so that a ds_read_b64 lane group is conflict-free.
+// Measured (r01): 0.90 ms against 0.81 ms for the int8 tile at 8192^3 -- every wave now widens its own fragments, the four
+// waves that share an A fragment do it four times, and the kernel becomes VALU-bound.  Kept for A/B (CLV_GEMM_VARIANT=4).
+template <int KBS, int MINW, bool PINGPONG, bool PACKED = false>
 __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__restrict__ A, const float *__restrict__ sA,
                                                          const uint8_t *__restrict__ B, const float *__restrict__ sB,
                                                          uint64_t M, uint64_t N, uint64_t K, float *__restrict__ C,
@@ -71,7 +77,8 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int GM_KB_PER_STAGE = KBS;
-    constexpr int GM_STAGE_BYTES = 2 * KBS * GM_TILE * 64;     // A + B as int8
+    constexpr int GM_ROW_BYTES = PACKED ? 32 : 64;             // per row and K-block in LDS
+    constexpr int GM_STAGE_BYTES = 2 * KBS * GM_TILE * GM_ROW_BYTES;     // A + B
     constexpr int NP = KBS / 2;                                // 16-byte pieces per thread, operand and stage
 
     // ---- tile assignment: XCD-aware (block b runs on XCD b % 8): give each XCD a contiguous range of tiles,
@@ -114,6 +121,10 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
         char *base = smem + buf * GM_STAGE_BYTES;
         auto put = [&](char *tile, int row, int piece, const u32x4 p) {
             const int kb = piece >> 1, half = piece & 1;
+            if (PACKED) {
+                *reinterpret_cast<u32x4 *>(tile + (kb * GM_TILE + row) * 32 + ((half ^ ((row >> 3) & 1)) << 4)) = p;
+                return;
+            }
             u32x4 s0, s1;
             unpack32(p, s0, s1);
             char *r = tile + (kb * GM_TILE + row) * 64;
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
             const int idx = tid + 512 * p;
             const int row = idx / (2 * KBS), piece = idx % (2 * KBS);
             put(base, row, piece, pa[p]);
-            put(base + GM_KB_PER_STAGE * GM_TILE * 64, row, piece, pb[p]);
+            put(base + GM_KB_PER_STAGE * GM_TILE * GM_ROW_BYTES, row, piece, pb[p]);
         }
     };
 
@@ -193,17 +204,19 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
     // MFMA->VALU dependency is covered by the other resident waves.  The fragments of K-block kb+1 are requested
     // from LDS right after the MFMAs of kb were issued, so their latency hides behind the fold of kb.
     i32x4 fa[4], fb[2];
+    auto frag = [&](const char *tile, int kb, int row) -> i32x4 {
+        if (PACKED) {
+            const u32x2 p = *reinterpret_cast<const u32x2 *>(tile + (kb * GM_TILE + row) * 32 + ((fkg ^ (((row >> 3) & 1) << 1)) << 3));
+            const uint32_t Mk = 0xF0F0F0F0u;
+            return i32x4{(int)(p.x & Mk), (int)((p.x << 4) & Mk), (int)(p.y & Mk), (int)((p.y << 4) & Mk)};
+        }
+        return *reinterpret_cast<const i32x4 *>(tile + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
+    };
     auto load_frags = [&](const char *tA, const char *tB, int kb) {
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const int row = wr * 64 + a * 16 + frow;
-            fa[a] = *reinterpret_cast<const i32x4 *>(tA + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
-        }
+        for (int a = 0; a < 4; a++) fa[a] = frag(tA, kb, wr * 64 + a * 16 + frow);
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int row = wc * 32 + b * 16 + frow;
-            fb[b] = *reinterpret_cast<const i32x4 *>(tB + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
-        }
+        for (int b = 0; b < 2; b++) fb[b] = frag(tB, kb, wc * 32 + b * 16 + frow);
     };
     auto mfma_all = [&]() {
 #pragma unroll
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
         const int buf = (int)(st & 1);
         if (st + 1 < nstages) fetch(st + 1);
         const char *tA = smem + buf * GM_STAGE_BYTES;
-        const char *tB = tA + GM_KB_PER_STAGE * GM_TILE * 64;
+        const char *tB = tA + GM_KB_PER_STAGE * GM_TILE * GM_ROW_BYTES;
         const uint64_t blk = st * GM_KB_PER_STAGE;
 #pragma unroll
         for (int kb = 0; kb < KBS; kb += 2) {
@@ -293,16 +306,19 @@ int clm4_gemm_mfma(const int8_t *A, const float *sA, uint64_t M, uint64_t K, con
     const uint32_t tiles_m = (uint32_t)(M / GM_TILE), tiles_n = (uint32_t)(N / GM_TILE);
     static const int variant = [] { const char *e = getenv("CLV_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     const bool kbs4 = (variant & 1) && (K % 256 == 0);
-    const size_t lds = 2 * (size_t)(2 * (kbs4 ? 4 : 2) * GM_TILE * 64);
-#define GM_LAUNCH(KBS, MINW, PP)                                                                                                  \
+    const bool packed = (variant & 4) != 0;                   // A/B only: measured slower (0.90 vs 0.81 ms at 8192^3), see the PACKED note
+    const size_t lds = 2 * (size_t)(2 * (kbs4 ? 4 : 2) * GM_TILE * ((packed && !kbs4 && !(variant & 2)) ? 32 : 64));
+#define GM_LAUNCH(KBS, MINW, PP, ...)                                                                                             \
     do {                                                                                                                          \
-        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_mfma<KBS, MINW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_m4_gemm_mfma<KBS, MINW, PP>), dim3(tiles_m * tiles_n), dim3(512), lds, st, (const uint8_t *)A, sA,    \
-                           (const uint8_t *)B, sB, M, N, K, C, tiles_m, tiles_n);                                                \
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_mfma<KBS, MINW, PP, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                                   \
+        hipLaunchKernelGGL((k_m4_gemm_mfma<KBS, MINW, PP, ##__VA_ARGS__>), dim3(tiles_m * tiles_n), dim3(512), lds, st,            \
+                           (const uint8_t *)A, sA, (const uint8_t *)B, sB, M, N, K, C, tiles_m, tiles_n);                          \
     } while (0)
     // default = single result set, 4 waves/SIMD (1.30 POP/s at 8192^3); variants kept for A/B runs (r01 notes)
     if (kbs4) GM_LAUNCH(4, 2, true);
     else if (variant & 2) GM_LAUNCH(2, 2, true);
+    else if (packed) GM_LAUNCH(2, 4, false, true);
     else GM_LAUNCH(2, 4, false);
 #undef GM_LAUNCH
     CLV_LAUNCH_CHECK();
