@@ -23,6 +23,9 @@
  *  - results: bit-identical to the reference's AVX2 path when stochastic rounding is disabled
  *    (rng == NULL); with an rng state the same XORShift stream as the reference's sequential methods is
  *    consumed (bit-identical nibbles for identical keys).  Exceptions are spelled out per function.
+ *  - asynchrony: every call only enqueues work on `stream`; results are valid after clv_stream_sync / an event.
+ *    clv4_dot and the threshold functions use a per-device scratch buffer when `workspace` is NULL: give each stream
+ *    its own workspace (clv4_dot_workspace_bytes / clv*_threshold_workspace_bytes) if calls on different streams may overlap.
  */
 #ifndef CLOVER_HIP_H
 #define CLOVER_HIP_H
