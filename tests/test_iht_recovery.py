@@ -1,0 +1,52 @@
+"""End to end: the quantized IHT loop does what it is for.  The reference's problem generator (test/performance/03_iht_gd_util.cpp:
+449-495): Phi uniform(-1,1), a K-sparse x of ones, y = Phi x in fp32; then Q_IHT entirely on the GPU.  No reference output to
+compare with (its experiments search mu and report quality curves) -- the assertion is that the sparse support comes back."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(m, n, K, seed):
+    rng = np.random.default_rng(seed)
+    Phi = rng.uniform(-1, 1, size=(m, n)).astype(np.float32)
+    x = np.zeros(n, np.float32)
+    x[rng.permutation(n)[:K]] = 1.0
+    return Phi, x, Phi @ x
+
+
+@pytest.mark.parametrize("vectors", ["8bit", "4bit"])
+def test_quantized_iht_recovers_the_sparse_support(hip, vectors):
+    m, n, K, iters, mu = 1024, 2048, 32, 60, 1.0 / 1024
+    Phi, x_true, y = _problem(m, n, K, 7)
+    lib = hip.lib
+    dPhi = hip.to_device(Phi)
+    qPhi, sPhi = hip.alloc(m * n // 2), hip.alloc((m // 64) * (n // 64) * 4)
+    hip.check(lib.clm4_quantize(dPhi.ptr, m, n, qPhi.ptr, sPhi.ptr, None, None))
+    qPhiT, sPhiT = hip.alloc(m * n // 2), hip.alloc((m // 64) * (n // 64) * 4)
+    hip.check(lib.clm4_transpose(qPhi.ptr, sPhi.ptr, m, n, qPhiT.ptr, sPhiT.ptr, None))
+    dy = hip.to_device(y)
+    xr = hip.alloc(4 * n)
+    if vectors == "8bit":                                   # the reference's published "4-bit" configuration
+        qy, sy = hip.alloc(m), hip.alloc(m // 16)
+        hip.check(lib.clv8_quantize(dy.ptr, m, qy.ptr, sy.ptr, None, None))
+        b = [hip.alloc(k) for k in (n, n // 16, m, m // 16, m, m // 16, n, n // 16)]
+        hip.check(lib.clm4_iht_v8(qPhi.ptr, sPhi.ptr, qPhiT.ptr, sPhiT.ptr, m, n, b[0].ptr, b[1].ptr, n, qy.ptr, sy.ptr, b[2].ptr, b[3].ptr,
+                                  b[4].ptr, b[5].ptr, b[6].ptr, b[7].ptr, iters, K, mu, 1, None, None))
+        hip.check(lib.clv8_restore(b[0].ptr, b[1].ptr, n, xr.ptr, None))
+    else:
+        qy, sy = hip.alloc(m // 2), hip.alloc(m // 16)
+        hip.check(lib.clv4_quantize(dy.ptr, m, qy.ptr, sy.ptr, None, None))
+        b = [hip.alloc(k) for k in (n // 2, n // 16, m // 2, m // 16, m // 2, m // 16, n // 2, n // 16)]
+        hip.check(lib.clm4_iht(qPhi.ptr, sPhi.ptr, qPhiT.ptr, sPhiT.ptr, m, n, b[0].ptr, b[1].ptr, n, qy.ptr, sy.ptr, b[2].ptr, b[3].ptr,
+                               b[4].ptr, b[5].ptr, b[6].ptr, b[7].ptr, iters, K, mu, 1, None, None))
+        hip.check(lib.clv4_restore(b[0].ptr, b[1].ptr, n, xr.ptr, None))
+    x = xr.download(np.float32, n)
+    assert np.count_nonzero(x) <= K
+    hit = len(set(np.argsort(-np.abs(x))[:K].tolist()) & set(np.flatnonzero(x_true).tolist()))
+    err = float(np.linalg.norm(x - x_true) / np.linalg.norm(x_true))
+    print(f"{vectors}: support {hit}/{K}, relative error {err:.3f}")
+    if vectors == "8bit":
+        assert hit >= K - 1 and err < 0.25
+    else:
+        assert hit >= K - 2 and err < 0.35     # 15 levels per block are coarse for the iterate; the support still comes back
