@@ -50,3 +50,46 @@ def test_quantized_iht_recovers_the_sparse_support(hip, vectors):
         assert hit >= K - 1 and err < 0.25
     else:
         assert hit >= K - 2 and err < 0.35     # 15 levels per block are coarse for the iterate; the support still comes back
+
+
+@pytest.mark.parametrize("vectors", ["8bit", "4bit"])
+def test_quantized_gd_recovers_the_sign_vector(hip, vectors):
+    """Q_GD on the reference's GD problem (03_iht_gd_util.cpp:497-536): row-normalised Phi (1.5 n x n), x in {-1,+1}^n, y = Phi x;
+    step size 0.4 as in test/accuracy/00_accuracy.cpp:97"""
+    n, iters, mu = 1024, 40, 0.4
+    m = 3 * n // 2
+    rng = np.random.default_rng(11)
+    Phi = rng.uniform(-1, 1, size=(m, n)).astype(np.float32)
+    Phi /= np.linalg.norm(Phi, axis=1, keepdims=True)
+    x_true = np.where(rng.uniform(-1, 1, n) < 0, -1.0, 1.0).astype(np.float32)
+    y = Phi @ x_true
+    lib = hip.lib
+    dPhi = hip.to_device(Phi)
+    qPhi, sPhi = hip.alloc(m * n // 2), hip.alloc((m // 64) * (n // 64) * 4)
+    hip.check(lib.clm4_quantize(dPhi.ptr, m, n, qPhi.ptr, sPhi.ptr, None, None))
+    qPhiT, sPhiT = hip.alloc(m * n // 2), hip.alloc((m // 64) * (n // 64) * 4)
+    hip.check(lib.clm4_transpose(qPhi.ptr, sPhi.ptr, m, n, qPhiT.ptr, sPhiT.ptr, None))
+    dy = hip.to_device(y)
+    xr = hip.alloc(4 * n)
+    if vectors == "8bit":
+        qy, sy = hip.alloc(m), hip.alloc(m // 16)
+        hip.check(lib.clv8_quantize(dy.ptr, m, qy.ptr, sy.ptr, None, None))
+        b = [hip.alloc(k) for k in (n, n // 16, m, m // 16, m, m // 16, n, n // 16)]
+        hip.check(lib.clm4_iht_v8(qPhi.ptr, sPhi.ptr, qPhiT.ptr, sPhiT.ptr, m, n, b[0].ptr, b[1].ptr, n, qy.ptr, sy.ptr, b[2].ptr, b[3].ptr,
+                                  b[4].ptr, b[5].ptr, b[6].ptr, b[7].ptr, iters, 0, mu, 0, None, None))
+        hip.check(lib.clv8_restore(b[0].ptr, b[1].ptr, n, xr.ptr, None))
+    else:
+        qy, sy = hip.alloc(m // 2), hip.alloc(m // 16)
+        hip.check(lib.clv4_quantize(dy.ptr, m, qy.ptr, sy.ptr, None, None))
+        b = [hip.alloc(k) for k in (n // 2, n // 16, m // 2, m // 16, m // 2, m // 16, n // 2, n // 16)]
+        # truncation toward zero swallows the small updates of a 15-level iterate: all-4-bit GD needs the stochastic rounding
+        # the reference builds with by default (and even so the reference runs its "4-bit" experiments with 8-bit vectors)
+        st = hip.new_rng(2024, 4202)
+        hip.check(lib.clm4_iht(qPhi.ptr, sPhi.ptr, qPhiT.ptr, sPhiT.ptr, m, n, b[0].ptr, b[1].ptr, n, qy.ptr, sy.ptr, b[2].ptr, b[3].ptr,
+                               b[4].ptr, b[5].ptr, b[6].ptr, b[7].ptr, iters, 0, mu, 0, st.ptr, None))
+        hip.check(lib.clv4_restore(b[0].ptr, b[1].ptr, n, xr.ptr, None))
+    x = xr.download(np.float32, n)
+    agree = float(np.mean(np.sign(x) == x_true))
+    err = float(np.linalg.norm(x - x_true) / np.linalg.norm(x_true))
+    print(f"{vectors}: signs recovered {agree:.3f}, relative error {err:.3f}")
+    assert agree >= (0.97 if vectors == "8bit" else 0.85)
