@@ -567,7 +567,9 @@ static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t
     // (A matrix-core variant for matrices with few row groups -- v_mfma_i32_16x16x64_i8 with x masked per fma chain in the B
     //  columns, so that C[row][chain] is the chain's block integer -- was built and was bit-exact, but slower: 16.4 us against
     //  11.2 us at 4096 x 8192.  hipcc copies every MFMA result out of the accumulation registers right behind the MFMA, which
-    //  serialises the blocks at MFMA latency; not worth hand-scheduling for this kernel.  r01.)
+    //  serialises the blocks at MFMA latency; not worth hand-scheduling for this kernel.  Also tried: 8 lanes per row, one fma
+    //  chain per lane (same loads, each lane widens half of every word): 13.2 us -- a SIMD issues one wave64 VALU instruction
+    //  per 4 cycles however many waves it holds, so what counts is total VALU work per SIMD, and that variant has more.  r01.)
     if (streaming) {
         if (rng) M8_LAUNCH(true, true); else M8_LAUNCH(true, false);
     } else {
