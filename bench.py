@@ -68,18 +68,31 @@ def cpu_baseline_child(path: str) -> None:
         if threads > rows // 64:
             continue
         F.set_threads(threads)
-        F.m4_mvm(d["qA"], d["sA"], rows, cols, d["qx"], d["sx"], out=out)     # warm-up
+        qA = F.first_touch_copy(d["qA"], rows)          # NUMA placement for this thread count (threads are bound: OMP_PROC_BIND)
+        F.m4_mvm(qA, d["sA"], rows, cols, d["qx"], d["sx"], out=out)     # warm-up
         ts = []
         t_end = time.perf_counter() + 4.0
         while len(ts) < 15 and (time.perf_counter() < t_end or len(ts) < 3):
             t0 = time.perf_counter()
-            F.m4_mvm(d["qA"], d["sA"], rows, cols, d["qx"], d["sx"], out=out)
+            F.m4_mvm(qA, d["sA"], rows, cols, d["qx"], d["sx"], out=out)
             ts.append(time.perf_counter() - t0)
         med = sorted(ts)[len(ts) // 2]
         if best is None or med < best[0]:
             best = (med, threads)
     match = bool(np.array_equal(out[0], d["r"]) and np.array_equal(out[1].view(np.uint32), d["sr"].view(np.uint32)))
-    print(json.dumps({"seconds": best[0], "threads": best[1], "gpu_result_matches_cpu": match}))
+    # the other half of BASELINE's metric: dot (the reference's sequential `dot`, one core) on two vectors cut out of the sample
+    dot = None
+    n = 1 << 24
+    if d["qA"].size >= n and d["sA"].size >= n // 64:
+        qu, qv, sc = d["qA"][: n // 2], d["qA"][n // 2: n], d["sA"][: n // 64]
+        F.v4_dot(qu, sc, qv, sc)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            F.v4_dot(qu, sc, qv, sc)
+            ts.append(time.perf_counter() - t0)
+        dot = {"n": n, "seconds": sorted(ts)[2]}
+    print(json.dumps({"seconds": best[0], "threads": best[1], "gpu_result_matches_cpu": match, "dot": dot}))
 
 
 def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sample_rows: int) -> dict:
@@ -101,6 +114,13 @@ def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sampl
                              capture_output=True, text=True, timeout=600).stdout
     res = json.loads(out.strip().splitlines()[-1])
     nbytes = mvm_bytes(sample_rows, cols)
+    quota = "no cgroup cpu quota"
+    try:
+        mx, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if mx != "max":
+            quota = f"cgroup cpu quota {int(mx) / int(period):g} cpus (short bursts run wider)"
+    except (OSError, ValueError):
+        pass
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -112,8 +132,12 @@ def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sampl
     return {
         "value": round(nbytes / res["seconds"] / 1e9, 3), "unit": "GB/s", "cores": res["threads"], "kind": "port",
         "sample": f"mvm of the first {sample_rows} rows x {cols} cols of the same matrix ({nbytes} B), median of <=15 runs, "
-                  f"AVX2+OpenMP restatement (oracle/clover4_fast.c) on {cpu_model}, host has {os.cpu_count()} cpus",
+                  f"AVX2+OpenMP restatement (oracle/clover4_fast.c, bound threads, NUMA first-touch placement, best of 1/16/64/half/all "
+                  f"threads) on {cpu_model}, {os.cpu_count()} cpus, {quota}",
         "ms": round(res["seconds"] * 1e3, 3), "gpu_result_matches_cpu": res["gpu_result_matches_cpu"],
+        **({"dot": {"value": round(1.125 * res["dot"]["n"] / res["dot"]["seconds"] / 1e9, 3), "unit": "GB/s", "cores": 1,
+                    "sample": f"CloverVector4::dot order (sequential, as the reference's dot), n = {res['dot']['n']}, median of 5"}}
+           if res.get("dot") else {}),
     }
 
 
@@ -125,7 +149,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows-per-gpu", type=int, default=65536)
     ap.add_argument("--cols", type=int, default=65536)
-    ap.add_argument("--cpu-sample-rows", type=int, default=16384)
+    ap.add_argument("--cpu-sample-rows", type=int, default=32768,
+                    help="rows of the matrix the CPU baseline multiplies (32768 x 65536 = 1 GiB of nibbles: beyond the 2 x 256 MB of L3 "
+                         "of the host, so the number is a DRAM number like the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)

@@ -217,6 +217,12 @@ class FastOracle:
     def set_threads(self, n: int) -> None:
         self.L.orcf_set_threads(C.c_int(n))
 
+    def first_touch_copy(self, A: np.ndarray, rows: int) -> np.ndarray:
+        """a copy of the packed matrix whose pages were first touched by the threads that will read them in m4_mvm"""
+        out = np.empty(A.size, np.uint8)                 # np.empty does not touch the pages
+        self.L.orcf_first_touch_copy(_p(out, _u8p), _p(A, _u8p), _u64(rows), _u64(A.size // rows))
+        return out
+
     def v4_quantize(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         n = x.size

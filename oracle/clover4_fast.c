@@ -147,6 +147,15 @@ void orcf_v4_quantize(const float *x, uint64_t n_pad, uint8_t *q, float *s)
     }
 }
 
+/* copy a matrix into `dst` with the SAME static partition orcf_m4_mvm uses, so that with bound threads every thread's row
+ * groups land in its own NUMA node's memory (first touch) -- what a tuned CPU run of the reference would arrange */
+void orcf_first_touch_copy(uint8_t *dst, const uint8_t *src, uint64_t rows, uint64_t row_bytes)
+{
+    const int64_t groups = (int64_t)(rows / 64);
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < groups; g++) memcpy(dst + (uint64_t)g * 64 * row_bytes, src + (uint64_t)g * 64 * row_bytes, 64 * row_bytes);
+}
+
 void orcf_m4_mvm(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols,
                  const uint8_t *x, const float *sx, uint8_t *r, float *sr)
 {
