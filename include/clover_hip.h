@@ -79,7 +79,8 @@ int  clv_event_elapsed_ms(void *start, void *stop, float *ms);
  * Initialise it with clv_rng_seed() (reproduces avx_xorshift128plus_init(key1, key2) on the host and uploads
  * it) or clv_rng_set() (explicit keys, CloverRandom::setRandomKeys); never write the buffer directly.
  * Calls that share a state must be ordered (same stream, or synchronised) -- they consume one sequential
- * stream -- and must not be captured into a hipGraph (each call carries a fresh launch stamp). */
+ * stream -- and must not be captured into a hipGraph (each call carries a fresh launch stamp).  A state belongs to the
+ * process that initialised it (the stamps come from a per-process counter): re-key with clv_rng_set after sharing a buffer. */
 #define CLV_RNG_STATE_BYTES 256
 int  clv_rng_seed(uint64_t *state_dev, uint64_t key1, uint64_t key2, void *stream);
 int  clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const uint64_t key2[4], void *stream);
