@@ -43,3 +43,31 @@ def test_error_codes_without_compute():
     assert b"multiples of 128" in lib.clv_last_error()
     n = ctypes.c_int(-1)
     assert lib.clv_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+
+
+def _build_c_program(tmp_path):
+    import subprocess
+    lib = build_hip_library()
+    exe = tmp_path / "abi_from_c"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", f"-I{repo_root() / 'include'}", str(repo_root() / "tests" / "c" / "abi_from_c.c"),
+                    "-o", str(exe), f"-L{lib.parent}", "-lclover_hip", f"-Wl,-rpath,{lib.parent}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """the drop-in boundary is C: gcc -std=c99 -pedantic compiles a client of include/clover_hip.h and links it to the library"""
+    import subprocess
+    exe = _build_c_program(tmp_path)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and ("dot=256.0" in p.stdout or "no_device" in p.stdout), (p.returncode, p.stdout, p.stderr)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_c_client_gets_the_readme_answer_on_the_gpu(tmp_path):
+    import subprocess
+    p = subprocess.run([str(_build_c_program(tmp_path))], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "dot=256.0" in p.stdout, (p.returncode, p.stdout, p.stderr)
