@@ -1,19 +1,19 @@
 // vector4.hip -- CloverVector4 hot path on gfx950: quantize, restore, dot (exact order / fast), word sums.
 //
 // Data layout in HBM = the reference's (CloverVector4.h:68-103): n_pad/2 value bytes (element 2i in the
-// high nibble of byte i), one fp32 scale per 64 elements.  One output dword = 8 consecutive elements,
-// so the natural unit of work is "lane = 8 elements": 8 lanes form a 64-element block and the block
-// maximum is a 3-step xor-shuffle inside that 8-lane group; nothing goes through LDS.
+// high nibble of byte i), one fp32 scale per 64 elements.  The streaming kernels map a lane to one float4 of the fp32
+// side, so that every wave-wide load or store instruction covers one contiguous KiB; a 64-element block is then one DPP
+// row of 16 lanes (block maximum by row rotations) and nothing goes through LDS.  Work is cut into fixed chunks, one per
+// wave (wave_chunks), not into one long span per resident wave.
 #include "common.h"
 
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // quantize (rounding disabled): CloverVector4.h:605-807 with rnd_* == 0
-//   per lane: 32 B in (2 x dwordx4), 4 B out; per wave: 2 KiB in, 256 B + 8 scales out.
 //   algorithmic bytes: 4.5625 per element.
 // ------------------------------------------------------------------------------------------------
-// one output word (8 elements, 8 lanes per block) from two float4
+// tail path (a chunk that is not a whole main-loop step): lane = 8 elements = one output dword from two float4, 8 lanes per block
 __device__ __forceinline__ void quantize_word(const f32x4 a, const f32x4 b, uint64_t i, uint32_t *__restrict__ q, float *__restrict__ s)
 {
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
