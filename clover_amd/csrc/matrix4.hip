@@ -232,10 +232,7 @@ __global__ __launch_bounds__(64 * L) void k_m4_mvm64(const uint8_t *__restrict__
 // ================================================================================================
 // quantize  (CloverMatrix4.h:512-766, rounding disabled)
 // ================================================================================================
-// workgroup = one 64x64 tile (256 threads); thread = (row r = tid>>3 [+32 on the second pass],
-// octet o = tid&7) holds 8 consecutive values = one output dword.  Pass 1 reduces the tile maximum
-// (registers -> wave shuffle -> LDS); pass 2 quantises from the registers, nothing is re-read.
-// workgroup = 64 rows x 256 columns = 4 tiles side by side (256 threads, 64 floats each).  A wave-instruction reads
+// k_m4_quantize_strip (the one in use): workgroup = 64 rows x 256 columns = 4 tiles side by side (256 threads, 64 floats each).  A wave-instruction reads
 // one contiguous KiB of a row (lane = float4); lanes 16t..16t+15 -- one DPP row -- belong to tile t, so the tile maximum
 // is a per-lane maximum over the wave's 16 rows, a row rotation reduce and a 4-wave combine in LDS.  A lane quantises
 // half a dword; lane pairs swap halves between two consecutive rows so that every lane stores a whole dword and a row
@@ -277,6 +274,9 @@ __global__ __launch_bounds__(256) void k_m4_quantize_strip(const float *__restri
     }
 }
 
+// k_m4_quantize (the first kernel of the round, kept behind CLV_M4Q_TILE=1 for A/B): workgroup = one 64x64 tile (256 threads);
+// thread = (row r = tid>>3 [+32 on the second pass], octet o = tid&7) holds 8 consecutive values = one output dword.  Pass 1
+// reduces the tile maximum (registers -> wave shuffle -> LDS); pass 2 quantises from the registers, nothing is re-read.
 __global__ __launch_bounds__(256) void k_m4_quantize(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
                                                      float *__restrict__ s, uint32_t tiles_x)
 {

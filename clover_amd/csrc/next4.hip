@@ -1,11 +1,12 @@
-// next4.hip -- the callers either side of the hot path: scaleAndAdd, transpose, threshold.
+// next4.hip -- the callers either side of the hot path: scaleAndAdd, transpose, threshold (CloverVector4, and the
+// large-vector / CloverVector8 threshold), the IHT / GD loop, and the mixed 4-bit x fp32 mvm.
 // Together with mvm these are all five steps of the reference's quantized IHT / GD iterations
 // (test/performance/01_measure.h:923-946, 999-1021), so x, t1..t3 can stay in HBM across iterations.
 #include "rng_device.h"
 
 // =================================================================================================
 // f1  CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478):  r = quantize(u + a * v), per 64-block
-//     val = fma((float)qv, f32(f32(sv*a)/7), (float)qu * f32(su/7));  lane = one dword of u and of v.
+//     val = fma((float)qv, f32(f32(sv*a)/7), (float)qu * f32(su/7));  lane = 4 dwords (half a block) of u and of v.
 //     algorithmic bytes: 3 * (1/2 + 1/16) = 1.6875 per element.
 // =================================================================================================
 __device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, float sv7, float v[8])
