@@ -10,7 +10,7 @@ import shutil
 import subprocess
 from pathlib import Path
 
-HIP_SOURCES = ["runtime.hip", "vector4.hip", "matrix4.hip", "rng4.hip", "gemm4.hip", "multi.hip", "next4.hip", "mixed8.hip"]
+HIP_SOURCES = ["runtime.hip", "vector4.hip", "matrix4.hip", "rng4.hip", "gemm4.hip", "gemm6.hip", "multi.hip", "next4.hip", "mixed8.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # the reference's arithmetic is a fixed sequence of separately rounded fp32 ops + explicit fmas:

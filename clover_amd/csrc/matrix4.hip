@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void k_m4_restore(const uint32_t *__restrict__
 // ================================================================================================
 int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s, uint64_t *rng, hipStream_t st);
 int clm4_gemm_mfma(const int8_t *A, const float *sA, uint64_t M, uint64_t K, const int8_t *B, const float *sB, uint64_t N, float *C, hipStream_t st);
+int clm4_gemm_fp6(const int8_t *A, const float *sA, uint64_t M, uint64_t K, const int8_t *B, const float *sB, uint64_t N, float *C, hipStream_t st);
 
 #define MVM_LDS_BYTES (MVM_CHUNK / 2 + (MVM_CHUNK / 64) * sizeof(float) + 64 * sizeof(float) + 256)
 
@@ -581,8 +582,10 @@ extern "C" int clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t 
     CLV_REQUIRE(M % 128 == 0 && N % 128 == 0 && K % 128 == 0, "clm4_gemm: M=%llu N=%llu K=%llu must be multiples of 128",
                 (unsigned long long)M, (unsigned long long)N, (unsigned long long)K);
     if (!M || !N) return CLV_OK;
-    static const bool use_simple = [] { const char *e = getenv("CLV_GEMM_KERNEL"); return e && !strcmp(e, "simple"); }();
-    if (!use_simple && K > 0) return clm4_gemm_mfma(A, sA, M, K, B, sB, N, C, as_stream(stream));
+    // CLV_GEMM_KERNEL (A/B runs): "i8" = the int8 MFMA kernel of gemm4.hip, "simple" = the scalar check kernel
+    static const int which = [] { const char *e = getenv("CLV_GEMM_KERNEL"); return !e ? 0 : !strcmp(e, "simple") ? 2 : !strcmp(e, "i8") ? 1 : 0; }();
+    if (which == 0 && K > 0) return clm4_gemm_fp6(A, sA, M, K, B, sB, N, C, as_stream(stream));
+    if (which == 1 && K > 0) return clm4_gemm_mfma(A, sA, M, K, B, sB, N, C, as_stream(stream));
     hipLaunchKernelGGL(k_m4_gemm_simple, dim3((unsigned)(N / 16), (unsigned)(M / 16)), dim3(256), 0, as_stream(stream),
                        (const uint8_t *)A, sA, M, K, (const uint8_t *)B, sB, N, C);
     CLV_LAUNCH_CHECK();
