@@ -11,8 +11,11 @@ import subprocess
 from pathlib import Path
 
 HIP_SOURCES = ["runtime.hip", "vector4.hip", "matrix4.hip", "rng4.hip", "gemm4.hip", "gemm6.hip", "multi.hip", "next4.hip", "mixed8.hip"]
+# per-file additions.  gemm6.hip: hipcc's SLP pass pairs the fold's scalar fmas into v_pk_fma_f32, which is slower beside MFMAs
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); measured here: see DESIGN.md 6
+EXTRA_FLAGS = {}
 HIP_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the reference's arithmetic is a fixed sequence of separately rounded fp32 ops + explicit fmas:
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
 ]
@@ -48,7 +51,20 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> Path:
     out = hip_library_path()
     out.parent.mkdir(parents=True, exist_ok=True)
     if force or _stale(out, deps):
-        cmd = [_hipcc(), *HIP_FLAGS, f"-I{root / 'include'}", f"-I{src_dir}", "-o", str(out), *map(str, srcs)]
+        # one object per source (in parallel, with its own flags), then one link
+        obj_dir = out.parent / "obj"
+        obj_dir.mkdir(exist_ok=True)
+        jobs = []
+        for src in srcs:
+            obj = obj_dir / (src.stem + ".o")
+            cmd = [_hipcc(), *HIP_FLAGS, *EXTRA_FLAGS.get(src.name, []), f"-I{root / 'include'}", f"-I{src_dir}", "-c", "-o", str(obj), str(src)]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((obj, cmd, subprocess.Popen(cmd)))
+        for obj, cmd, proc in jobs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o, _, _ in jobs]]
         cmd += ["-ldl"]          # RCCL is dlopen'ed lazily by multi.hip
         if verbose:
             print(" ".join(cmd))

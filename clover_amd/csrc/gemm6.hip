@@ -29,9 +29,7 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define G6_TILE 128
-#define G6_SUB_BYTES (G6_TILE * 48)                 // one operand, one K-block: 128 rows x 48 B = 6 DMA chunks of 1 KiB
-#define G6_BUF_BYTES (4 * G6_SUB_BYTES)             // stage = A and B, two K-blocks: [A j0][A j1][B j0][B j1]
-#define G6_LDS_BYTES (3 * G6_BUF_BYTES)
+#define G6_LDS_BYTES(WR) (3 * (2 * 64 * (WR) * 48 + 2 * 128 * 48))      // three stage buffers
 #define G6_SCALE_8 0x82828282                       // E8M0 130 = 2^3 in every byte: (8 a)(8 b) turns magnitude / 8 back into integers
 
 // ---- pass 1 -----------------------------------------------------------------------------------------------------
@@ -78,7 +76,8 @@ __device__ __forceinline__ i32x8 frag24(const char *p16, const char *p8)
     return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
 }
 
-__global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
+template <int WR>       // wave rows: the tile is 64 WR x 128, 4 WR waves (WR = 2: two workgroups per CU, WR = 4: one)
+__global__ __launch_bounds__(256 * WR, WR == 2 ? 4 : 1) void k_m4_gemm_fp6(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
                                                         const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t M,
                                                         uint64_t N, uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n)
 {
@@ -103,47 +102,64 @@ __global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restric
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const uint64_t m0 = (uint64_t)tm * G6_TILE, n0 = (uint64_t)tn * G6_TILE;
+    constexpr int SUBA = 64 * WR * 48, SUBB = 128 * 48;          // one operand, one K-block: [row][48 B]
+    constexpr int BUF = 2 * SUBA + 2 * SUBB;                    // stage: [A j0][A j1][B j0][B j1]
+    constexpr int NW = 4 * WR, NCH = BUF / 1024, NI = (NCH + NW - 1) / NW;
+    const uint64_t m0 = (uint64_t)tm * (64 * WR), n0 = (uint64_t)tn * G6_TILE;
     const uint64_t kbn = K / 64;
     const uint64_t npairs = kbn / 2;
     const uint64_t rs = kbn * 48;                               // bytes per row of the FP6 images
 
-    // DMA roles: a stage image is 24 chunks of 1 KiB, chunk q = 12 operand + 6 j + c holding slots 64 c .. 64 c + 63 of
-    // the [row][3 x 16 B] image of K-block j; wave w brings in chunks w, w + 8, w + 16.  Source = uniform base + lane offset.
+    // DMA roles: the stage image is NCH chunks of 1 KiB (64 slots of 16 B); chunk q lies in sub-image A j (q < 6 WR,
+    // j = q / (3 WR)) or B j and holds slots 64 c .. 64 c + 63 of its [row][3 x 16 B] array; wave w brings in chunks
+    // w + NW i.  Source = uniform base + lane offset.  Rows past the end of A (WR = 4, M an odd multiple of 128) are read
+    // from what follows in the workspace -- the image of B -- and never stored.
     const uint8_t *tileA = A6 + m0 * rs, *tileB = B6 + n0 * rs;
-    uint32_t voff[3];
+    uint32_t voff[NI];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int c = (wave + 8 * i) % 6;
+    for (int i = 0; i < NI; i++) {
+        const int q = wave + NW * i;
+        const int c = q < 6 * WR ? q % (3 * WR) : (q - 6 * WR) % 6;
         const int s = 64 * c + lane;
         const int row = s / 3, piece = s - 3 * row;
         voff[i] = (uint32_t)row * (uint32_t)rs + 16u * piece;
     }
+    const int nrole = NCH % NW == 0 || wave < NCH % NW ? NI : NI - 1;       // wave-uniform
     auto issue = [&](int buf, uint64_t p) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int q = wave + 8 * i;
-            const int o = q / 12, j = (q % 12) / 6;
-            const uint8_t *src = (o ? tileB : tileA) + 96 * p + 48 * j;
-            __builtin_amdgcn_global_load_lds((gptr_t *)(src + voff[i]), (lptr_t *)(smem + buf * G6_BUF_BYTES + 1024 * q), 16, 0, 0);
+        for (int i = 0; i < NI; i++) {
+            const int q = wave + NW * i;
+            if (i < nrole) {
+                const bool isA = q < 6 * WR;
+                const int j = isA ? q / (3 * WR) : (q - 6 * WR) / 6;
+                const uint8_t *src = (isA ? tileA : tileB) + 96 * p + 48 * j;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(src + voff[i]), (lptr_t *)(smem + buf * BUF + 1024 * q), 16, 0, 0);
+            }
         }
     };
+    // all of this wave's DMAs but those of the newest stage have landed
+    auto wait_prev = [&](bool newest_in_flight) {
+        if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nrole == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    };
+    static_assert(NI == 3, "wait_prev covers 3 or 2 DMA instructions per wave and stage");
 
     // fragment lane: row = lane & 31 of the 32-row tile, half = lane >> 5 of the K-block
     const int frow = lane & 31, h = lane >> 5;
     const int tail = 32 + 8 * (h ^ ((lane >> 4) & 1));
     const int offA = (wr * 64 + frow) * 48 + 16 * h;
-    const int offB = 2 * G6_SUB_BYTES + (wc * 32 + frow) * 48 + 16 * h;
+    const int offB = 2 * SUBA + (wc * 32 + frow) * 48 + 16 * h;
     // the 8-byte tails through unrelated registers: hipcc would otherwise pair them into ds_read2_b64 / ds_read2st64_b64,
     // which run at half the rate of two ds_read_b64 and have other bank rules
     int tA[2][2], tB[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        tB[j] = 2 * G6_SUB_BYTES + j * G6_SUB_BYTES + (wc * 32 + frow) * 48 + tail;
+        tB[j] = 2 * SUBA + j * SUBB + (wc * 32 + frow) * 48 + tail;
         asm volatile("" : "+v"(tB[j]));
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            tA[j][a] = j * G6_SUB_BYTES + (wr * 64 + a * 32 + frow) * 48 + tail;
+            tA[j][a] = j * SUBA + (wr * 64 + a * 32 + frow) * 48 + tail;
             asm volatile("" : "+v"(tA[j][a]));
         }
     }
@@ -154,31 +170,30 @@ __global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restric
 #pragma unroll
         for (int t = 0; t < 16; t++) acc[a][t] = 0.0f;
 
-    const float *sArow = sA + ((m0 >> 6) + wr) * kbn;
+    const bool live = m0 + wr * 64 < M;                          // wave-uniform: M is a multiple of 128
+    const float *sArow = sA + ((m0 >> 6) + (live ? wr : 0)) * kbn;
     const float *sBrow = sB + ((n0 >> 6) + (wc >> 1)) * kbn;
     const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
-    // Three buffers: stage p + 2 is requested while stage p is computed, so a DMA has two stage times to land.  Every
-    // wave issues exactly 3 DMA instructions per stage: vmcnt(3) = "all but the newest stage have landed".  Raw barrier:
+    // Three buffers: stage p + 2 is requested while stage p is computed, so a DMA has two stage times to land.  Raw barrier:
     // __syncthreads() would add a vmcnt(0) and drain the prefetch (cdna_hip_programming.md, pipelining across barriers).
     issue(0, 0);
     if (npairs > 1) issue(1, 1);
-    if (npairs > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_prev(npairs > 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     int buf = 0;
     for (uint64_t p = 0; p < npairs; p++) {
         if (p + 2 < npairs) issue(buf >= 1 ? buf - 1 : 2, p + 2);            // (p + 2) % 3: last read in stage p - 1
-        const char *base = smem + buf * G6_BUF_BYTES;
+        const char *base = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const float c = (sArow[2 * p + j] * CLV_RCP49) * sBrow[2 * p + j];
-            const i32x8 fb = frag24(base + offB + j * G6_SUB_BYTES, base + tB[j]);
+            const i32x8 fb = frag24(base + offB + j * SUBB, base + tB[j]);
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const i32x8 fa = frag24(base + offA + j * G6_SUB_BYTES + a * 32 * 48, base + tA[j][a]);
+                const i32x8 fa = frag24(base + offA + j * SUBA + a * 32 * 48, base + tA[j][a]);
                 const f32x16 s = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, zero16, 2, 2, 0, G6_SCALE_8, 0, G6_SCALE_8);
 #pragma unroll
                 for (int t = 0; t < 16; t++) acc[a][t] = __builtin_fmaf(c, s[t], acc[a][t]);
@@ -186,13 +201,14 @@ __global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restric
         }
         // stage p + 1 must have landed before anyone reads it; stage p + 2 (if requested) may stay in flight
         // (the register operands only pin the wait behind the stage's arithmetic: hipcc otherwise hoists it to the top)
-        if (p + 2 < npairs) asm volatile("s_waitcnt vmcnt(3)" ::"v"(acc[0][15]), "v"(acc[1][15]) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::"v"(acc[0][15]), "v"(acc[1][15]) : "memory");
+        asm volatile("" ::"v"(acc[0][15]), "v"(acc[1][15]) : "memory");
+        wait_prev(p + 2 < npairs);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         buf = buf == 2 ? 0 : buf + 1;
     }
 
+    if (!live) return;
     // C/D layout of the 32x32 tile: column = lane & 31, row = (t & 3) + 8 (t >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -209,11 +225,10 @@ int clm4_gemm_fp6(const int8_t *A, const float *sA, uint64_t M, uint64_t K, cons
                   hipStream_t st)
 {
     const uint64_t a_bytes = M * K / 4 * 3, b_bytes = N * K / 4 * 3;
-    const bool same = (A == B && M == N);
     void *ws = nullptr;
-    int rc = clv_internal_workspace(&ws, a_bytes + (same ? 0 : b_bytes));
+    int rc = clv_internal_workspace(&ws, a_bytes + b_bytes);
     if (rc) return rc;
-    uint8_t *A6 = reinterpret_cast<uint8_t *>(ws), *B6 = same ? A6 : A6 + a_bytes;
+    uint8_t *A6 = reinterpret_cast<uint8_t *>(ws), *B6 = A6 + a_bytes;
     const int cus = clv_cu_count();
     auto widen = [&](const int8_t *q, uint8_t *w, uint64_t rows) {
         const uint64_t nh = rows * K / 32;
@@ -222,11 +237,21 @@ int clm4_gemm_fp6(const int8_t *A, const float *sA, uint64_t M, uint64_t K, cons
         hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)blocks), dim3(256), 0, st, (const u32x4 *)q, w, nh, K / 64);
     };
     widen(A, A6, M);
-    if (!same) widen(B, B6, N);
+    widen(B, B6, N);
     CLV_LAUNCH_CHECK();
-    const uint32_t tiles_m = (uint32_t)(M / G6_TILE), tiles_n = (uint32_t)(N / G6_TILE);
-    CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES));
-    hipLaunchKernelGGL(k_m4_gemm_fp6, dim3(tiles_m * tiles_n), dim3(512), G6_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
+    // 256x128 tiles (one 16-wave workgroup per CU) stage 25 % fewer bytes per flop than two 128x128 workgroups; used once
+    // there are enough of them to occupy the chip.  CLV_G6_ROWS=128|256 forces one (A/B runs).
+    static const int force = [] { const char *e = getenv("CLV_G6_ROWS"); return e ? atoi(e) : 0; }();
+    const uint32_t tiles_n = (uint32_t)(N / G6_TILE), big_m = (uint32_t)((M + 255) / 256);
+    const bool big = force ? force == 256 : (uint64_t)big_m * tiles_n >= (uint64_t)cus;
+    if (big) {
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES(4)));
+        hipLaunchKernelGGL(k_m4_gemm_fp6<4>, dim3(big_m * tiles_n), dim3(1024), G6_LDS_BYTES(4), st, A6, sA, B6, sB, M, N, K, C, big_m, tiles_n);
+    } else {
+        const uint32_t tiles_m = (uint32_t)(M / G6_TILE);
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES(2)));
+        hipLaunchKernelGGL(k_m4_gemm_fp6<2>, dim3(tiles_m * tiles_n), dim3(512), G6_LDS_BYTES(2), st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
+    }
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

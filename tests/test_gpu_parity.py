@@ -172,6 +172,61 @@ def test_gemm_bit_exact(hip, oracle, shape):
     assert same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N))
 
 
+def test_gemm_wide_scale_range(hip, oracle):
+    """scales over 30 decades: the per-block factor c_b goes through the fold unscaled, whatever its magnitude"""
+    M, N, K = 256, 384, 512
+    rng = np.random.default_rng(99)
+    qA, _ = random_packed(rng, M * K)
+    qB, _ = random_packed(rng, N * K)
+    sA = (10.0 ** rng.uniform(-15, 15, size=(M // 64) * (K // 64))).astype(np.float32)
+    sB = (10.0 ** rng.uniform(-15, 15, size=(N // 64) * (K // 64))).astype(np.float32)
+    C = hip.m4_gemm(qA, sA, M, K, qB, sB, N)
+    assert np.isfinite(C).all() and same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N))
+
+
+def test_gemm_extreme_nibbles(hip, oracle):
+    """every value +-7: the largest block sums (64 * 49) of either sign"""
+    M, N, K = 128, 128, 256
+    rng = np.random.default_rng(5)
+    sign = rng.integers(0, 2, size=(M * K // 2, 2))
+    qA = np.where(sign[:, 0], 0x70, 0x90).astype(np.uint8) | np.where(sign[:, 1], 0x07, 0x09).astype(np.uint8)
+    sign = rng.integers(0, 2, size=(N * K // 2, 2))
+    qB = np.where(sign[:, 0], 0x70, 0x90).astype(np.uint8) | np.where(sign[:, 1], 0x07, 0x09).astype(np.uint8)
+    qB[: K // 2] = 0x77                                                 # row 0 of B all +7 ...
+    qA[: K // 2] = 0x77                                                 # ... against row 0 of A all +7: S_b = 3136
+    qA[K // 2: K] = 0x99                                                # row 1 of A all -7: S_b = -3136
+    sA = np.ones((M // 64) * (K // 64), np.float32)
+    sB = np.ones((N // 64) * (K // 64), np.float32)
+    C = hip.m4_gemm(qA, sA, M, K, qB, sB, N).reshape(M, N)
+    assert same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N).reshape(M, N))
+    assert C[0, 0] > 0 and C[1, 0] == -C[0, 0]
+
+
+def test_gemm_int8_kernel_bit_exact():
+    """the int8-MFMA kernel (gemm4.hip, CLV_GEMM_KERNEL=i8) is kept for A/B runs: same bits.  The switch is read once per
+    process, hence the child process."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from clover_amd.lib_binding import CloverHip\n"
+        "from oracle.binding import Oracle\n"
+        "hip, o = CloverHip(), Oracle()\n"
+        "rng = np.random.default_rng(3)\n"
+        "M, N, K = 256, 128, 384\n"
+        "qA = rng.integers(0, 256, M * K // 2).astype(np.uint8); qB = rng.integers(0, 256, N * K // 2).astype(np.uint8)\n"
+        "qA[(qA >> 4) == 8] ^= 0x10; qA[(qA & 15) == 8] ^= 0x01; qB[(qB >> 4) == 8] ^= 0x10; qB[(qB & 15) == 8] ^= 0x01\n"
+        "sA = rng.uniform(0.5, 2, (M // 64) * (K // 64)).astype(np.float32); sB = rng.uniform(0.5, 2, (N // 64) * (K // 64)).astype(np.float32)\n"
+        "C = hip.m4_gemm(qA, sA, M, K, qB, sB, N); Co = o.m4_gemm(qA, sA, M, K, qB, sB, N)\n"
+        "assert C.tobytes() == Co.tobytes()\n"
+        "print('ok')\n")
+    import os
+    env = dict(os.environ, CLV_GEMM_KERNEL="i8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 640)])
 def test_matrix_restore_exact(hip, oracle, shape):
     """CloverMatrix4::restore_scalar (CloverMatrix4.h:266-301)"""
