@@ -362,7 +362,7 @@ def extras(hip, torch, dev, stream) -> dict:
     f_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_FAST, o.data_ptr(), None, stream)), 50)
     e_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_EXACT, o.data_ptr() + 4, None, stream)), 5)
     vals = o.cpu().numpy()
-    # configs[3]: gemm 8192^3 (int8 MFMA, fp32 per-K-block epilogue)
+    # configs[3]: gemm 8192^3 (block-scaled FP6 MFMA on exact E2M3 operands, one fma per element and K-block)
     G = 8192
     gA = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
     gB = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
@@ -376,7 +376,10 @@ def extras(hip, torch, dev, stream) -> dict:
     g_ms = timeit(lambda: hip.check(lib.clm4_gemm(gA.data_ptr(), gsA.data_ptr(), G, G, gB.data_ptr(), gsB.data_ptr(), G, gC.data_ptr(), stream)), 10)
     gemm = {"ms": round(g_ms, 4), "TOP/s": round(2.0 * G ** 3 / g_ms / 1e9, 1),
             "frac_of_int8_mfma_peak": round(2.0 * G ** 3 / g_ms / 1e9 / 5000.0, 4),
-            "note": "int4 x int4 via v_mfma_i32_16x16x64_i8 (nibbles widened to int8 in LDS), peak = 5 POP/s dense int8"}
+            "frac_of_fp6_mfma_peak": round(2.0 * G ** 3 / g_ms / 1e9 / 10000.0, 4),
+            "note": "int4 x int4, bit-exact: nibbles re-coded once as FP6 E2M3 (exact), v_mfma_scale_f32_32x32x64_f8f6f4 returns the "
+                    "integer block sums as fp32, one fma per element folds the block scale; time includes the re-coding pass; "
+                    "peaks: 5 POP/s dense int8 (the pipe BASELINE names), 10 PF dense FP6; CLV_GEMM_KERNEL=i8 runs the int8-MFMA kernel"}
     del gA, gB, gC
     # the caller loop: one quantized IHT iteration, N = 8192 (m x 2m, K = 25 % of m), HBM-resident
     m, nn = 4096, 8192

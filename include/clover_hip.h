@@ -120,7 +120,9 @@ int  clm4_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols,
 int  clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols,
                   const int8_t *x, const float *sx, float *d, void *stream);
 /* GEMM, build-defined (the reference has none; semantics in oracle/clover4_oracle.h and DESIGN.md):
- * A is M x K, B is N x K, C = A * B^T as fp32 M x N row-major, one fma chain over K-blocks per element. */
+ * A is M x K, B is N x K, C = A * B^T as fp32 M x N row-major, one fma chain over K-blocks per element.
+ * Uses the library's internal per-device workspace ((M + N) * K * 3/4 bytes, grow-only): calls that share it must not
+ * run concurrently on different streams of one device. */
 int  clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K,
                const int8_t *B, const float *sB, uint64_t N, float *C, void *stream);
 
