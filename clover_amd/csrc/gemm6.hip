@@ -11,17 +11,18 @@
 // side, turn that into S itself, and ONE fma per element folds it in.
 //
 // Pass 1 (k_m4_to_fp6): nibbles -> FP6, 24 bytes per 32 elements (half a K-block = what one lane feeds the instruction).
-//   Row-major, 48 bytes per row and K-block laid out [half 0: 16 B][half 1: 16 B][8 B][8 B], the two 8-byte tails
-//   swapped in rows with bit 4 set (see the fragment reads).  Memory-bound, ~4 % of the GEMM time at 8192^3.  The element
-//   order inside a half is whatever the conversion produces (the same for A and B): integer sums are order-free.
+//   48 bytes per row and K-block laid out [half 0: 16 B][half 1: 16 B][8 B][8 B], the two 8-byte tails swapped in rows
+//   with bit 4 set (see the fragment reads); rows and K-blocks in the order pass 2 stages them (see k_m4_to_fp6).
+//   Memory-bound, 6 % of the GEMM time at 8192^3.  The element order inside a half is whatever the conversion produces
+//   (the same for A and B): integer sums are order-free.
 // Pass 2 (k_m4_gemm_fp6): 128x128 tile per 512-thread workgroup (2x4 waves, wave tile 64x32 = two 32x32 results inside
-//   one scale tile of A and of B, so c_b is wave-uniform).  A stage is one pair of K-blocks, brought in by LDS-DMA
-//   (global_load_lds_dwordx4: no staging registers, no ds_write) three stages deep.  The DMA writes lane-linear, so the
-//   LDS image of an operand and K-block is the plain [row][48 B] array.  A fragment lane (row = lane & 31,
-//   half = lane >> 5) reads 16 + 8 bytes: row stride 48 B = 3 x 16 with 3 odd, and the ds_read_b128 lane groups cover
-//   every residue of row mod 16 once, so they are conflict-free; the ds_read_b64 half-waves see rows r and r + 16 on
-//   the same banks, which the swapped tails move apart.  Both run at the full 256 B/clk (a ds_read2_b64 would not:
-//   MI355X_MICROARCH.md LDS table).  One barrier per stage.
+//   one scale tile of A and of B, so c_b is wave-uniform), two workgroups per CU.  A stage is one pair of K-blocks,
+//   brought in by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) three stages deep.  The DMA
+//   writes lane-linear, so the LDS image of an operand and K-block is the plain [row][48 B] array.  A fragment lane
+//   (row = lane & 31, half = lane >> 5) reads 16 + 8 bytes: row stride 48 B = 3 x 16 with 3 odd, and the ds_read_b128
+//   lane groups cover every residue of row mod 16 once, so they are conflict-free; the ds_read_b64 half-waves see rows
+//   r and r + 16 on the same banks, which the swapped tails move apart.  Both run at the full 256 B/clk (a
+//   ds_read2_b64 would not: MI355X_MICROARCH.md LDS table).  One barrier per stage.
 #include "common.h"
 
 #include <stdlib.h>
@@ -29,7 +30,7 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define G6_TILE 128
-#define G6_LDS_BYTES(WR) (3 * (2 * 64 * (WR) * 48 + 2 * 128 * 48))      // three stage buffers
+#define G6_LDS_BYTES (3 * 4 * G6_TILE * 48)         // three stage buffers of [A j0][A j1][B j0][B j1], 128 rows x 48 B each
 #define G6_SCALE_8 0x82828282                       // E8M0 130 = 2^3 in every byte: (8 a)(8 b) turns magnitude / 8 back into integers
 
 // ---- pass 1 -----------------------------------------------------------------------------------------------------
@@ -43,23 +44,44 @@ __device__ __forceinline__ uint32_t fp6_codes24(uint32_t t)
     return (c & 0x3Fu) | ((c >> 2) & 0xFC0u) | ((c >> 4) & 0x3F000u) | ((c >> 6) & 0xFC0000u);
 }
 
-__global__ __launch_bounds__(256) void k_m4_to_fp6(const u32x4 *__restrict__ q, uint8_t *__restrict__ w, uint64_t nhalves, uint64_t kbn)
+// Output order = the order pass 2 stages it: [tile of 128 rows][pair of K-blocks][K-block][row][48 B], so that one stage of one
+// operand is one contiguous run and every DMA instruction of pass 2 reads 1 KiB of consecutive bytes.
+// A workgroup re-codes 64 rows x 8 K-blocks: loads walk along the rows (256 contiguous bytes per row), the codes go to LDS
+// as [K-block][row][48 B], and each K-block's 64 x 48 = 3 KiB leave as one contiguous run.
+#define F6_ROWS 64
+#define F6_KB 8
+__global__ __launch_bounds__(256) void k_m4_to_fp6(const u32x4 *__restrict__ q, uint8_t *__restrict__ w, uint64_t kbn)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nhalves; i += stride) {
-        const u32x4 p = q[i];
+    __shared__ __attribute__((aligned(16))) uint8_t img[F6_KB * F6_ROWS * 48];
+    const uint64_t row0 = (uint64_t)blockIdx.y * F6_ROWS, kb0 = (uint64_t)blockIdx.x * F6_KB;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < F6_ROWS * F6_KB * 2 / 256; it++) {
+        const int e = tid + 256 * it;                         // (row, half) with the 16 halves of a row adjacent
+        const int r = e >> 4, hh = e & 15, kb = hh >> 1, h = hh & 1;
+        const uint64_t row = row0 + r;
+        u32x4 p = {0u, 0u, 0u, 0u};
+        if (kb0 + kb < kbn) p = q[(row * kbn + kb0 + kb) * 2 + h];      // kbn is even, not a multiple of 8
         uint32_t x[8];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             x[2 * d] = fp6_codes24((p[d] >> 4) & 0x0F0F0F0Fu);
             x[2 * d + 1] = fp6_codes24(p[d] & 0x0F0F0F0Fu);
         }
-        const uint64_t blk = i >> 1;                      // row * kbn + K-block
-        const uint32_t h = (uint32_t)i & 1u;
-        const uint32_t swap = (uint32_t)((blk / kbn) >> 4) & 1u;
-        uint8_t *o = w + blk * 48;
+        const uint32_t swap = (uint32_t)(row >> 4) & 1u;
+        uint8_t *o = img + (kb * F6_ROWS + r) * 48;
         *reinterpret_cast<u32x4 *>(o + 16 * h) = u32x4{x[0] | (x[1] << 24), (x[1] >> 8) | (x[2] << 16), (x[2] >> 16) | (x[3] << 8), x[4] | (x[5] << 24)};
         *reinterpret_cast<u32x2 *>(o + 32 + 8 * (h ^ swap)) = u32x2{(x[5] >> 8) | (x[6] << 16), (x[6] >> 16) | (x[7] << 8)};
+    }
+    __syncthreads();
+    // K-block kb of rows row0 .. row0 + 63: sub-image (tile, pair, j), rows r0 .. r0 + 63 of it
+    const uint64_t tile = row0 / G6_TILE, r0 = row0 % G6_TILE;
+#pragma unroll
+    for (int it = 0; it < F6_KB * F6_ROWS * 48 / 16 / 256; it++) {
+        const int e = tid + 256 * it;                         // 16-byte piece of the LDS image
+        const int kb = e / (F6_ROWS * 3), off = e - kb * (F6_ROWS * 3);
+        const uint64_t sub = (tile * (kbn / 2) + (kb0 + kb) / 2) * 2 + ((kb0 + kb) & 1);
+        if (kb0 + kb < kbn) *reinterpret_cast<u32x4 *>(w + (sub * G6_TILE + r0) * 48 + 16 * (uint64_t)off) = *reinterpret_cast<const u32x4 *>(img + 16 * e);
     }
 }
 
@@ -76,8 +98,7 @@ __device__ __forceinline__ i32x8 frag24(const char *p16, const char *p8)
     return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
 }
 
-template <int WR>       // wave rows: the tile is 64 WR x 128, 4 WR waves (WR = 2: two workgroups per CU, WR = 4: one)
-__global__ __launch_bounds__(256 * WR, WR == 2 ? 4 : 1) void k_m4_gemm_fp6(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
+__global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
                                                         const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t M,
                                                         uint64_t N, uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n)
 {
@@ -102,64 +123,49 @@ __global__ __launch_bounds__(256 * WR, WR == 2 ? 4 : 1) void k_m4_gemm_fp6(const
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    constexpr int SUBA = 64 * WR * 48, SUBB = 128 * 48;          // one operand, one K-block: [row][48 B]
-    constexpr int BUF = 2 * SUBA + 2 * SUBB;                    // stage: [A j0][A j1][B j0][B j1]
-    constexpr int NW = 4 * WR, NCH = BUF / 1024, NI = (NCH + NW - 1) / NW;
-    const uint64_t m0 = (uint64_t)tm * (64 * WR), n0 = (uint64_t)tn * G6_TILE;
+    constexpr int SUB = G6_TILE * 48;                           // one operand, one K-block: [row][48 B] = 6 KiB
+    constexpr int BUF = 4 * SUB;                                // stage: [A j0][A j1][B j0][B j1] = 24 DMA chunks of 1 KiB
+    const uint64_t m0 = (uint64_t)tm * G6_TILE, n0 = (uint64_t)tn * G6_TILE;
     const uint64_t kbn = K / 64;
     const uint64_t npairs = kbn / 2;
-    const uint64_t rs = kbn * 48;                               // bytes per row of the FP6 images
 
-    // DMA roles: the stage image is NCH chunks of 1 KiB (64 slots of 16 B); chunk q lies in sub-image A j (q < 6 WR,
-    // j = q / (3 WR)) or B j and holds slots 64 c .. 64 c + 63 of its [row][3 x 16 B] array; wave w brings in chunks
-    // w + NW i.  Source = uniform base + lane offset.  Rows past the end of A (WR = 4, M an odd multiple of 128) are read
-    // from what follows in the workspace -- the image of B -- and never stored.
-    const uint8_t *tileA = A6 + m0 * rs, *tileB = B6 + n0 * rs;
-    uint32_t voff[NI];
-#pragma unroll
-    for (int i = 0; i < NI; i++) {
-        const int q = wave + NW * i;
-        const int c = q < 6 * WR ? q % (3 * WR) : (q - 6 * WR) % 6;
-        const int s = 64 * c + lane;
-        const int row = s / 3, piece = s - 3 * row;
-        voff[i] = (uint32_t)row * (uint32_t)rs + 16u * piece;
-    }
-    const int nrole = NCH % NW == 0 || wave < NCH % NW ? NI : NI - 1;       // wave-uniform
+    // DMA roles: the stage image is 24 chunks of 1 KiB, 12 of A then 12 of B, and pass 1 laid both operands out in exactly
+    // this order: a chunk is 1 KiB of consecutive bytes, lane l takes bytes 16 l.  (With row-major operands, 22 row
+    // segments per instruction, the L1 address path was 80 % busy and the kernel 0.65 ms; like this 44 % and 0.55 ms.)
+    // Wave w brings in chunks w (A), w + 8 (A for w < 4, else B) and w + 16 (B).
+    const uint8_t *stageA = A6 + (uint64_t)tm * npairs * (2 * SUB) + 16 * lane;
+    const uint8_t *stageB = B6 + (uint64_t)tn * npairs * (2 * SUB) + 16 * lane;
+    const uint8_t *src0 = stageA + 1024 * wave;
+    const uint8_t *src1 = wave < 4 ? stageA + 1024 * (wave + 8) : stageB + 1024 * (wave - 4);
+    const uint8_t *src2 = stageB + 1024 * (wave + 4);
     auto issue = [&](int buf, uint64_t p) {
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            const int q = wave + NW * i;
-            if (i < nrole) {
-                const bool isA = q < 6 * WR;
-                const int j = isA ? q / (3 * WR) : (q - 6 * WR) / 6;
-                const uint8_t *src = (isA ? tileA : tileB) + 96 * p + 48 * j;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(src + voff[i]), (lptr_t *)(smem + buf * BUF + 1024 * q), 16, 0, 0);
-            }
-        }
+        char *l = smem + buf * BUF + 1024 * wave;
+        const uint64_t o = p * (2 * SUB);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(src0 + o), (lptr_t *)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(src1 + o), (lptr_t *)(l + 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(src2 + o), (lptr_t *)(l + 16384), 16, 0, 0);
     };
-    // all of this wave's DMAs but those of the newest stage have landed
+    // all of this wave's DMAs but the 3 of the newest stage have landed
     auto wait_prev = [&](bool newest_in_flight) {
-        if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nrole == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (newest_in_flight) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    static_assert(NI == 3, "wait_prev covers 3 or 2 DMA instructions per wave and stage");
 
     // fragment lane: row = lane & 31 of the 32-row tile, half = lane >> 5 of the K-block
     const int frow = lane & 31, h = lane >> 5;
     const int tail = 32 + 8 * (h ^ ((lane >> 4) & 1));
     const int offA = (wr * 64 + frow) * 48 + 16 * h;
-    const int offB = 2 * SUBA + (wc * 32 + frow) * 48 + 16 * h;
+    const int offB = 2 * SUB + (wc * 32 + frow) * 48 + 16 * h;
     // the 8-byte tails through unrelated registers: hipcc would otherwise pair them into ds_read2_b64 / ds_read2st64_b64,
     // which run at half the rate of two ds_read_b64 and have other bank rules
     int tA[2][2], tB[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        tB[j] = 2 * SUBA + j * SUBB + (wc * 32 + frow) * 48 + tail;
+        tB[j] = (2 + j) * SUB + (wc * 32 + frow) * 48 + tail;
         asm volatile("" : "+v"(tB[j]));
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            tA[j][a] = j * SUBA + (wr * 64 + a * 32 + frow) * 48 + tail;
+            tA[j][a] = j * SUB + (wr * 64 + a * 32 + frow) * 48 + tail;
             asm volatile("" : "+v"(tA[j][a]));
         }
     }
@@ -170,8 +176,7 @@ __global__ __launch_bounds__(256 * WR, WR == 2 ? 4 : 1) void k_m4_gemm_fp6(const
 #pragma unroll
         for (int t = 0; t < 16; t++) acc[a][t] = 0.0f;
 
-    const bool live = m0 + wr * 64 < M;                          // wave-uniform: M is a multiple of 128
-    const float *sArow = sA + ((m0 >> 6) + (live ? wr : 0)) * kbn;
+    const float *sArow = sA + ((m0 >> 6) + wr) * kbn;
     const float *sBrow = sB + ((n0 >> 6) + (wc >> 1)) * kbn;
     const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -190,10 +195,10 @@ __global__ __launch_bounds__(256 * WR, WR == 2 ? 4 : 1) void k_m4_gemm_fp6(const
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const float c = (sArow[2 * p + j] * CLV_RCP49) * sBrow[2 * p + j];
-            const i32x8 fb = frag24(base + offB + j * SUBB, base + tB[j]);
+            const i32x8 fb = frag24(base + offB + j * SUB, base + tB[j]);
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const i32x8 fa = frag24(base + offA + j * SUBA + a * 32 * 48, base + tA[j][a]);
+                const i32x8 fa = frag24(base + offA + j * SUB + a * 32 * 48, base + tA[j][a]);
                 const f32x16 s = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, zero16, 2, 2, 0, G6_SCALE_8, 0, G6_SCALE_8);
 #pragma unroll
                 for (int t = 0; t < 16; t++) acc[a][t] = __builtin_fmaf(c, s[t], acc[a][t]);
@@ -208,7 +213,6 @@ __global__ __launch_bounds__(256 * WR, WR == 2 ? 4 : 1) void k_m4_gemm_fp6(const
         buf = buf == 2 ? 0 : buf + 1;
     }
 
-    if (!live) return;
     // C/D layout of the 32x32 tile: column = lane & 31, row = (t & 3) + 8 (t >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -229,29 +233,16 @@ int clm4_gemm_fp6(const int8_t *A, const float *sA, uint64_t M, uint64_t K, cons
     int rc = clv_internal_workspace(&ws, a_bytes + b_bytes);
     if (rc) return rc;
     uint8_t *A6 = reinterpret_cast<uint8_t *>(ws), *B6 = A6 + a_bytes;
-    const int cus = clv_cu_count();
-    auto widen = [&](const int8_t *q, uint8_t *w, uint64_t rows) {
-        const uint64_t nh = rows * K / 32;
-        uint64_t blocks = (nh + 255) / 256;
-        if (blocks > (uint64_t)cus * 16) blocks = (uint64_t)cus * 16;
-        hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)blocks), dim3(256), 0, st, (const u32x4 *)q, w, nh, K / 64);
+    auto recode = [&](const int8_t *q, uint8_t *w, uint64_t rows) {
+        hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)((K / 64 + F6_KB - 1) / F6_KB), (unsigned)(rows / F6_ROWS)), dim3(256), 0, st, (const u32x4 *)q, w,
+                           K / 64);
     };
-    widen(A, A6, M);
-    widen(B, B6, N);
+    recode(A, A6, M);
+    recode(B, B6, N);
     CLV_LAUNCH_CHECK();
-    // 256x128 tiles (one 16-wave workgroup per CU) stage 25 % fewer bytes per flop than two 128x128 workgroups; used once
-    // there are enough of them to occupy the chip.  CLV_G6_ROWS=128|256 forces one (A/B runs).
-    static const int force = [] { const char *e = getenv("CLV_G6_ROWS"); return e ? atoi(e) : 0; }();
-    const uint32_t tiles_n = (uint32_t)(N / G6_TILE), big_m = (uint32_t)((M + 255) / 256);
-    const bool big = force ? force == 256 : (uint64_t)big_m * tiles_n >= (uint64_t)cus;
-    if (big) {
-        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES(4)));
-        hipLaunchKernelGGL(k_m4_gemm_fp6<4>, dim3(big_m * tiles_n), dim3(1024), G6_LDS_BYTES(4), st, A6, sA, B6, sB, M, N, K, C, big_m, tiles_n);
-    } else {
-        const uint32_t tiles_m = (uint32_t)(M / G6_TILE);
-        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES(2)));
-        hipLaunchKernelGGL(k_m4_gemm_fp6<2>, dim3(tiles_m * tiles_n), dim3(512), G6_LDS_BYTES(2), st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
-    }
+    const uint32_t tiles_m = (uint32_t)(M / G6_TILE), tiles_n = (uint32_t)(N / G6_TILE);
+    CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES));
+    hipLaunchKernelGGL(k_m4_gemm_fp6, dim3(tiles_m * tiles_n), dim3(512), G6_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

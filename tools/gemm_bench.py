@@ -12,7 +12,7 @@ from clover_amd.lib_binding import CloverHip  # noqa: E402
 
 hip = CloverHip()
 lib = hip.lib
-for G in (4096, 8192):
+for G in [int(g) for g in os.environ.get("GB_SIZES", "4096,8192").split(",")]:
     A, B = hip.alloc(G * G // 2), hip.alloc(G * G // 2)
     sA, sB = hip.alloc((G // 64) ** 2 * 4), hip.alloc((G // 64) ** 2 * 4)
     Cc = hip.alloc(G * G * 4)
