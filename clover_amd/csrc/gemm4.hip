@@ -9,8 +9,7 @@
 //
 // Mapping
 //   workgroup 512 threads = 2x4 waves, tile 128x128; wave tile 64x32 = 4x2 MFMA tiles inside ONE scale tile
-//   of A and of B, so c_b is wave-uniform.  Two sets of int32 results are ping-ponged per K-block so that the
-//   VALU folds K-block b-1 while the matrix pipe works on K-block b.
+//   of A and of B, so c_b is wave-uniform.
 //   staging: global (packed nibbles, 64 B per row per stage = 2 K-blocks) -> registers -> unpack -> LDS int8,
 //   double-buffered.  Unpacking needs no sign extension: (w & 0xF0F0F0F0) holds 16*q of the high nibbles and
 //   ((w << 4) & 0xF0F0F0F0) 16*q of the low nibbles as int8, so the MFMA returns 256*S_b exactly; the 2^-8
@@ -26,16 +25,11 @@
 //   an fma folds it in; both as packed fp32 pairs (fold4): 4 VALU per MFMA instead of 4 half-rate + 4 full-rate.
 #include "common.h"
 
-#include <stdlib.h>
-
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define GM_BIAS_BITS 0x4B400000          // 12582912.0f
 #define GM_BIAS_F 12582912.0f
 #define GM_BIAS4 (i32x4{GM_BIAS_BITS, GM_BIAS_BITS, GM_BIAS_BITS, GM_BIAS_BITS})
-
-// exact (float)(raw - bias) for a biased MFMA result
-__device__ __forceinline__ float unbias(int raw) { return __int_as_float(raw) - GM_BIAS_F; }
 
 // fold the 4 results one lane holds of a 16x16 MFMA tile: acc[t] = fma(c8, raw[t] - bias, acc[t]) as two packed-fp32
 // pairs (v_pk_add_f32 + v_pk_fma_f32: 4 VALU instructions per MFMA instead of 8, each component IEEE-exact as before)
@@ -64,24 +58,17 @@ __device__ __forceinline__ void unpack32(const u32x4 p, u32x4 &s0, u32x4 &s1)
     s1 = u32x4{p.z & M, (p.z << 4) & M, p.w & M, (p.w << 4) & M};
 }
 
-// KBS = K-blocks per LDS stage (one barrier per stage), MINW = occupancy target in waves per SIMD
-// PACKED: the LDS tile keeps the nibbles packed (32 bytes per row and K-block instead of 64): half the LDS write traffic
-// (the 13-cycle ds_write_b128 was as expensive as all fragment reads), 8-byte fragment reads, and the widening to int8 moves
-// behind the read (two ANDs and a shift per dword; K order inside a lane's 16 bytes = [e0 e2 e4 e6 | e1 e3 e5 e7 | ...],
-// the same for A and B).  8-byte slots are XOR-swizzled with bit 3 of the row so that a ds_read_b64 lane group is conflict-free.
-// Measured (r01): 0.90 ms against 0.81 ms for the int8 tile at 8192^3 -- every wave now widens its own fragments, the four
-// waves that share an A fragment do it four times, and the kernel becomes VALU-bound.  Kept for A/B (CLV_GEMM_VARIANT=4).
-template <int KBS, int MINW, bool PINGPONG, bool PACKED = false>
-__global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__restrict__ A, const float *__restrict__ sA,
+// One LDS stage = 2 K-blocks (one barrier per stage), single result set, 4 waves per SIMD.  Variants measured and dropped in
+// round 1: two result sets ping-ponged at 2 waves/SIMD (slower), 4 K-blocks per barrier (no gain), a PACKED
+// LDS tile widened after the fragment read (0.90 vs 0.81 ms: every wave widens its own fragments, VALU-bound).
+#define GM_KBS 2
+__global__ __launch_bounds__(512, 4) void k_m4_gemm_mfma(const uint8_t *__restrict__ A, const float *__restrict__ sA,
                                                          const uint8_t *__restrict__ B, const float *__restrict__ sB,
                                                          uint64_t M, uint64_t N, uint64_t K, float *__restrict__ C,
                                                          uint32_t tiles_m, uint32_t tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int GM_KB_PER_STAGE = KBS;
-    constexpr int GM_ROW_BYTES = PACKED ? 32 : 64;             // per row and K-block in LDS
-    constexpr int GM_STAGE_BYTES = 2 * KBS * GM_TILE * GM_ROW_BYTES;     // A + B
-    constexpr int NP = KBS / 2;                                // 16-byte pieces per thread, operand and stage
+    constexpr int GM_STAGE_BYTES = 2 * GM_KBS * GM_TILE * 64;  // A + B, 64 int8 bytes per row and K-block
 
     // ---- tile assignment: XCD-aware (block b runs on XCD b % 8): give each XCD a contiguous range of tiles,
     // walked in 8-wide column groups so neighbours share A rows / B columns in that XCD's L2
@@ -105,42 +92,29 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
     const int wr = wave >> 2, wc = wave & 3;                   // 2 x 4 waves, each 64 rows x 32 columns
     const uint64_t m0 = (uint64_t)tm * GM_TILE, n0 = (uint64_t)tn * GM_TILE;
     const uint64_t kbn = K / 64;                               // K-blocks
-    const uint64_t nstages = kbn / GM_KB_PER_STAGE;            // K is a multiple of 128
+    const uint64_t nstages = kbn / GM_KBS;                     // K is a multiple of 128
 
-    // staging role: NP x (row, 16-byte piece) per operand per stage; a row holds 32*KBS packed bytes per stage
-    u32x4 pa[NP], pb[NP];
+    // staging role: one (row, 16-byte piece) per operand per stage; a row holds 64 packed bytes per stage
+    const int srow = tid / (2 * GM_KBS), spiece = tid % (2 * GM_KBS);
+    u32x4 pa, pb;
     auto fetch = [&](uint64_t st) {
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const int idx = tid + 512 * p;
-            const int row = idx / (2 * KBS), piece = idx % (2 * KBS);
-            const uint64_t off = st * (32 * KBS) + 16 * piece;
-            pa[p] = *reinterpret_cast<const u32x4 *>(A + (m0 + row) * (K / 2) + off);
-            pb[p] = *reinterpret_cast<const u32x4 *>(B + (n0 + row) * (K / 2) + off);
-        }
+        const uint64_t off = st * (32 * GM_KBS) + 16 * spiece;
+        pa = *reinterpret_cast<const u32x4 *>(A + (m0 + srow) * (K / 2) + off);
+        pb = *reinterpret_cast<const u32x4 *>(B + (n0 + srow) * (K / 2) + off);
     };
     auto stash = [&](int buf) {
         char *base = smem + buf * GM_STAGE_BYTES;
-        auto put = [&](char *tile, int row, int piece, const u32x4 p) {
-            const int kb = piece >> 1, half = piece & 1;
-            if (PACKED) {
-                *reinterpret_cast<u32x4 *>(tile + (kb * GM_TILE + row) * 32 + ((half ^ ((row >> 3) & 1)) << 4)) = p;
-                return;
-            }
+        auto put = [&](char *tile, const u32x4 p) {
+            const int kb = spiece >> 1, half = spiece & 1;
             u32x4 s0, s1;
             unpack32(p, s0, s1);
-            char *r = tile + (kb * GM_TILE + row) * 64;
-            const int f = swz(row, kb);
+            char *r = tile + (kb * GM_TILE + srow) * 64;
+            const int f = swz(srow, kb);
             *reinterpret_cast<u32x4 *>(r + (((2 * half) ^ f) << 4)) = s0;
             *reinterpret_cast<u32x4 *>(r + (((2 * half + 1) ^ f) << 4)) = s1;
         };
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const int idx = tid + 512 * p;
-            const int row = idx / (2 * KBS), piece = idx % (2 * KBS);
-            put(base, row, piece, pa[p]);
-            put(base + GM_KB_PER_STAGE * GM_TILE * GM_ROW_BYTES, row, piece, pb[p]);
-        }
+        put(base, pa);
+        put(base + GM_KBS * GM_TILE * 64, pb);
     };
 
     float acc[4][2][4];
@@ -151,67 +125,15 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 #pragma unroll
             for (int t = 0; t < 4; t++) acc[a][b][t] = 0.0f;
 
-    // Two sets of int32 MFMA results, ping-ponged per K-block: while the matrix pipe produces K-block kb into
-    // one set, the VALU folds the previous K-block's set into the fp32 accumulators, so no VALU instruction ever
-    // waits on the MFMA issued just before it.
-    i32x4 S0[4][2], S1[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) { S0[a][b] = GM_BIAS4; S1[a][b] = GM_BIAS4; }
-    float c_prev = 0.0f;                      // scale factor belonging to the set that is folded next
-
     const float *sArow = sA + ((m0 >> 6) + wr) * kbn;
     const float *sBrow = sB + ((n0 >> 6) + (wc >> 1)) * kbn;
     const int frow = lane & 15, fkg = lane >> 4;
 
-    // one K-block: MFMAs into `Sn` interleaved with the fold of the previous set `Sp`
-    auto kblock = [&](const char *tA, const char *tB, int kb, i32x4 (&Sn)[4][2], const i32x4 (&Sp)[4][2], float cp) {
-        i32x4 fa[4], fb[2];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const int row = wr * 64 + a * 16 + frow;
-            fa[a] = *reinterpret_cast<const i32x4 *>(tA + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
-        }
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int row = wc * 32 + b * 16 + frow;
-            fb[b] = *reinterpret_cast<const i32x4 *>(tB + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
-        }
-        const bool normal = __builtin_fabsf(cp) >= 1.0e-30f || cp == 0.0f;  // hoisted: ONE uniform branch per K-block
-        const float c8 = cp * 0.00390625f;
-        if (normal) {
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    const i32x4 prev = Sp[a][b];
-                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
-                    fold4(acc[a][b], prev, c8);
-                }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    const i32x4 prev = Sp[a][b];
-                    Sn[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(cp, (float)((prev[t] - GM_BIAS_BITS) >> 8), acc[a][b][t]);
-                }
-        }
-    };
-
-    // single-set variant (fewer registers -> more waves per SIMD): MFMAs of a K-block, then its own fold; the
-    // MFMA->VALU dependency is covered by the other resident waves.  The fragments of K-block kb+1 are requested
-    // from LDS right after the MFMAs of kb were issued, so their latency hides behind the fold of kb.
-    i32x4 fa[4], fb[2];
+    // MFMAs of a K-block, then its own fold; the MFMA->VALU dependency is covered by the other resident waves.  The
+    // fragments of K-block kb+1 are requested from LDS right after the MFMAs of kb were issued, so their latency hides
+    // behind the fold of kb.
+    i32x4 S[4][2], fa[4], fb[2];
     auto frag = [&](const char *tile, int kb, int row) -> i32x4 {
-        if (PACKED) {
-            const u32x2 p = *reinterpret_cast<const u32x2 *>(tile + (kb * GM_TILE + row) * 32 + ((fkg ^ (((row >> 3) & 1) << 1)) << 3));
-            const uint32_t Mk = 0xF0F0F0F0u;
-            return i32x4{(int)(p.x & Mk), (int)((p.x << 4) & Mk), (int)(p.y & Mk), (int)((p.y << 4) & Mk)};
-        }
         return *reinterpret_cast<const i32x4 *>(tile + (kb * GM_TILE + row) * 64 + ((fkg ^ swz(row, kb)) << 4));
     };
     auto load_frags = [&](const char *tA, const char *tB, int kb) {
@@ -224,23 +146,23 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) S0[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
+            for (int b = 0; b < 2; b++) S[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], GM_BIAS4, 0, 0, 0);
     };
     auto fold_all = [&](float c) {
-        const bool normal = __builtin_fabsf(c) >= 1.0e-30f || c == 0.0f;
+        const bool normal = __builtin_fabsf(c) >= 1.0e-30f || c == 0.0f;   // c / 256 must not lose bits: ONE uniform branch per K-block
         const float c8 = c * 0.00390625f;
         if (normal) {
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 2; b++) fold4(acc[a][b], S0[a][b], c8);
+                for (int b = 0; b < 2; b++) fold4(acc[a][b], S[a][b], c8);
         } else {
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int b = 0; b < 2; b++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c, (float)((S0[a][b][t] - GM_BIAS_BITS) >> 8), acc[a][b][t]);
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = __builtin_fmaf(c, (float)((S[a][b][t] - GM_BIAS_BITS) >> 8), acc[a][b][t]);
         }
     };
 
@@ -252,41 +174,18 @@ __global__ __launch_bounds__(512, MINW) void k_m4_gemm_mfma(const uint8_t *__res
         const int buf = (int)(st & 1);
         if (st + 1 < nstages) fetch(st + 1);
         const char *tA = smem + buf * GM_STAGE_BYTES;
-        const char *tB = tA + GM_KB_PER_STAGE * GM_TILE * GM_ROW_BYTES;
-        const uint64_t blk = st * GM_KB_PER_STAGE;
-#pragma unroll
-        for (int kb = 0; kb < KBS; kb += 2) {
-            const float c0 = (sArow[blk + kb] * CLV_RCP49) * sBrow[blk + kb];
-            const float c1 = (sArow[blk + kb + 1] * CLV_RCP49) * sBrow[blk + kb + 1];
-            if (PINGPONG) {
-                kblock(tA, tB, kb, S0, S1, c_prev);     // even K-block -> S0, folding the previous odd one (S1)
-                kblock(tA, tB, kb + 1, S1, S0, c0);     // odd K-block  -> S1, folding the even one (S0)
-                c_prev = c1;
-            } else {
-                if (kb == 0) load_frags(tA, tB, 0);
-                mfma_all();
-                load_frags(tA, tB, kb + 1);
-                fold_all(c0);
-                mfma_all();
-                if (kb + 2 < KBS) load_frags(tA, tB, kb + 2);
-                fold_all(c1);
-            }
-        }
+        const char *tB = tA + GM_KBS * GM_TILE * 64;
+        const uint64_t blk = st * GM_KBS;
+        const float c0 = (sArow[blk] * CLV_RCP49) * sBrow[blk];
+        const float c1 = (sArow[blk + 1] * CLV_RCP49) * sBrow[blk + 1];
+        load_frags(tA, tB, 0);
+        mfma_all();
+        load_frags(tA, tB, 1);
+        fold_all(c0);
+        mfma_all();
+        fold_all(c1);
         if (st + 1 < nstages) stash(buf ^ 1);
         __syncthreads();
-    }
-    // fold the last K-block
-    if (PINGPONG) {
-        const bool normal = __builtin_fabsf(c_prev) >= 1.0e-30f || c_prev == 0.0f;
-        const float c8 = c_prev * 0.00390625f;
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    acc[a][b][t] = normal ? __builtin_fmaf(c8, unbias(S1[a][b][t]), acc[a][b][t])
-                                          : __builtin_fmaf(c_prev, (float)((S1[a][b][t] - GM_BIAS_BITS) >> 8), acc[a][b][t]);
     }
 
     // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + t
@@ -306,23 +205,10 @@ int clm4_gemm_mfma(const int8_t *A, const float *sA, uint64_t M, uint64_t K, con
                    hipStream_t st)
 {
     const uint32_t tiles_m = (uint32_t)(M / GM_TILE), tiles_n = (uint32_t)(N / GM_TILE);
-    static const int variant = [] { const char *e = getenv("CLV_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-    const bool kbs4 = (variant & 1) && (K % 256 == 0);
-    const bool packed = (variant & 4) != 0;                   // A/B only: measured slower (0.90 vs 0.81 ms at 8192^3), see the PACKED note
-    const size_t lds = 2 * (size_t)(2 * (kbs4 ? 4 : 2) * GM_TILE * ((packed && !kbs4 && !(variant & 2)) ? 32 : 64));
-#define GM_LAUNCH(KBS, MINW, PP, ...)                                                                                             \
-    do {                                                                                                                          \
-        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_mfma<KBS, MINW, PP, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds));                                                                                   \
-        hipLaunchKernelGGL((k_m4_gemm_mfma<KBS, MINW, PP, ##__VA_ARGS__>), dim3(tiles_m * tiles_n), dim3(512), lds, st,            \
-                           (const uint8_t *)A, sA, (const uint8_t *)B, sB, M, N, K, C, tiles_m, tiles_n);                          \
-    } while (0)
-    // default = single result set, 4 waves/SIMD (1.30 POP/s at 8192^3); variants kept for A/B runs (r01 notes)
-    if (kbs4) GM_LAUNCH(4, 2, true);
-    else if (variant & 2) GM_LAUNCH(2, 2, true);
-    else if (packed) GM_LAUNCH(2, 4, false, true);
-    else GM_LAUNCH(2, 4, false);
-#undef GM_LAUNCH
+    const size_t lds = 2 * (size_t)(2 * GM_KBS * GM_TILE * 64);
+    CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_m4_gemm_mfma, dim3(tiles_m * tiles_n), dim3(512), lds, st, (const uint8_t *)A, sA, (const uint8_t *)B, sB, M, N, K, C,
+                       tiles_m, tiles_n);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GEMM timing at 8192^3 / 4096^3 (variant via CLV_GEMM_VARIANT)."""
+"""GEMM timing at 8192^3 / 4096^3 (GB_SIZES=... for others; CLV_GEMM_KERNEL=i8 for the int8-MFMA kernel)."""
 import ctypes as C
 import os
 import sys
@@ -39,4 +39,4 @@ for G in [int(g) for g in os.environ.get("GB_SIZES", "4096,8192").split(",")]:
         ts.append(ms.value / 5)
     ms = sorted(ts)[2]
     chk = float(np.abs(Cc.download(np.float32, 4096)).sum())
-    print(f"variant={os.environ.get('CLV_GEMM_VARIANT', '0')} G={G} {ms:.4f} ms {2.0 * G ** 3 / ms / 1e9:.1f} TOP/s checksum={chk:.6e}")
+    print(f"kernel={os.environ.get('CLV_GEMM_KERNEL', 'fp6')} G={G} {ms:.4f} ms {2.0 * G ** 3 / ms / 1e9:.1f} TOP/s checksum={chk:.6e}")
