@@ -118,6 +118,65 @@ static void rate(const char *name, float *dout, int blocks)
     printf("%-28s blocks=%d  %.3f ms  %.1f ns per tile-Kstep per SIMD (x2.4 = cycles: %.1f)\n", name, blocks, ms, ms * 1e6 / tiles, ms * 1e6 / tiles * 2.4);
 }
 
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_rate32(float *out, int iters, float c)
+{
+    const int lane = threadIdx.x & 63;
+    i32x8 a[2], b[2];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 8; j++) { a[i][j] = (j < 6) ? (lane * 7 + i + j) & 0x07070707 : 0; b[i][j] = (j < 6) ? (lane * 5 + i + j) & 0x07070707 : 0; }
+    f32x16 acc[2];
+    for (int x = 0; x < 2; x++) for (int t = 0; t < 16; t++) acc[x][t] = 0.0f;
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 sp = z;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                if (MODE == 4) acc[x] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[x], b[j], acc[x], 2, 2, 0, 0x82828282, 0, 0x82828282);
+                else if (MODE == 6) {
+                    // software-pipelined: MFMA of this tile first, then the fold of the previous tile's result beside it
+                    const f32x16 s = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[x], b[j], z, 2, 2, 0, 0x82828282, 0, 0x82828282);
+                    const int px = x ^ 1;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) acc[px][t] = __builtin_fmaf(c, sp[t], acc[px][t]);
+                    sp = s;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                } else {
+                    const f32x16 s = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[x], b[j], z, 2, 2, 0, 0x82828282, 0, 0x82828282);
+#pragma unroll
+                    for (int t = 0; t < 16; t++) acc[x][t] = __builtin_fmaf(c, s[t], acc[x][t]);
+                }
+            }
+        a[0][0] ^= it;
+    }
+    float s = 0.0f;
+    for (int x = 0; x < 2; x++) for (int t = 0; t < 16; t++) s += acc[x][t];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE>
+static void rate32(const char *name, float *dout, int blocks)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000;
+    hipLaunchKernelGGL(k_rate32<MODE>, dim3(blocks), dim3(512), 0, 0, dout, 100, 0.5f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_rate32<MODE>, dim3(blocks), dim3(512), 0, 0, dout, iters, 0.5f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double waves_per_simd = blocks * 8.0 / 1024.0;
+    const double mfmas = (double)iters * 4 * waves_per_simd;
+    printf("%-28s blocks=%d  %.3f ms  %.1f ns per 32x32x64 MFMA per SIMD (x2.4 = cycles: %.1f); 8192^3 at this rate: %.3f ms\n", name, blocks, ms,
+           ms * 1e6 / mfmas, ms * 1e6 / mfmas * 2.4, ms * 1e6 / mfmas * 8192.0 * 1e-6);
+}
+
 int main()
 {
     std::vector<int> A(16 * 128), B(16 * 128);
@@ -169,6 +228,11 @@ int main()
         rate<1>("fp6 MX, fma fold", dout, blocks);
         rate<2>("int8, no fold", dout, blocks);
         rate<3>("int8, sub+fma fold", dout, blocks);
+    }
+    for (int blocks : {256, 512}) {
+        rate32<4>("fp6 32x32x64, no fold", dout, blocks);
+        rate32<5>("fp6 32x32x64, 16 fma fold", dout, blocks);
+        rate32<6>("fp6 32x32x64, pipelined fold", dout, blocks);
     }
     return 0;
 }
