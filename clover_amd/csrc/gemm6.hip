@@ -15,14 +15,16 @@
 //   with bit 4 set (see the fragment reads); rows and K-blocks in the order pass 2 stages them (see k_m4_to_fp6).
 //   Memory-bound, 6 % of the GEMM time at 8192^3.  The element order inside a half is whatever the conversion produces
 //   (the same for A and B): integer sums are order-free.
-// Pass 2 (k_m4_gemm_fp6): 128x128 tile per 512-thread workgroup (2x4 waves, wave tile 64x32 = two 32x32 results inside
-//   one scale tile of A and of B, so c_b is wave-uniform), two workgroups per CU.  A stage is one pair of K-blocks,
-//   brought in by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) three stages deep.  The DMA
+// Pass 2 (k_m4_gemm_fp6): 128x128 tile per 256-thread workgroup (2x2 waves, wave tile 64x64 = four 32x32 results inside
+//   one scale tile of A and of B, so c_b is wave-uniform), three workgroups per CU.  A stage is one pair of K-blocks,
+//   brought in by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), double-buffered.  The DMA
 //   writes lane-linear, so the LDS image of an operand and K-block is the plain [row][48 B] array.  A fragment lane
 //   (row = lane & 31, half = lane >> 5) reads 16 + 8 bytes: row stride 48 B = 3 x 16 with 3 odd, and the ds_read_b128
 //   lane groups cover every residue of row mod 16 once, so they are conflict-free; the ds_read_b64 half-waves see rows
 //   r and r + 16 on the same banks, which the swapped tails move apart.  Both run at the full 256 B/clk (a
 //   ds_read2_b64 would not: MI355X_MICROARCH.md LDS table).  One barrier per stage.
+//   (An 8-wave workgroup with 64x32 wave tiles, two per CU, three buffers: 2-6 % slower from 4096^3 up -- half again the
+//   fragment reads per MFMA -- and 10 % faster at 2048^3.)
 #include "common.h"
 
 #include <stdlib.h>
@@ -30,7 +32,7 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define G6_TILE 128
-#define G6_LDS_BYTES (3 * 4 * G6_TILE * 48)         // three stage buffers of [A j0][A j1][B j0][B j1], 128 rows x 48 B each
+#define G6_LDS_BYTES (2 * 4 * G6_TILE * 48)         // two stage buffers of [A j0][A j1][B j0][B j1], 128 rows x 48 B each
 #define G6_SCALE_8 0x82828282                       // E8M0 130 = 2^3 in every byte: (8 a)(8 b) turns magnitude / 8 back into integers
 
 // ---- pass 1 -----------------------------------------------------------------------------------------------------
@@ -98,9 +100,9 @@ __device__ __forceinline__ i32x8 frag24(const char *p16, const char *p8)
     return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
 }
 
-__global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
-                                                        const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t M,
-                                                        uint64_t N, uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n)
+__global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
+                                                            const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t M,
+                                                            uint64_t N, uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave >> 1, wc = wave & 1;
     constexpr int SUB = G6_TILE * 48;                           // one operand, one K-block: [row][48 B] = 6 KiB
     constexpr int BUF = 4 * SUB;                                // stage: [A j0][A j1][B j0][B j1] = 24 DMA chunks of 1 KiB
     const uint64_t m0 = (uint64_t)tm * G6_TILE, n0 = (uint64_t)tn * G6_TILE;
@@ -132,96 +134,95 @@ __global__ __launch_bounds__(512, 4) void k_m4_gemm_fp6(const uint8_t *__restric
     // DMA roles: the stage image is 24 chunks of 1 KiB, 12 of A then 12 of B, and pass 1 laid both operands out in exactly
     // this order: a chunk is 1 KiB of consecutive bytes, lane l takes bytes 16 l.  (With row-major operands, 22 row
     // segments per instruction, the L1 address path was 80 % busy and the kernel 0.65 ms; like this 44 % and 0.55 ms.)
-    // Wave w brings in chunks w (A), w + 8 (A for w < 4, else B) and w + 16 (B).
-    const uint8_t *stageA = A6 + (uint64_t)tm * npairs * (2 * SUB) + 16 * lane;
-    const uint8_t *stageB = B6 + (uint64_t)tn * npairs * (2 * SUB) + 16 * lane;
-    const uint8_t *src0 = stageA + 1024 * wave;
-    const uint8_t *src1 = wave < 4 ? stageA + 1024 * (wave + 8) : stageB + 1024 * (wave - 4);
-    const uint8_t *src2 = stageB + 1024 * (wave + 4);
+    // Wave w brings in chunks w + 4 i of A and of B, i < 3.
+    const uint8_t *stageA = A6 + (uint64_t)tm * npairs * (2 * SUB) + 1024 * wave + 16 * lane;
+    const uint8_t *stageB = B6 + (uint64_t)tn * npairs * (2 * SUB) + 1024 * wave + 16 * lane;
     auto issue = [&](int buf, uint64_t p) {
         char *l = smem + buf * BUF + 1024 * wave;
-        const uint64_t o = p * (2 * SUB);
-        __builtin_amdgcn_global_load_lds((gptr_t *)(src0 + o), (lptr_t *)l, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)(src1 + o), (lptr_t *)(l + 8192), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)(src2 + o), (lptr_t *)(l + 16384), 16, 0, 0);
-    };
-    // all of this wave's DMAs but the 3 of the newest stage have landed
-    auto wait_prev = [&](bool newest_in_flight) {
-        if (newest_in_flight) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint8_t *a = stageA + p * (2 * SUB), *b = stageB + p * (2 * SUB);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            __builtin_amdgcn_global_load_lds((gptr_t *)(a + 4096 * i), (lptr_t *)(l + 4096 * i), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(b + 4096 * i), (lptr_t *)(l + 2 * SUB + 4096 * i), 16, 0, 0);
+        }
     };
 
-    // fragment lane: row = lane & 31 of the 32-row tile, half = lane >> 5 of the K-block
+    // fragment lane: row = lane & 31 of a 32-row tile, half = lane >> 5 of the K-block
     const int frow = lane & 31, h = lane >> 5;
     const int tail = 32 + 8 * (h ^ ((lane >> 4) & 1));
     const int offA = (wr * 64 + frow) * 48 + 16 * h;
-    const int offB = 2 * SUB + (wc * 32 + frow) * 48 + 16 * h;
+    const int offB = 2 * SUB + (wc * 64 + frow) * 48 + 16 * h;
     // the 8-byte tails through unrelated registers: hipcc would otherwise pair them into ds_read2_b64 / ds_read2st64_b64,
     // which run at half the rate of two ds_read_b64 and have other bank rules
-    int tA[2][2], tB[2];
+    int tA[2][2], tB[2][2];                                     // [K-block of the stage][32-row tile]
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        tB[j] = (2 + j) * SUB + (wc * 32 + frow) * 48 + tail;
-        asm volatile("" : "+v"(tB[j]));
+    for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             tA[j][a] = j * SUB + (wr * 64 + a * 32 + frow) * 48 + tail;
-            asm volatile("" : "+v"(tA[j][a]));
+            tB[j][a] = (2 + j) * SUB + (wc * 64 + a * 32 + frow) * 48 + tail;
+            asm volatile("" : "+v"(tA[j][a]), "+v"(tB[j][a]));
         }
-    }
 
-    f32x16 acc[2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int t = 0; t < 16; t++) acc[a][t] = 0.0f;
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 16; t++) acc[a][b][t] = 0.0f;
 
     const float *sArow = sA + ((m0 >> 6) + wr) * kbn;
-    const float *sBrow = sB + ((n0 >> 6) + (wc >> 1)) * kbn;
+    const float *sBrow = sB + ((n0 >> 6) + wc) * kbn;
     const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
-    // Three buffers: stage p + 2 is requested while stage p is computed, so a DMA has two stage times to land.  Raw barrier:
-    // __syncthreads() would add a vmcnt(0) and drain the prefetch (cdna_hip_programming.md, pipelining across barriers).
+    // Two buffers: stage p + 1 is requested while stage p is computed (three, two stages ahead with counted vmcnt, measured the
+    // same and would cost the third workgroup per CU).  Raw barrier + explicit waits: the compiler does not know what an LDS-DMA
+    // writes, and a __syncthreads() here adds nothing.
     issue(0, 0);
-    if (npairs > 1) issue(1, 1);
-    wait_prev(npairs > 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    int buf = 0;
     for (uint64_t p = 0; p < npairs; p++) {
-        if (p + 2 < npairs) issue(buf >= 1 ? buf - 1 : 2, p + 2);            // (p + 2) % 3: last read in stage p - 1
+        const int buf = (int)(p & 1);
+        if (p + 1 < npairs) issue(buf ^ 1, p + 1);                           // the other buffer was last read in stage p - 1
         const char *base = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const float c = (sArow[2 * p + j] * CLV_RCP49) * sBrow[2 * p + j];
-            const i32x8 fb = frag24(base + offB + j * SUB, base + tB[j]);
+            i32x8 fb[2];
+#pragma unroll
+            for (int b = 0; b < 2; b++) fb[b] = frag24(base + offB + j * SUB + b * 32 * 48, base + tB[j][b]);
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const i32x8 fa = frag24(base + offA + j * SUB + a * 32 * 48, base + tA[j][a]);
-                const f32x16 s = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, zero16, 2, 2, 0, G6_SCALE_8, 0, G6_SCALE_8);
 #pragma unroll
-                for (int t = 0; t < 16; t++) acc[a][t] = __builtin_fmaf(c, s[t], acc[a][t]);
+                for (int b = 0; b < 2; b++) {
+                    const f32x16 s = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[b], zero16, 2, 2, 0, G6_SCALE_8, 0, G6_SCALE_8);
+#pragma unroll
+                    for (int t = 0; t < 16; t++) acc[a][b][t] = __builtin_fmaf(c, s[t], acc[a][b][t]);
+                }
             }
         }
-        // stage p + 1 must have landed before anyone reads it; stage p + 2 (if requested) may stay in flight
+        // stage p + 1 must have landed before anyone reads it
         // (the register operands only pin the wait behind the stage's arithmetic: hipcc otherwise hoists it to the top)
-        asm volatile("" ::"v"(acc[0][15]), "v"(acc[1][15]) : "memory");
-        wait_prev(p + 2 < npairs);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(acc[0][0][15]), "v"(acc[1][1][15]) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        buf = buf == 2 ? 0 : buf + 1;
     }
 
     // C/D layout of the 32x32 tile: column = lane & 31, row = (t & 3) + 8 (t >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const uint64_t i = m0 + wr * 64 + a * 32 + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);
-            const uint64_t j = n0 + wc * 32 + (lane & 31);
-            __builtin_nontemporal_store(acc[a][t], &C[i * N + j]);
-        }
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint64_t i = m0 + wr * 64 + a * 32 + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);
+                const uint64_t j = n0 + wc * 64 + b * 32 + (lane & 31);
+                __builtin_nontemporal_store(acc[a][b][t], &C[i * N + j]);
+            }
 }
 
 // workspace: the FP6 images of A and B, (M + N) * K * 3/4 bytes
@@ -242,7 +243,7 @@ int clm4_gemm_fp6(const int8_t *A, const float *sA, uint64_t M, uint64_t K, cons
     CLV_LAUNCH_CHECK();
     const uint32_t tiles_m = (uint32_t)(M / G6_TILE), tiles_n = (uint32_t)(N / G6_TILE);
     CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES));
-    hipLaunchKernelGGL(k_m4_gemm_fp6, dim3(tiles_m * tiles_n), dim3(512), G6_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
+    hipLaunchKernelGGL(k_m4_gemm_fp6, dim3(tiles_m * tiles_n), dim3(256), G6_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
