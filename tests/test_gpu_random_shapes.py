@@ -87,3 +87,18 @@ def test_matrix_ops_random(hip, oracle, seed):
     r8o, sr8o = oracle.m4_mvm_v8(qA, sA, M, N, q8, s8, o)
     assert same(r8, r8o) and same(sr8, sr8o)
     assert np.array_equal(hip.rng_get(g)[1], oracle.rng_keys(o)[1])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gemm_random(hip, oracle, seed):
+    """GEMM through quantized REAL data (zeros, tiny / huge blocks): every shape class of the FP6 path -- K-block counts that are
+    not multiples of the 8 the re-coding pass walks, single-tile and multi-tile M and N."""
+    rng = np.random.default_rng(7000 + seed)
+    M, N, K = (128 * int(rng.integers(1, 5)) for _ in range(3))
+    K = 128 * int(rng.integers(1, 11))
+    A = _data(rng, M * K, seed % 4).reshape(M, K)
+    B = _data(rng, N * K, (seed + 2) % 4).reshape(N, K)
+    qA, sA = oracle.m4_quantize(A)
+    qB, sB = oracle.m4_quantize(B)
+    C = hip.m4_gemm(qA, sA, M, K, qB, sB, N)
+    assert same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N))
