@@ -76,3 +76,34 @@ def unpack_gathered(buf: torch.Tensor, rows_total: int, world: int) -> tuple[tor
         off += packed_bytes(rk)
     scales = torch.cat(sc).contiguous().view(torch.float32)
     return torch.cat(nib).contiguous(), scales
+
+
+# ---- GEMM: C = A * B^T sharded by rows of A (B replicated) ----------------------------------------------------------------
+# Every element of C is one fma chain over the K-blocks of its own row of A and row of B, so a rank that holds
+# rows [b, b + c) of A computes rows [b, b + c) of C bit for bit as the unsharded call would.  Shards are multiples of 128
+# rows (clm4_gemm's unit); the only exchange, if the whole C is wanted in one place, is an all-gather of fp32 rows.
+
+def partition_gemm_rows(rows: int, nparts: int, part: int) -> tuple[int, int]:
+    """(row_begin, row_count) of shard `part` of A / C: multiples of 128, remainder spread over the first ranks."""
+    assert rows % 128 == 0 and 0 <= part < nparts
+    blocks = rows // 128
+    base, extra = divmod(blocks, nparts)
+    b0 = part * base + min(part, extra)
+    return b0 * 128, (base + (1 if part < extra else 0)) * 128
+
+
+def gather_gemm_rows(c_local: torch.Tensor, rows_total: int, ncols: int, group=None) -> torch.Tensor:
+    """All-gather the per-rank row shards of C (fp32, [rows_k, ncols]) in rank order -> [rows_total, ncols]."""
+    world = dist.get_world_size(group)
+    counts = [partition_gemm_rows(rows_total, world, k)[1] for k in range(world)]
+    assert c_local.dtype == torch.float32 and c_local.numel() == counts[dist.get_rank(group)] * ncols
+    mx = max(counts)
+    src = c_local.reshape(-1)
+    if len(set(counts)) != 1:                      # unequal shards: pad to the largest, drop the pads afterwards
+        src = torch.zeros(mx * ncols, dtype=torch.float32, device=c_local.device)
+        src[: c_local.numel()] = c_local.reshape(-1)
+    out = torch.empty(mx * ncols * world, dtype=torch.float32, device=c_local.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    if len(set(counts)) == 1:
+        return out.view(rows_total, ncols)
+    return torch.cat([out[k * mx * ncols: k * mx * ncols + counts[k] * ncols] for k in range(world)]).view(rows_total, ncols)

@@ -15,7 +15,8 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from clover_amd.sharding import gather_packed, packed_bytes, partition_rows, unpack_gathered  # noqa: E402
+from clover_amd.sharding import (gather_gemm_rows, gather_packed, packed_bytes, partition_gemm_rows, partition_rows,  # noqa: E402
+                                 unpack_gathered)
 
 
 def test_partition_matches_c_abi_and_covers_rows():
@@ -74,6 +75,43 @@ def test_sharded_mvm_gloo(world, rows):
     ret = ctx.Manager().dict()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(k, world, port, rows, 256, ret)) for k in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(k) for k in range(world)), dict(ret)
+
+
+def _gemm_worker(rank, world, port, M, N, K, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.binding import Oracle
+        orc = Oracle()
+        rng = np.random.default_rng(321)                      # same data on every rank
+        qA = rng.integers(0, 256, size=M * K // 2, dtype=np.uint8) & 0x77
+        qB = rng.integers(0, 256, size=N * K // 2, dtype=np.uint8) & 0x77
+        sA = rng.uniform(0.5, 2, size=(M // 64) * (K // 64)).astype(np.float32)
+        sB = rng.uniform(0.5, 2, size=(N // 64) * (K // 64)).astype(np.float32)
+        b, c = partition_gemm_rows(M, world, rank)
+        kb = K // 64
+        C_loc = orc.m4_gemm(qA[b * K // 2:(b + c) * K // 2], sA[(b // 64) * kb:((b + c) // 64) * kb], c, K, qB, sB, N)
+        full = gather_gemm_rows(torch.from_numpy(np.ascontiguousarray(C_loc)).reshape(c, N), M, N)
+        ref = orc.m4_gemm(qA, sA, M, K, qB, sB, N).reshape(M, N)
+        ret[rank] = bool(np.array_equal(full.numpy().view(np.uint32), ref.view(np.uint32)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,M", [(2, 256), (3, 512)])
+def test_sharded_gemm_gloo(world, M):
+    """row-sharded GEMM (equal and unequal shards): the gathered C equals the unsharded one bit for bit"""
+    assert [partition_gemm_rows(M, world, k) for k in range(world)][-1][0] + partition_gemm_rows(M, world, world - 1)[1] == M
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_gemm_worker, args=(k, world, port, M, 128, 256, ret)) for k in range(world)]
     for p in procs:
         p.start()
     for p in procs:
