@@ -52,10 +52,16 @@ __device__ __forceinline__ uint32_t fp6_codes24(uint32_t t)
 // as [K-block][row][48 B], and each K-block's 64 x 48 = 3 KiB leave as one contiguous run.
 #define F6_ROWS 64
 #define F6_KB 8
-__global__ __launch_bounds__(256) void k_m4_to_fp6(const u32x4 *__restrict__ q, uint8_t *__restrict__ w, uint64_t kbn)
+__global__ __launch_bounds__(256) void k_m4_to_fp6(const u32x4 *__restrict__ qa, uint8_t *__restrict__ wa, uint32_t row_groups_a,
+                                                   const u32x4 *__restrict__ qb, uint8_t *__restrict__ wb, uint64_t kbn)
 {
+    // both operands in one launch: blockIdx.y walks the 64-row groups of A, then those of B
+    const bool second = blockIdx.y >= row_groups_a;
+    const u32x4 *__restrict__ q = second ? qb : qa;
+    uint8_t *__restrict__ w = second ? wb : wa;
+    const uint32_t by = second ? blockIdx.y - row_groups_a : blockIdx.y;
     __shared__ __attribute__((aligned(16))) uint8_t img[F6_KB * F6_ROWS * 48];
-    const uint64_t row0 = (uint64_t)blockIdx.y * F6_ROWS, kb0 = (uint64_t)blockIdx.x * F6_KB;
+    const uint64_t row0 = (uint64_t)by * F6_ROWS, kb0 = (uint64_t)blockIdx.x * F6_KB;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < F6_ROWS * F6_KB * 2 / 256; it++) {
@@ -234,15 +240,10 @@ int clm4_gemm_fp6(const int8_t *A, const float *sA, uint64_t M, uint64_t K, cons
     int rc = clv_internal_workspace(&ws, a_bytes + b_bytes);
     if (rc) return rc;
     uint8_t *A6 = reinterpret_cast<uint8_t *>(ws), *B6 = A6 + a_bytes;
-    auto recode = [&](const int8_t *q, uint8_t *w, uint64_t rows) {
-        hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)((K / 64 + F6_KB - 1) / F6_KB), (unsigned)(rows / F6_ROWS)), dim3(256), 0, st, (const u32x4 *)q, w,
-                           K / 64);
-    };
-    recode(A, A6, M);
-    recode(B, B6, N);
+    hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)((K / 64 + F6_KB - 1) / F6_KB), (unsigned)((M + N) / F6_ROWS)), dim3(256), 0, st, (const u32x4 *)A, A6,
+                       (uint32_t)(M / F6_ROWS), (const u32x4 *)B, B6, K / 64);
     CLV_LAUNCH_CHECK();
     const uint32_t tiles_m = (uint32_t)(M / G6_TILE), tiles_n = (uint32_t)(N / G6_TILE);
-    CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS_BYTES));
     hipLaunchKernelGGL(k_m4_gemm_fp6, dim3(tiles_m * tiles_n), dim3(256), G6_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
