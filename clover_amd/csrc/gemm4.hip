@@ -1,6 +1,6 @@
 // gemm4.hip -- CloverMatrix4 x CloverMatrix4^T -> fp32 on the gfx950 matrix cores, int8 MFMA version.
 // NOT the default any more: gemm6.hip (FP6 block-scaled MFMA on exactly representable operands, one fma per element) is
-// 28 % faster; this kernel runs under CLV_GEMM_KERNEL=i8 for A/B measurements and keeps its parity test.
+// a third faster; this kernel runs under CLV_GEMM_KERNEL=i8 for A/B measurements and keeps its parity test.
 //
 // The reference has no GEMM; semantics are defined in oracle/clover4_oracle.h / DESIGN.md 6:
 //   C[i][j] = fold_b fmaf(c_b, (float)S_b, C),  S_b = exact int32 sum of the 64 nibble products of K-block b,
