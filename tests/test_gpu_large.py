@@ -136,6 +136,42 @@ def test_gemm_2048_sampled(hip, oracle):
             assert bits(acc) == bits(Ch[i, j]), (i, j)
 
 
+def test_gemm_4096_two_pipelines_agree():
+    """4096^3 in full: the FP6 kernel (LDS-DMA staging, block-scaled MFMA) and the int8-MFMA kernel (register staging, int32 results)
+    share no code below the ABI, so equal digests over the whole of C check every tile of both; three runs of the FP6 kernel
+    must also be identical (a staging race would show up as tiles that come and go).  The kernel switch is read once per
+    process, hence child processes."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, hashlib, numpy as np\n"
+        "from clover_amd.lib_binding import CloverHip\n"
+        "hip = CloverHip(); lib = hip.lib; G = 4096\n"
+        "A, B = hip.alloc(G * G // 2), hip.alloc(G * G // 2)\n"
+        "sA, sB = hip.alloc((G // 64) ** 2 * 4), hip.alloc((G // 64) ** 2 * 4)\n"
+        "Cc = hip.alloc(G * G * 4)\n"
+        "for t, sd in ((A, 11), (B, 12)): hip.check(lib.clv_fill_random_nibbles(t.ptr, t.nbytes, sd, 0, None))\n"
+        "for t, sd in ((sA, 13), (sB, 14)): hip.check(lib.clv_fill_random_scales(t.ptr, t.nbytes // 4, sd, 0, None))\n"
+        "for rep in range(3):\n"
+        "    hip.check(lib.clv_memset(Cc.ptr, 0xFF, Cc.nbytes, None))\n"
+        "    hip.check(lib.clm4_gemm(A.ptr, sA.ptr, G, G, B.ptr, sB.ptr, G, Cc.ptr, None))\n"
+        "    print('digest', hashlib.sha256(Cc.download(np.uint8).tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for kern in ("fp6", "i8"):
+        env = dict(os.environ)
+        env.pop("CLV_GEMM_KERNEL", None)
+        if kern == "i8":
+            env["CLV_GEMM_KERNEL"] = "i8"
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[kern] = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("digest")]
+        assert len(digests[kern]) == 3
+    assert len(set(digests["fp6"])) == 1, digests
+    assert digests["fp6"][0] == digests["i8"][0], digests
+
+
 def test_sharded_c_api_single_process(hip, oracle):
     """clm4_sharded_* (one process, N devices, RCCL gather): with the devices visible here (1 on the test
     box; 8 on a full node) the gathered result must equal the unsharded clm4_mvm byte for byte."""
