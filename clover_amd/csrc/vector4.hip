@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_v4_dot_chain(const f32x4 *__restrict__ 
             const uint64_t gend = (ngroups - g0) < DX_TILE_GROUPS ? (ngroups - g0) : DX_TILE_GROUPS;
             const uint64_t full = (npairs / 4 > g0) ? ((npairs / 4 - g0) < gend ? (npairs / 4 - g0) : gend) : 0;
             uint64_t g = 0;
-#pragma unroll 4
+#pragma unroll 16
             for (; g < full; g++) {
                 const f32x4 f = bf[g * 16 + j];
                 const f32x4 c = bc[g * 2 + (j >> 3)];
