@@ -68,6 +68,10 @@ struct clm4_shard_ctx {
     std::vector<float *> sA, sx, sr;        // per device: shard tile scales, x scales, FULL result scales
     std::vector<hipStream_t> st;
     std::vector<ncclComm_t> comm;
+    // GEMM (clm4_sharded_gemm): B replicated, one row shard of C per device
+    uint64_t gemm_n = 0;
+    std::vector<int8_t *> B;
+    std::vector<float *> sB, C;
 };
 
 // contiguous shards in units of 64 rows, remainder spread over the first ranks (as a static OpenMP split)
@@ -93,6 +97,9 @@ extern "C" int clm4_sharded_destroy(clm4_shard_ctx *c)
         void *ptrs[] = {d < (int)c->A.size() ? c->A[d] : nullptr, d < (int)c->x.size() ? c->x[d] : nullptr, d < (int)c->r.size() ? c->r[d] : nullptr,
                         d < (int)c->sA.size() ? c->sA[d] : nullptr, d < (int)c->sx.size() ? c->sx[d] : nullptr, d < (int)c->sr.size() ? c->sr[d] : nullptr};
         for (void *p : ptrs) if (p) (void)hipFree(p);
+        void *gptrs[] = {d < (int)c->B.size() ? (void *)c->B[d] : nullptr, d < (int)c->sB.size() ? (void *)c->sB[d] : nullptr,
+                         d < (int)c->C.size() ? (void *)c->C[d] : nullptr};
+        for (void *p : gptrs) if (p) (void)hipFree(p);
     }
     (void)hipSetDevice(cur);
     delete c;
@@ -249,5 +256,69 @@ extern "C" int clm4_sharded_result(const clm4_shard_ctx *c, int part, const int8
     CLV_REQUIRE(c && part >= 0 && part < c->ndev, "clm4_sharded_result: bad argument");
     if (r_dev) *r_dev = c->r[part];
     if (sr_dev) *sr_dev = c->sr[part];
+    return CLV_OK;
+}
+
+
+// C = A * B^T with A the sharded matrix (rows x cols) and B an N x cols CloverMatrix4 replicated on every device: device d ends
+// with rows [row_begin_d, +row_count_d) of C (fp32, row-major, N columns).  Every element of C is its own fma chain over the
+// K-blocks, so the shards equal the unsharded clm4_gemm bit for bit and nothing needs to be exchanged; C_host
+// (optional) receives the whole C.  clm4_gemm works in units of 128 rows: every shard must be a multiple of 128.
+extern "C" int clm4_sharded_gemm(clm4_shard_ctx *c, const int8_t *B, const float *sB, uint64_t N, int b_on_host, float *C_host)
+{
+    CLV_REQUIRE(c && B && sB && N && N % 128 == 0, "clm4_sharded_gemm: bad argument");
+    for (int d = 0; d < c->ndev; d++)
+        CLV_REQUIRE(c->row_count[d] % 128 == 0, "clm4_sharded_gemm: shard %d has %llu rows, not a multiple of 128", d, (unsigned long long)c->row_count[d]);
+    int cur = 0;
+    CLV_HIP(hipGetDevice(&cur));
+    const uint64_t K = c->cols, b_bytes = N * K / 2, sb_count = (N / 64) * (K / 64);
+    if (c->gemm_n != N) {                                      // (re)allocate B and the C shards for this N
+        c->B.resize(c->ndev, nullptr); c->sB.resize(c->ndev, nullptr); c->C.resize(c->ndev, nullptr);
+        for (int d = 0; d < c->ndev; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            CLV_HIP(hipStreamSynchronize(c->st[d]));
+            if (c->B[d]) CLV_HIP(hipFree(c->B[d]));
+            if (c->sB[d]) CLV_HIP(hipFree(c->sB[d]));
+            if (c->C[d]) CLV_HIP(hipFree(c->C[d]));
+            c->B[d] = nullptr; c->sB[d] = nullptr; c->C[d] = nullptr;
+            CLV_HIP(hipMalloc((void **)&c->B[d], b_bytes));
+            CLV_HIP(hipMalloc((void **)&c->sB[d], sb_count * sizeof(float)));
+            CLV_HIP(hipMalloc((void **)&c->C[d], c->row_count[d] * N * sizeof(float)));
+        }
+        c->gemm_n = N;
+    }
+    // 1. B to device 0, then to everyone
+    CLV_HIP(hipSetDevice(c->dev[0]));
+    const hipMemcpyKind kind = b_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    CLV_HIP(hipMemcpyAsync(c->B[0], B, b_bytes, kind, c->st[0]));
+    CLV_HIP(hipMemcpyAsync(c->sB[0], sB, sb_count * sizeof(float), kind, c->st[0]));
+    if (c->ndev > 1) {
+        CLV_NCCL(rccl()->GroupStart());
+        for (int d = 0; d < c->ndev; d++) {
+            CLV_NCCL(rccl()->Broadcast(c->B[d], c->B[d], b_bytes, ncclInt8, 0, c->comm[d], c->st[d]));
+            CLV_NCCL(rccl()->Broadcast(c->sB[d], c->sB[d], sb_count, ncclFloat32, 0, c->comm[d], c->st[d]));
+        }
+        CLV_NCCL(rccl()->GroupEnd());
+    }
+    // 2. every device multiplies its row shard
+    for (int d = 0; d < c->ndev; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        int rc = clm4_gemm(c->A[d], c->sA[d], c->row_count[d], K, c->B[d], c->sB[d], N, c->C[d], c->st[d]);
+        if (rc != CLV_OK) { (void)hipSetDevice(cur); return rc; }
+    }
+    for (int d = 0; d < c->ndev; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        CLV_HIP(hipStreamSynchronize(c->st[d]));
+        if (C_host) CLV_HIP(hipMemcpy(C_host + c->row_begin[d] * N, c->C[d], c->row_count[d] * N * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    CLV_HIP(hipSetDevice(cur));
+    return CLV_OK;
+}
+
+// device pointer of shard `part`'s rows of C (valid after clm4_sharded_gemm)
+extern "C" int clm4_sharded_gemm_result(const clm4_shard_ctx *c, int part, const float **C_dev)
+{
+    CLV_REQUIRE(c && part >= 0 && part < c->ndev && C_dev && c->gemm_n, "clm4_sharded_gemm_result: bad argument");
+    *C_dev = c->C[part];
     return CLV_OK;
 }

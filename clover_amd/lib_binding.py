@@ -81,6 +81,8 @@ SIGNATURES = {
     "clm4_sharded_fill_random": (C.c_int, [_vp, _u64]),
     "clm4_sharded_mvm": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "clm4_sharded_result": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "clm4_sharded_gemm": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _vp]),
+    "clm4_sharded_gemm_result": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "clv_fill_random_nibbles": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),
     "clv_fill_random_scales": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),
     "clv_fill_random_ints_f32": (C.c_int, [_vp, _u64, C.c_int, _u64, _u64, _vp]),

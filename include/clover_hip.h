@@ -210,6 +210,11 @@ int  clm4_sharded_fill_random(clm4_shard_ctx *ctx, uint64_t seed);
 /* r = A*x; every device ends with the full packed result; r_host/sr_host (optional) receive a copy */
 int  clm4_sharded_mvm(clm4_shard_ctx *ctx, const int8_t *x, const float *sx, int x_on_host, int8_t *r_host, float *sr_host);
 int  clm4_sharded_result(const clm4_shard_ctx *ctx, int part, const int8_t **r_dev, const float **sr_dev);
+/* C = A * B^T with the sharded A and an N x cols CloverMatrix4 B (host memory or device `part 0`) replicated on every device:
+ * device d ends with its rows of C (fp32, N columns), bit-identical to clm4_gemm on the whole matrix; nothing is exchanged
+ * between the shards.  Every shard must be a multiple of 128 rows.  C_host (optional) receives the whole C. */
+int  clm4_sharded_gemm(clm4_shard_ctx *ctx, const int8_t *B, const float *sB, uint64_t N, int b_on_host, float *C_host);
+int  clm4_sharded_gemm_result(const clm4_shard_ctx *ctx, int part, const float **C_dev);
 
 /* ---- synthetic data (bench / tests): fills device buffers without an fp32 source ------------------ */
 /* nibbles uniform in [-7,7], scales uniform in [0.5,2): counter-based splitmix64 of (seed, index), so any

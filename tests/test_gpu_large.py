@@ -204,5 +204,18 @@ def test_sharded_c_api_single_process(hip, oracle):
         b, c = u64(), u64()
         hip.check(lib.clm4_sharded_info(ctx, ndev - 1, None, C.byref(b), C.byref(c), None, None))
         assert b.value + c.value == rows
+        # row-sharded GEMM against the unsharded call and the oracle (rows / ndev stays a multiple of 128 for ndev = 1, 2, 4, 8)
+        N = 256
+        rngb = np.random.default_rng(6)
+        qB = (rngb.integers(0, 256, size=N * cols // 2, dtype=np.uint8) & 0x77).astype(np.uint8)
+        sB = rngb.uniform(0.5, 2, size=(N // 64) * (cols // 64)).astype(np.float32)
+        Cs = np.zeros(rows * N, np.float32)
+        for _ in range(2):                                             # second call reuses the buffers
+            hip.check(lib.clm4_sharded_gemm(ctx, qB.ctypes.data, sB.ctypes.data, N, 1, Cs.ctypes.data))
+        assert same(Cs, hip.m4_gemm(A_h, sA_h, rows, cols, qB, sB, N).reshape(-1))
+        assert same(Cs[: 128 * N], oracle.m4_gemm(A_h[: 128 * cols // 2], sA_h[: 2 * (cols // 64)], 128, cols, qB, sB, N).reshape(-1))
+        cd = vp()
+        hip.check(lib.clm4_sharded_gemm_result(ctx, 0, C.byref(cd)))
+        assert cd.value
     finally:
         hip.check(lib.clm4_sharded_destroy(ctx))
