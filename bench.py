@@ -152,10 +152,15 @@ def main() -> None:
     ap.add_argument("--cpu-sample-rows", type=int, default=32768,
                     help="rows of the matrix the CPU baseline multiplies (32768 x 65536 = 1 GiB of nibbles: beyond the 2 x 256 MB of L3 "
                          "of the host, so the number is a DRAM number like the reference's)")
+    ap.add_argument("--workload", choices=("mvm", "gemm"), default="mvm",
+                    help="mvm (default): the headline GEMV of BASELINE configs[2]; gemm: configs[3], one GPU, its own JSON line")
+    ap.add_argument("--gemm-size", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.workload == "gemm":
+        return gemm_main(args)
 
     if args.cpu_baseline_child:
         cpu_baseline_child(args.cpu_baseline_child)
@@ -327,6 +332,65 @@ def main() -> None:
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def gemm_main(args) -> None:
+    """BASELINE configs[3]: CloverMatrix4::gemm G x G x G (default 8192) on one GPU.  A step = one clm4_gemm call (the FP6 re-coding
+    pass + the MFMA kernel); the matrix-pipe bound is the dense int8 peak BASELINE names (5 POP/s), the FP6 peak is quoted beside."""
+    import torch
+
+    from clover_amd.lib_binding import CloverHip
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("bench.py --workload gemm measures one GPU (row shards of C are independent: clm4_sharded_gemm)")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    hip = CloverHip(device=0)
+    lib = hip.lib
+    stream = torch.cuda.current_stream().cuda_stream
+    G = args.gemm_size
+    assert G % 128 == 0
+    A = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
+    B = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
+    sA = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
+    sB = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
+    Cm = torch.empty(G * G, dtype=torch.float32, device=dev)
+    for t, sd in ((A, 21), (B, 22)):
+        hip.check(lib.clv_fill_random_nibbles(t.data_ptr(), t.numel(), sd, 0, stream))
+    for t, sd in ((sA, 23), (sB, 24)):
+        hip.check(lib.clv_fill_random_scales(t.data_ptr(), t.numel(), sd, 0, stream))
+
+    def step():
+        hip.check(lib.clm4_gemm(A.data_ptr(), sA.data_ptr(), G, G, B.data_ptr(), sB.data_ptr(), G, Cm.data_ptr(), stream))
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = elapsed / args.steps * 1e3
+    call_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    ops = 2.0 * G ** 3
+    tops = ops / (ms * 1e-3) / 1e12
+    ach = ops / (call_ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "int4 GEMM (CloverMatrix4 x CloverMatrix4^T -> fp32) TOP/s, 2 M N K / time", "value": round(tops, 1), "unit": "TOP/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int4", "data": "synthetic",
+        "config": {"workload": f"CloverMatrix4::gemm {G}x{G}x{G} int4 (BASELINE configs[3]), bit-exact against the build-defined "
+                               "semantics (one fma chain over the 64-element K-blocks per element)", "M": G, "N": G, "K": G,
+                   "parallelism": "1 GPU"},
+        "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": 5000.0, "unit": "TOP/s", "frac": round(ach / 5000.0, 4),
+                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6 (one clm4_gemm call)", "kernel_avg_ms": round(call_ms, 5),
+                     "peak_note": "5 POP/s = dense int8 MFMA, the pipe BASELINE names; the kernel runs on the FP6 block-scaled pipe "
+                                  "(10 PF dense): frac of that = " + str(round(ach / 10000.0, 4)) + "; matrix-pipe busy cycles from PMC in "
+                                  "profiles/r01_gemm_fp6_8192_pmc.txt"},
+    }))
 
 
 def extras(hip, torch, dev, stream) -> dict:
