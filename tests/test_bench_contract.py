@@ -1,0 +1,49 @@
+"""bench.py keeps the driver's contract: one JSON line with the agreed keys (small shapes here; the real run is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def _run(args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_help_runs_without_a_gpu():
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+@pytest.mark.gpu
+def test_mvm_line():
+    d = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--rows-per-gpu", "8192", "--cols", "8192", "--cpu-sample-rows", "1024"])
+    for k in CONTRACT + ("cpu_baseline",):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "GB/s" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["scaling"] == "weak" and d["dtype"] == "int4" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "GB/s" and cb["gpu_result_matches_cpu"] is True
+
+
+@pytest.mark.gpu
+def test_gemm_line():
+    d = _run(["--workload", "gemm", "--gemm-size", "1024", "--steps", "3", "--warmup", "1"])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["unit"] == "TOP/s" and d["roofline"]["bound"] == "mfma" and d["value"] > 0
