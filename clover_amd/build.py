@@ -78,6 +78,9 @@ def build_oracle(force: bool = False) -> Path:
     if force:
         subprocess.run(["make", "-C", str(odir), "clean"], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(["make", "-C", str(odir), "all"], check=True, stdout=subprocess.DEVNULL)
+    # oracle/_ref: the reference's generator header compiled from /root/reference where that tree exists (this container);
+    # a no-op on the GPU box, which uses the prebuilt oracle/_ref/*.so that travelled with the snapshot
+    subprocess.run(["make", "-C", str(odir), "ref"], check=True, stdout=subprocess.DEVNULL)
     return odir / "liboracle.so"
 
 

@@ -59,6 +59,14 @@ class Oracle:
         self.L.orc_rng_draw(C.byref(r), _p(w, C.POINTER(C.c_uint32)))
         return w
 
+    def rng_jump(self, r: OrcRng) -> None:
+        self.L.orc_rng_jump(C.byref(r))
+
+    def rng_digest(self, r: OrcRng, count: int) -> tuple[int, int]:
+        x, a = _u64(0), _u64(0)
+        self.L.orc_rng_digest(C.byref(r), _u64(count), C.byref(x), C.byref(a))
+        return x.value, a.value
+
     # -- vector --------------------------------------------------------------------------------
     def v4_quantize(self, x: np.ndarray, rng: OrcRng | None = None):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -239,3 +247,40 @@ class FastOracle:
         sr = np.zeros(rows // 64, np.float32) if out is None else out[1]
         self.L.orcf_m4_mvm(_p(qA, _u8p), _p(sA, _fp), _u64(rows), _u64(cols), _p(qx, _u8p), _p(sx, _fp), _p(r, _u8p), _p(sr, _fp))
         return r, sr
+
+
+class RefXorshift:
+    """The REFERENCE's generator itself (oracle/_ref/libxorshift_ref.so = oracle/ref_xorshift.cpp compiled over
+    /root/reference/include/simdxorshift128plus.h).  Built by `make -C oracle ref` where the reference tree exists; the
+    prebuilt .so travels to the GPU box.  available() is False where neither holds (then only the committed fixture pins)."""
+
+    PATH = _HERE / "_ref" / "libxorshift_ref.so"
+
+    @classmethod
+    def available(cls) -> bool:
+        if not cls.PATH.exists():
+            subprocess.run(["make", "-C", str(_HERE), "ref"], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return cls.PATH.exists()
+
+    def __init__(self):
+        if not self.available():
+            raise FileNotFoundError(str(self.PATH))
+        self.L = C.CDLL(str(self.PATH))
+
+    def init(self, key1: int, key2: int):
+        s0, s1 = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+        self.L.ref_xs_init(_u64(key1), _u64(key2), _p(s0, C.POINTER(_u64)), _p(s1, C.POINTER(_u64)))
+        return s0, s1
+
+    def draw(self, s0, s1, count: int) -> np.ndarray:
+        W = np.zeros(8 * count, np.uint32)
+        self.L.ref_xs_draw(_p(s0, C.POINTER(_u64)), _p(s1, C.POINTER(_u64)), _u64(count), _p(W, C.POINTER(C.c_uint32)))
+        return W.reshape(count, 8)
+
+    def digest(self, s0, s1, count: int) -> tuple[int, int]:
+        x, a = _u64(0), _u64(0)
+        self.L.ref_xs_digest(_p(s0, C.POINTER(_u64)), _p(s1, C.POINTER(_u64)), _u64(count), C.byref(x), C.byref(a))
+        return x.value, a.value
+
+    def jump(self, s0, s1) -> None:
+        self.L.ref_xs_jump(_p(s0, C.POINTER(_u64)), _p(s1, C.POINTER(_u64)))

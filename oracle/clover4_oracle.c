@@ -73,6 +73,29 @@ void orc_rng_draw(orc_rng *r, uint32_t W[8])
     }
 }
 
+/* avx_xorshift128plus_jump (simdxorshift128plus.h:115-127): new lane 0 = 2^64-step jump of OLD lane 3,
+ * lanes 1..3 chained from it -- a fresh, non-overlapping key for another thread. */
+void orc_rng_jump(orc_rng *r)
+{
+    canon_jump(r->s0[3], r->s1[3], &r->s0[0], &r->s1[0]);
+    for (int l = 1; l < 4; l++) canon_jump(r->s0[l - 1], r->s1[l - 1], &r->s0[l], &r->s1[l]);
+}
+
+/* `count` draws folded into two words (xor and wrapping sum of the four 64-bit lane outputs): long-stream checks */
+void orc_rng_digest(orc_rng *r, uint64_t count, uint64_t *xor_fold, uint64_t *sum)
+{
+    uint64_t x = 0, a = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        uint32_t W[8];
+        orc_rng_draw(r, W);
+        for (int l = 0; l < 4; l++) {
+            const uint64_t o = (uint64_t)W[2 * l] | ((uint64_t)W[2 * l + 1] << 32);
+            x ^= o; a += o;
+        }
+    }
+    *xor_fold = x; *sum = a;
+}
+
 /* CloverVector4.h:690-734: mask 0x7F7F7F7F, four byte-shifts per draw, int->float, times 2^-31. */
 void orc_rng_block_noise(orc_rng *r, float noise[8][8])
 {

@@ -10,8 +10,12 @@
  * and mkl.h unconditionally; neither exists here and stand-ins are not allowed), so the oracle is pinned
  * against the known-answer vectors captured from the reference's SIMD path that SURVEY.md Appendix D
  * records (KAT1..KAT3: quantize bytes + scales, dot bit patterns, restore bit patterns, matrix quantize +
- * mvm bytes + scales) -- see tests/test_oracle_kat.py.  The stochastic (XORShift) stream has no captured
- * vector: it is restated from include/simdxorshift128plus.h:97-109 and is "parity unpinned".
+ * mvm bytes + scales) -- see tests/test_oracle_kat.py.  The generator (a7) IS pinned on the reference: its
+ * header include/simdxorshift128plus.h builds standalone (oracle/ref_xorshift.cpp -> oracle/_ref/), and
+ * tests/golden/xorshift_ref.json (init lanes, 256 draws, 2^20-draw digest, jump) is generated from it by
+ * `make -C oracle ref-fixtures` -- see tests/test_xorshift_ref.py.  What remains "parity unpinned" is the
+ * noise DERIVATION from those draws and its lane maps (CloverVector4.h:690-734, :1236-1243; CloverMatrix4.h:
+ * 925-932), which live inside the unbuildable container headers: restated from the source only.
  *
  * All sizes are PADDED sizes (vector: multiple of 128 elements; matrix: rows, cols multiples of 128),
  * exactly as the reference's containers hold them (include/CloverVector.h:86-92, CloverMatrix.h:48-53).
@@ -36,6 +40,10 @@ typedef struct { uint64_t s0[4]; uint64_t s1[4]; } orc_rng;
 void     orc_rng_init(orc_rng *r, uint64_t key1, uint64_t key2);
 /* One avx_xorshift128plus draw (simdxorshift128plus.h:97-109): 8 x uint32, W[2k]=lo32(lane k). */
 void     orc_rng_draw(orc_rng *r, uint32_t W[8]);
+/* avx_xorshift128plus_jump (simdxorshift128plus.h:115-127). */
+void     orc_rng_jump(orc_rng *r);
+/* count draws -> xor-fold and wrapping sum of the 64-bit lane outputs (fixture: tests/golden/xorshift_ref.json) */
+void     orc_rng_digest(orc_rng *r, uint64_t count, uint64_t *xor_fold, uint64_t *sum);
 /* The 64 noises of one block (two draws), indexed [group g=0..7][lane j=0..7] (CloverVector4.h:690-734). */
 void     orc_rng_block_noise(orc_rng *r, float noise[8][8]);
 
