@@ -492,7 +492,9 @@ extern "C" int clvx_mvm_variant(int variant, const int8_t *A, const float *sA, u
 static int check_mvm_args(const char *fn, const void *A, const void *sA, uint64_t rows, uint64_t cols, const void *x, const void *sx)
 {
     CLV_REQUIRE(A && sA && x && sx, "%s: null pointer", fn);
-    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "%s: rows=%llu cols=%llu must be multiples of 128", fn,
+    // a whole CloverMatrix4 has rows % 128 == 0 (CloverMatrix.h:48-53); a multiple of 64 is a row shard of one -- the unit
+    // mvm_parallel hands a thread (CloverMatrix4.h:1700-1705) and clm4_sharded_* / sharding.py hand a GPU
+    CLV_REQUIRE(rows % 64 == 0 && cols % 128 == 0, "%s: rows=%llu must be a multiple of 64 and cols=%llu of 128", fn,
                 (unsigned long long)rows, (unsigned long long)cols);
     CLV_REQUIRE(rows / 64 <= 0x7FFFFFFFull, "%s: too many rows", fn);
     return CLV_OK;

@@ -584,7 +584,8 @@ static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t
 static int check_mvm8_args(const char *fn, const void *A, const void *sA, uint64_t rows, uint64_t cols, const void *x, const void *sx)
 {
     CLV_REQUIRE(A && sA && x && sx, "%s: null pointer", fn);
-    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0, "%s: rows=%llu cols=%llu must be multiples of 128", fn, (unsigned long long)rows,
+    // rows % 64: a row shard of a matrix (see check_mvm_args in matrix4.hip)
+    CLV_REQUIRE(rows % 64 == 0 && cols % 128 == 0, "%s: rows=%llu must be a multiple of 64 and cols=%llu of 128", fn, (unsigned long long)rows,
                 (unsigned long long)cols);
     CLV_REQUIRE(rows / 64 <= 0x7FFFFFFFull, "%s: too many rows", fn);
     return CLV_OK;

@@ -4,8 +4,10 @@
 // (CloverMatrix4.h:1700-1705).  The MI355X equivalent: contiguous row shards (multiples of 64 rows) per GPU,
 // x replicated (36 KiB for 65536 columns), the packed result all-gathered over xGMI with RCCL.  No partial
 // sum ever crosses a device, so the result is bit-identical to the single-GPU one -- never an all-reduce.
-// The gather moves rows/2 + rows/16 bytes in total (C5: 576 KiB): latency-bound, so it is issued as one
-// grouped set of broadcasts (works for unequal shards too) on each device's stream right behind its kernel.
+// The gather moves rows/2 + rows/16 bytes in total (C5: 576 KiB): latency-bound.  Equal shards (every BASELINE
+// configuration): ONE grouped pair of in-place ncclAllGather (nibbles, scales) per device, right behind its kernel on
+// the device's stream.  Ragged shards (rows/64 not divisible by ndev): one grouped set of broadcasts per owner.
+// Shards that repeat a device (a test layout: all the shard arithmetic on one GPU) exchange with plain copies.
 //
 // One process drives all devices (one stream + one RCCL communicator per device).  RCCL is dlopen'ed on
 // first use so that libclover_hip.so itself does not depend on it.  bench.py uses the other idiom (one
@@ -24,6 +26,8 @@ struct RcclApi {
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);      // optional
     ncclResult_t (*GroupStart)();
     ncclResult_t (*GroupEnd)();
     const char *(*GetErrorString)(ncclResult_t);
@@ -41,10 +45,12 @@ static RcclApi *rccl()
         a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
         a.Broadcast = (decltype(a.Broadcast))dlsym(h, "ncclBroadcast");
+        a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+        a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
         a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
         a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-        a.ok = a.CommInitAll && a.CommDestroy && a.Broadcast && a.GroupStart && a.GroupEnd && a.GetErrorString;
+        a.ok = a.CommInitAll && a.CommDestroy && a.Broadcast && a.AllGather && a.GroupStart && a.GroupEnd && a.GetErrorString;
         return a;
     }();
     return &api;
@@ -59,8 +65,27 @@ static RcclApi *rccl()
         }                                                                                               \
     } while (0)
 
+// restores the caller's current device on every return path
+struct DeviceGuard {
+    int cur = -1;
+    DeviceGuard() { if (hipGetDevice(&cur) != hipSuccess) cur = -1; }
+    ~DeviceGuard() { if (cur >= 0) (void)hipSetDevice(cur); }
+};
+
+// an RCCL group that is closed on every return path (an error between GroupStart and GroupEnd must not leave it open)
+struct RcclGroup {
+    bool open = false;
+    ncclResult_t start() { ncclResult_t r = rccl()->GroupStart(); open = (r == 0); return r; }
+    ncclResult_t end() { open = false; return rccl()->GroupEnd(); }
+    ~RcclGroup() { if (open) (void)rccl()->GroupEnd(); }
+};
+
 struct clm4_shard_ctx {
     int ndev = 0;
+    bool loopback = false;                  // some device listed twice: exchanges are plain copies, no RCCL (test layout)
+    bool equal = false;                     // all shards have the same number of rows: the gather is one ncclAllGather pair
+    std::vector<hipEvent_t> ev;             // 3 per shard: before the kernel, after it, after the gather
+    int rccl_ranks = 0;                     // communicator size RCCL reports having built (0: no communicator)
     uint64_t rows = 0, cols = 0;
     std::vector<int> dev;
     std::vector<uint64_t> row_begin, row_count;
@@ -88,12 +113,13 @@ extern "C" int clm4_shard_partition(uint64_t rows, int nparts, int part, uint64_
 extern "C" int clm4_sharded_destroy(clm4_shard_ctx *c)
 {
     if (!c) return CLV_OK;
-    int cur = 0;
-    (void)hipGetDevice(&cur);
+    DeviceGuard guard;
     for (int d = 0; d < (int)c->dev.size(); d++) {
         (void)hipSetDevice(c->dev[d]);
         if (d < (int)c->comm.size() && c->comm[d]) rccl()->CommDestroy(c->comm[d]);
         if (d < (int)c->st.size() && c->st[d]) (void)hipStreamDestroy(c->st[d]);
+        for (int e = 0; e < 3; e++)
+            if (3 * d + e < (int)c->ev.size() && c->ev[3 * d + e]) (void)hipEventDestroy(c->ev[3 * d + e]);
         void *ptrs[] = {d < (int)c->A.size() ? c->A[d] : nullptr, d < (int)c->x.size() ? c->x[d] : nullptr, d < (int)c->r.size() ? c->r[d] : nullptr,
                         d < (int)c->sA.size() ? c->sA[d] : nullptr, d < (int)c->sx.size() ? c->sx[d] : nullptr, d < (int)c->sr.size() ? c->sr[d] : nullptr};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -101,7 +127,6 @@ extern "C" int clm4_sharded_destroy(clm4_shard_ctx *c)
                          d < (int)c->C.size() ? (void *)c->C[d] : nullptr};
         for (void *p : gptrs) if (p) (void)hipFree(p);
     }
-    (void)hipSetDevice(cur);
     delete c;
     return CLV_OK;
 }
@@ -113,9 +138,7 @@ extern "C" int clm4_sharded_create(clm4_shard_ctx **out, int ndev, const int *de
                 (unsigned long long)rows, (unsigned long long)cols, ndev);
     int avail = 0;
     CLV_HIP(hipGetDeviceCount(&avail));
-    CLV_REQUIRE(ndev <= avail, "clm4_sharded_create: %d devices requested, %d visible", ndev, avail);
-    int cur = 0;
-    CLV_HIP(hipGetDevice(&cur));
+    DeviceGuard guard;
     clm4_shard_ctx *c = new clm4_shard_ctx;
     c->ndev = ndev;
     c->rows = rows;
@@ -127,29 +150,40 @@ extern "C" int clm4_sharded_create(clm4_shard_ctx **out, int ndev, const int *de
     c->sA.assign(ndev, nullptr); c->sx.assign(ndev, nullptr); c->sr.assign(ndev, nullptr);
     c->st.assign(ndev, nullptr);
     c->comm.assign(ndev, nullptr);
+    c->ev.assign(3 * (size_t)ndev, nullptr);
     int rc = CLV_OK;
     for (int d = 0; d < ndev && rc == CLV_OK; d++) {
         c->dev[d] = devices ? devices[d] : d;
+        if (c->dev[d] < 0 || c->dev[d] >= avail) {
+            clv_set_error("clm4_sharded_create: device %d requested, %d visible", c->dev[d], avail);
+            rc = CLV_ERR_INVALID;
+            break;
+        }
+        for (int e = 0; e < d; e++) c->loopback |= (c->dev[e] == c->dev[d]);
         clm4_shard_partition(rows, ndev, d, &c->row_begin[d], &c->row_count[d]);
         auto alloc = [&](void **p, uint64_t bytes) { return hipMalloc(p, bytes ? bytes : 1) == hipSuccess; };
-        if (hipSetDevice(c->dev[d]) != hipSuccess || hipStreamCreateWithFlags(&c->st[d], hipStreamNonBlocking) != hipSuccess ||
-            !alloc((void **)&c->A[d], c->row_count[d] * cols / 2) || !alloc((void **)&c->sA[d], (c->row_count[d] / 64) * (cols / 64) * 4) ||
+        bool ok = hipSetDevice(c->dev[d]) == hipSuccess && hipStreamCreateWithFlags(&c->st[d], hipStreamNonBlocking) == hipSuccess;
+        for (int e = 0; e < 3 && ok; e++) ok = hipEventCreate(&c->ev[3 * d + e]) == hipSuccess;
+        if (!ok || !alloc((void **)&c->A[d], c->row_count[d] * cols / 2) || !alloc((void **)&c->sA[d], (c->row_count[d] / 64) * (cols / 64) * 4) ||
             !alloc((void **)&c->x[d], cols / 2) || !alloc((void **)&c->sx[d], cols / 16) || !alloc((void **)&c->r[d], rows / 2) ||
             !alloc((void **)&c->sr[d], rows / 16)) {
             clv_set_error("clm4_sharded_create: device %d setup failed: %s", c->dev[d], hipGetErrorString(hipGetLastError()));
             rc = CLV_ERR_HIP;
         }
     }
-    if (rc == CLV_OK && ndev > 1) {
+    c->equal = (rows / 64) % (uint64_t)ndev == 0;
+    if (rc == CLV_OK && ndev > 1 && !c->loopback) {
         if (!rccl()->ok) {
             clv_set_error("clm4_sharded_create: librccl.so could not be loaded");
             rc = CLV_ERR_UNSUPPORTED;
         } else if (ncclResult_t r = rccl()->CommInitAll(c->comm.data(), ndev, c->dev.data())) {
             clv_set_error("ncclCommInitAll failed: %s", rccl()->GetErrorString(r));
             rc = CLV_ERR_HIP;
+        } else {
+            c->rccl_ranks = ndev;
+            if (rccl()->CommCount) (void)rccl()->CommCount(c->comm[0], &c->rccl_ranks);
         }
     }
-    (void)hipSetDevice(cur);
     if (rc != CLV_OK) { clm4_sharded_destroy(c); return rc; }
     *out = c;
     return CLV_OK;
@@ -171,8 +205,7 @@ extern "C" int clm4_sharded_info(const clm4_shard_ctx *c, int part, int *device,
 extern "C" int clm4_sharded_upload(clm4_shard_ctx *c, const int8_t *A_host, const float *sA_host)
 {
     CLV_REQUIRE(c && A_host && sA_host, "clm4_sharded_upload: null argument");
-    int cur = 0;
-    CLV_HIP(hipGetDevice(&cur));
+    DeviceGuard guard;
     const uint64_t hb = c->cols / 64;
     for (int d = 0; d < c->ndev; d++) {
         CLV_HIP(hipSetDevice(c->dev[d]));
@@ -180,7 +213,6 @@ extern "C" int clm4_sharded_upload(clm4_shard_ctx *c, const int8_t *A_host, cons
         CLV_HIP(hipMemcpyAsync(c->sA[d], sA_host + (c->row_begin[d] / 64) * hb, (c->row_count[d] / 64) * hb * 4, hipMemcpyHostToDevice, c->st[d]));
     }
     for (int d = 0; d < c->ndev; d++) { CLV_HIP(hipSetDevice(c->dev[d])); CLV_HIP(hipStreamSynchronize(c->st[d])); }
-    CLV_HIP(hipSetDevice(cur));
     return CLV_OK;
 }
 
@@ -188,8 +220,7 @@ extern "C" int clm4_sharded_upload(clm4_shard_ctx *c, const int8_t *A_host, cons
 extern "C" int clm4_sharded_fill_random(clm4_shard_ctx *c, uint64_t seed)
 {
     CLV_REQUIRE(c, "clm4_sharded_fill_random: null argument");
-    int cur = 0;
-    CLV_HIP(hipGetDevice(&cur));
+    DeviceGuard guard;
     const uint64_t hb = c->cols / 64;
     int rc = CLV_OK;
     for (int d = 0; d < c->ndev && rc == CLV_OK; d++) {
@@ -198,8 +229,29 @@ extern "C" int clm4_sharded_fill_random(clm4_shard_ctx *c, uint64_t seed)
         if (rc == CLV_OK) rc = clv_fill_random_scales(c->sA[d], (c->row_count[d] / 64) * hb, seed + 1, (c->row_begin[d] / 64) * hb, c->st[d]);
     }
     for (int d = 0; d < c->ndev; d++) { CLV_HIP(hipSetDevice(c->dev[d])); CLV_HIP(hipStreamSynchronize(c->st[d])); }
-    CLV_HIP(hipSetDevice(cur));
     return rc;
+}
+
+// replicate `bytes` at p[0] (already enqueued on st[0]) to p[d] for every shard
+static int replicate_from_0(clm4_shard_ctx *c, void *const *p, uint64_t bytes)
+{
+    if (c->ndev == 1) return CLV_OK;
+    if (c->loopback) {
+        // same-process test layout: order the copies behind shard 0's stream with an event
+        CLV_HIP(hipSetDevice(c->dev[0]));
+        CLV_HIP(hipEventRecord(c->ev[2], c->st[0]));
+        for (int d = 1; d < c->ndev; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            CLV_HIP(hipStreamWaitEvent(c->st[d], c->ev[2], 0));
+            CLV_HIP(hipMemcpyAsync(p[d], p[0], bytes, hipMemcpyDeviceToDevice, c->st[d]));
+        }
+        return CLV_OK;
+    }
+    RcclGroup g;
+    CLV_NCCL(g.start());
+    for (int d = 0; d < c->ndev; d++) CLV_NCCL(rccl()->Broadcast(p[d], p[d], bytes, ncclInt8, 0, c->comm[d], c->st[d]));
+    CLV_NCCL(g.end());
+    return CLV_OK;
 }
 
 // r = A * x on all shards, result all-gathered so that EVERY device ends up with the full packed result.
@@ -208,45 +260,88 @@ extern "C" int clm4_sharded_fill_random(clm4_shard_ctx *c, uint64_t seed)
 extern "C" int clm4_sharded_mvm(clm4_shard_ctx *c, const int8_t *x, const float *sx, int x_on_host, int8_t *r_host, float *sr_host)
 {
     CLV_REQUIRE(c && x && sx, "clm4_sharded_mvm: null argument");
-    int cur = 0;
-    CLV_HIP(hipGetDevice(&cur));
+    DeviceGuard guard;
     const uint64_t cols = c->cols;
-    // 1. x to device 0, then to everyone
+    const int n = c->ndev;
+    // 1. x to shard 0, then to everyone
     CLV_HIP(hipSetDevice(c->dev[0]));
     const hipMemcpyKind kind = x_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     CLV_HIP(hipMemcpyAsync(c->x[0], x, cols / 2, kind, c->st[0]));
     CLV_HIP(hipMemcpyAsync(c->sx[0], sx, cols / 16, kind, c->st[0]));
-    if (c->ndev > 1) {
-        CLV_NCCL(rccl()->GroupStart());
-        for (int d = 0; d < c->ndev; d++) {
-            CLV_NCCL(rccl()->Broadcast(c->x[d], c->x[d], cols / 2, ncclInt8, 0, c->comm[d], c->st[d]));
-            CLV_NCCL(rccl()->Broadcast(c->sx[d], c->sx[d], cols / 64, ncclFloat32, 0, c->comm[d], c->st[d]));
-        }
-        CLV_NCCL(rccl()->GroupEnd());
-    }
+    int rc = replicate_from_0(c, (void *const *)c->x.data(), cols / 2);
+    if (rc == CLV_OK) rc = replicate_from_0(c, (void *const *)c->sx.data(), cols / 16);
+    if (rc != CLV_OK) return rc;
     // 2. every shard multiplies, writing its slice of its own copy of the full result
-    for (int d = 0; d < c->ndev; d++) {
+    for (int d = 0; d < n; d++) {
         CLV_HIP(hipSetDevice(c->dev[d]));
-        int rc = clm4_mvm(c->A[d], c->sA[d], c->row_count[d], cols, c->x[d], c->sx[d], c->r[d] + c->row_begin[d] / 2,
-                          c->sr[d] + c->row_begin[d] / 64, nullptr, c->st[d]);
-        if (rc != CLV_OK) { (void)hipSetDevice(cur); return rc; }
+        CLV_HIP(hipEventRecord(c->ev[3 * d + 0], c->st[d]));
+        rc = clm4_mvm(c->A[d], c->sA[d], c->row_count[d], cols, c->x[d], c->sx[d], c->r[d] + c->row_begin[d] / 2,
+                      c->sr[d] + c->row_begin[d] / 64, nullptr, c->st[d]);
+        if (rc != CLV_OK) return rc;
+        CLV_HIP(hipEventRecord(c->ev[3 * d + 1], c->st[d]));
     }
-    // 3. all-gather of the packed slices = one broadcast per owner, grouped
-    if (c->ndev > 1) {
-        CLV_NCCL(rccl()->GroupStart());
-        for (int root = 0; root < c->ndev; root++)
-            for (int d = 0; d < c->ndev; d++) {
+    // 3. all-gather of the packed slices
+    if (n > 1 && c->loopback) {
+        // every shard's slice is complete at its ev[1]; the consumers wait for it and copy
+        for (int d = 0; d < n; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            for (int o = 0; o < n; o++) {
+                if (o == d) continue;
+                CLV_HIP(hipStreamWaitEvent(c->st[d], c->ev[3 * o + 1], 0));
+                CLV_HIP(hipMemcpyAsync(c->r[d] + c->row_begin[o] / 2, c->r[o] + c->row_begin[o] / 2, c->row_count[o] / 2, hipMemcpyDeviceToDevice, c->st[d]));
+                CLV_HIP(hipMemcpyAsync(c->sr[d] + c->row_begin[o] / 64, c->sr[o] + c->row_begin[o] / 64, c->row_count[o] / 16, hipMemcpyDeviceToDevice, c->st[d]));
+            }
+        }
+    } else if (n > 1 && c->equal) {
+        // in place: rank d's contribution already sits at offset d * count of its receive buffer
+        const uint64_t rc_rows = c->row_count[0];
+        RcclGroup g;
+        CLV_NCCL(g.start());
+        for (int d = 0; d < n; d++) {
+            CLV_NCCL(rccl()->AllGather(c->r[d] + c->row_begin[d] / 2, c->r[d], rc_rows / 2, ncclInt8, c->comm[d], c->st[d]));
+            CLV_NCCL(rccl()->AllGather(c->sr[d] + c->row_begin[d] / 64, c->sr[d], rc_rows / 64, ncclFloat32, c->comm[d], c->st[d]));
+        }
+        CLV_NCCL(g.end());
+    } else if (n > 1) {
+        RcclGroup g;
+        CLV_NCCL(g.start());
+        for (int root = 0; root < n; root++)
+            for (int d = 0; d < n; d++) {
                 int8_t *pr = c->r[d] + c->row_begin[root] / 2;
                 float *ps = c->sr[d] + c->row_begin[root] / 64;
                 CLV_NCCL(rccl()->Broadcast(pr, pr, c->row_count[root] / 2, ncclInt8, root, c->comm[d], c->st[d]));
                 CLV_NCCL(rccl()->Broadcast(ps, ps, c->row_count[root] / 64, ncclFloat32, root, c->comm[d], c->st[d]));
             }
-        CLV_NCCL(rccl()->GroupEnd());
+        CLV_NCCL(g.end());
     }
-    for (int d = 0; d < c->ndev; d++) { CLV_HIP(hipSetDevice(c->dev[d])); CLV_HIP(hipStreamSynchronize(c->st[d])); }
+    for (int d = 0; d < n; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        CLV_HIP(hipEventRecord(c->ev[3 * d + 2], c->st[d]));
+    }
+    for (int d = 0; d < n; d++) { CLV_HIP(hipSetDevice(c->dev[d])); CLV_HIP(hipStreamSynchronize(c->st[d])); }
     if (r_host) { CLV_HIP(hipSetDevice(c->dev[0])); CLV_HIP(hipMemcpy(r_host, c->r[0], c->rows / 2, hipMemcpyDeviceToHost)); }
     if (sr_host) { CLV_HIP(hipSetDevice(c->dev[0])); CLV_HIP(hipMemcpy(sr_host, c->sr[0], c->rows / 16, hipMemcpyDeviceToHost)); }
-    CLV_HIP(hipSetDevice(cur));
+    return CLV_OK;
+}
+
+// what the last clm4_sharded_mvm spent on shard `part`: its kernel and the exchange behind it (HIP events on the shard's stream)
+extern "C" int clm4_sharded_timing(const clm4_shard_ctx *c, int part, float *mvm_ms, float *gather_ms)
+{
+    CLV_REQUIRE(c && part >= 0 && part < c->ndev, "clm4_sharded_timing: bad argument");
+    DeviceGuard guard;
+    CLV_HIP(hipSetDevice(c->dev[part]));
+    if (mvm_ms) CLV_HIP(hipEventElapsedTime(mvm_ms, c->ev[3 * part + 0], c->ev[3 * part + 1]));
+    if (gather_ms) CLV_HIP(hipEventElapsedTime(gather_ms, c->ev[3 * part + 1], c->ev[3 * part + 2]));
+    return CLV_OK;
+}
+
+// how the shards exchange: ranks in the RCCL communicator (0: none -- one shard, or the same-device test layout),
+// and whether the gather is the single all-gather (equal shards) or the per-owner broadcasts (ragged)
+extern "C" int clm4_sharded_comm_info(const clm4_shard_ctx *c, int *rccl_ranks, int *equal_shards)
+{
+    CLV_REQUIRE(c, "clm4_sharded_comm_info: null argument");
+    if (rccl_ranks) *rccl_ranks = c->rccl_ranks;
+    if (equal_shards) *equal_shards = c->equal ? 1 : 0;
     return CLV_OK;
 }
 
@@ -269,8 +364,7 @@ extern "C" int clm4_sharded_gemm(clm4_shard_ctx *c, const int8_t *B, const float
     CLV_REQUIRE(c && B && sB && N && N % 128 == 0, "clm4_sharded_gemm: bad argument");
     for (int d = 0; d < c->ndev; d++)
         CLV_REQUIRE(c->row_count[d] % 128 == 0, "clm4_sharded_gemm: shard %d has %llu rows, not a multiple of 128", d, (unsigned long long)c->row_count[d]);
-    int cur = 0;
-    CLV_HIP(hipGetDevice(&cur));
+    DeviceGuard guard;
     const uint64_t K = c->cols, b_bytes = N * K / 2, sb_count = (N / 64) * (K / 64);
     if (c->gemm_n != N) {                                      // (re)allocate B and the C shards for this N
         c->B.resize(c->ndev, nullptr); c->sB.resize(c->ndev, nullptr); c->C.resize(c->ndev, nullptr);
@@ -292,26 +386,21 @@ extern "C" int clm4_sharded_gemm(clm4_shard_ctx *c, const int8_t *B, const float
     const hipMemcpyKind kind = b_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     CLV_HIP(hipMemcpyAsync(c->B[0], B, b_bytes, kind, c->st[0]));
     CLV_HIP(hipMemcpyAsync(c->sB[0], sB, sb_count * sizeof(float), kind, c->st[0]));
-    if (c->ndev > 1) {
-        CLV_NCCL(rccl()->GroupStart());
-        for (int d = 0; d < c->ndev; d++) {
-            CLV_NCCL(rccl()->Broadcast(c->B[d], c->B[d], b_bytes, ncclInt8, 0, c->comm[d], c->st[d]));
-            CLV_NCCL(rccl()->Broadcast(c->sB[d], c->sB[d], sb_count, ncclFloat32, 0, c->comm[d], c->st[d]));
-        }
-        CLV_NCCL(rccl()->GroupEnd());
-    }
+    int rrc = replicate_from_0(c, (void *const *)c->B.data(), b_bytes);
+    if (rrc == CLV_OK) rrc = replicate_from_0(c, (void *const *)c->sB.data(), sb_count * sizeof(float));
+    if (rrc != CLV_OK) return rrc;
     // 2. every device multiplies its row shard
     for (int d = 0; d < c->ndev; d++) {
         CLV_HIP(hipSetDevice(c->dev[d]));
         int rc = clm4_gemm(c->A[d], c->sA[d], c->row_count[d], K, c->B[d], c->sB[d], N, c->C[d], c->st[d]);
-        if (rc != CLV_OK) { (void)hipSetDevice(cur); return rc; }
+        if (rc != CLV_OK) return rc;
+        if (c->loopback) CLV_HIP(hipStreamSynchronize(c->st[d]));      // shards of one device share clm4_gemm's per-device workspace
     }
     for (int d = 0; d < c->ndev; d++) {
         CLV_HIP(hipSetDevice(c->dev[d]));
         CLV_HIP(hipStreamSynchronize(c->st[d]));
         if (C_host) CLV_HIP(hipMemcpy(C_host + c->row_begin[d] * N, c->C[d], c->row_count[d] * N * sizeof(float), hipMemcpyDeviceToHost));
     }
-    CLV_HIP(hipSetDevice(cur));
     return CLV_OK;
 }
 

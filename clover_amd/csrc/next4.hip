@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
 extern "C" int clm4_mvm_f32(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const float *x, float *r, void *stream)
 {
     CLV_REQUIRE(A && sA && x && r, "clm4_mvm_f32: null pointer");
-    CLV_REQUIRE(rows % 128 == 0 && cols % 128 == 0 && rows / 64 <= 0x7FFFFFFFull, "clm4_mvm_f32: rows=%llu cols=%llu must be multiples of 128",
+    CLV_REQUIRE(rows % 64 == 0 && cols % 128 == 0 && rows / 64 <= 0x7FFFFFFFull, "clm4_mvm_f32: rows=%llu must be a multiple of 64 (a row shard) and cols=%llu of 128",
                 (unsigned long long)rows, (unsigned long long)cols);
     if (!rows) return CLV_OK;
     const size_t lds = (MVF_CHUNK + MVF_CHUNK / 64) * sizeof(float);                     // 65 KiB

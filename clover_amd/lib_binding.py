@@ -77,6 +77,8 @@ SIGNATURES = {
     "clm4_sharded_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), _u64, _u64]),
     "clm4_sharded_destroy": (C.c_int, [_vp]),
     "clm4_sharded_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_vp), C.POINTER(_vp)]),
+    "clm4_sharded_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "clm4_sharded_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "clm4_sharded_upload": (C.c_int, [_vp, _vp, _vp]),
     "clm4_sharded_fill_random": (C.c_int, [_vp, _u64]),
     "clm4_sharded_mvm": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),

@@ -11,7 +11,9 @@
  *  - plain C, no C++/torch types.  Every data pointer is a DEVICE pointer (HBM) unless the name says
  *    `host`; `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *  - sizes are the PADDED sizes the reference containers hold: vector length_pad (multiple of 128,
- *    CloverVector.h:86-92), matrix rows/cols (multiples of 128, CloverMatrix.h:48-53).
+ *    CloverVector.h:86-92), matrix rows/cols (multiples of 128, CloverMatrix.h:48-53).  The mvm family (clm4_mvm,
+ *    clm4_rowdots, clm4_mvm_scale_and_add, clm4_mvm_v8*, clm4_rowdots_v8, clm4_mvm_f32) also accepts rows % 64 == 0:
+ *    a row shard of a matrix, the unit mvm_parallel gives a thread (CloverMatrix4.h:1700-1705).
  *  - data format = the reference's: byte i holds element 2i in its HIGH nibble and 2i+1 in its LOW nibble,
  *    two's complement, values in [-7,7] (CloverVector4.h:511-514); one fp32 scale (the block's absolute
  *    maximum, 0 -> 1.0) per 64 elements (CloverVector4.h:661-673) / per 64x64 tile, row-major tile grid
@@ -199,7 +201,9 @@ int  clm4_iht(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const fl
  * packed result is all-gathered; no partial sums cross devices, so results equal clm4_mvm bit for bit. */
 typedef struct clm4_shard_ctx clm4_shard_ctx;
 int  clm4_shard_partition(uint64_t rows, int nparts, int part, uint64_t *row_begin, uint64_t *row_count);
-int  clm4_sharded_create(clm4_shard_ctx **ctx, int ndev, const int *devices /* NULL: 0..ndev-1 */, uint64_t rows, uint64_t cols);
+/* devices: NULL = 0..ndev-1.  Listing a device more than once is allowed (all shard arithmetic on fewer GPUs, exchanges become
+ * plain copies, no RCCL): the layout tests use to run ragged and 8-way partitions on one GPU. */
+int  clm4_sharded_create(clm4_shard_ctx **ctx, int ndev, const int *devices, uint64_t rows, uint64_t cols);
 int  clm4_sharded_destroy(clm4_shard_ctx *ctx);
 int  clm4_sharded_info(const clm4_shard_ctx *ctx, int part, int *device, uint64_t *row_begin, uint64_t *row_count,
                        int8_t **A_dev, float **sA_dev);
@@ -210,6 +214,11 @@ int  clm4_sharded_fill_random(clm4_shard_ctx *ctx, uint64_t seed);
 /* r = A*x; every device ends with the full packed result; r_host/sr_host (optional) receive a copy */
 int  clm4_sharded_mvm(clm4_shard_ctx *ctx, const int8_t *x, const float *sx, int x_on_host, int8_t *r_host, float *sr_host);
 int  clm4_sharded_result(const clm4_shard_ctx *ctx, int part, const int8_t **r_dev, const float **sr_dev);
+/* what the last clm4_sharded_mvm spent on shard `part`: its kernel and the exchange behind it (HIP events on that shard's stream) */
+int  clm4_sharded_timing(const clm4_shard_ctx *ctx, int part, float *mvm_ms, float *gather_ms);
+/* ranks in the RCCL communicator the context built (0: none needed), and whether the gather is the single ncclAllGather pair
+ * (equal shards) or the per-owner broadcasts (ragged shards) */
+int  clm4_sharded_comm_info(const clm4_shard_ctx *ctx, int *rccl_ranks, int *equal_shards);
 /* C = A * B^T with the sharded A and an N x cols CloverMatrix4 B (host memory or device `part 0`) replicated on every device:
  * device d ends with its rows of C (fp32, N columns), bit-identical to clm4_gemm on the whole matrix; nothing is exchanged
  * between the shards.  Every shard must be a multiple of 128 rows.  C_host (optional) receives the whole C. */

@@ -39,7 +39,9 @@ def test_error_codes_without_compute():
     # argument validation happens before any device work: callable on a CPU-only box
     assert lib.clv4_quantize(None, 128, None, None, None, None) == -1
     assert b"null" in lib.clv_last_error()
-    assert lib.clm4_mvm(1, 1, 100, 128, 1, 1, 1, 1, None, None) == -1   # rows not a multiple of 128
+    assert lib.clm4_mvm(1, 1, 100, 128, 1, 1, 1, 1, None, None) == -1   # rows not a multiple of 64
+    assert b"multiple of 64" in lib.clv_last_error()
+    assert lib.clm4_gemm(1, 1, 192, 128, 1, 1, 128, 1, None) == -1       # a GEMM operand is a whole matrix: multiples of 128
     assert b"multiples of 128" in lib.clv_last_error()
     n = ctypes.c_int(-1)
     assert lib.clv_device_count(ctypes.byref(n)) == 0 and n.value >= 0

@@ -3,8 +3,10 @@
 
   C2  quantize + dot, n = 2^24         : bit-exact vs the AVX2 restatement (itself == scalar oracle)
   C3  mvm 65536 x 65536                : sampled 64-row output blocks vs the scalar oracle; shard == whole
-  C4  gemm (8192^3 is ~1e12 ops)       : 2048^3 here, sampled elements vs the oracle's definition
-  C5  row sharding                     : concatenated shard results == unsharded result, byte for byte
+  C4  gemm 8192^3 (and 2048^3)         : sampled elements of the full result vs the oracle's definition
+  C5  mvm 2^20 x 2^16, row-sharded     : the whole 32 GiB matrix on ONE GPU: the 8 shards of 131072 x 65536 an 8-GPU node would
+                                         hold, run one after the other, == the unsharded call byte for byte; sampled 64-row blocks of
+                                         every shard vs the scalar oracle
 """
 import ctypes as C
 
@@ -89,6 +91,47 @@ def test_c3_mvm_65536_sampled_and_sharded(hip, oracle):
     assert same(np.concatenate(parts_r), r_h) and same(np.concatenate(parts_s), sr_h)
 
 
+def test_c5_whole_matrix_and_its_eight_shards_on_one_gpu(hip, oracle):
+    """BASELINE config 5 (mvm 2^20 x 2^16, 8 row shards of 131072 x 65536 = 4 GiB + 8 MiB each) on a single MI355X: the 32 GiB
+    matrix fits its 288 GB.  Each shard is generated where an 8-GPU rank would generate it (same seed, byte offset of the shard:
+    what bench.py --gpus 8 --rows-per-gpu 131072 does), multiplied on its own, and the concatenation must equal the unsharded call."""
+    rows, cols, parts = 1 << 20, 1 << 16, 8
+    hb, shard = cols // 64, (1 << 20) // 8
+    A = hip.alloc(rows * cols // 2)
+    sA = hip.alloc((rows // 64) * hb * 4)
+    x, sx = hip.alloc(cols // 2), hip.alloc(hb * 4)
+    lib = hip.lib
+    for k in range(parts):                   # per-shard generation == whole-matrix generation (counter-based fill)
+        hip.check(lib.clv_fill_random_nibbles(A.ptr + k * shard * cols // 2, shard * cols // 2, 0xC5, k * shard * cols // 2, None))
+        hip.check(lib.clv_fill_random_scales(sA.ptr + k * (shard // 64) * hb * 4, (shard // 64) * hb, 0xC6, k * (shard // 64) * hb, None))
+    hip.check(lib.clv_fill_random_nibbles(x.ptr, x.nbytes, 0xC7, 0, None))
+    hip.check(lib.clv_fill_random_scales(sx.ptr, hb, 0xC8, 0, None))
+    r, sr = hip.alloc(rows // 2), hip.alloc(rows // 64 * 4)
+    hip.check(lib.clm4_mvm(A.ptr, sA.ptr, rows, cols, x.ptr, sx.ptr, r.ptr, sr.ptr, None, None))
+    r_h, sr_h = r.download(np.uint8), sr.download(np.float32)
+    qx, sxh = x.download(np.uint8), sx.download(np.float32)
+    parts_r, parts_s = [], []
+    for k in range(parts):
+        rk, srk = hip.alloc(shard // 2), hip.alloc(shard // 64 * 4)
+        hip.check(lib.clm4_mvm(A.ptr + k * shard * cols // 2, sA.ptr + k * (shard // 64) * hb * 4, shard, cols, x.ptr, sx.ptr, rk.ptr, srk.ptr, None, None))
+        parts_r.append(rk.download(np.uint8))
+        parts_s.append(srk.download(np.float32))
+    assert same(np.concatenate(parts_r), r_h) and same(np.concatenate(parts_s), sr_h)
+    assert len(set(r_h[:: 4099].tolist())) > 16            # not a constant
+    # sampled 64-row blocks, at least one in every shard incl. first / last block of a shard, vs the scalar oracle
+    groups = sorted({0, 1, rows // 64 - 1} | {k * (shard // 64) + o for k in range(parts) for o in (0, 1027, shard // 64 - 1)})
+    for g in groups[::2] + [groups[-1]]:
+        blk = _download(hip, A.ptr + g * 64 * cols // 2, 64 * cols // 2, np.uint8)
+        sblk = _download(hip, sA.ptr + g * hb * 4, hb * 4, np.float32)
+        d = oracle.m4_rowdots(blk, sblk, 64, cols, qx, sxh)
+        ro, sro = oracle.v4_quantize(np.concatenate([d, np.zeros(64, np.float32)]))
+        assert same(r_h[g * 32:(g + 1) * 32], ro[:32]) and bits(sr_h[g]) == bits(sro[0]), g
+    # the fill of a shard is the whole matrix's bytes at that offset (checked on the last shard's first KiB against a fresh fill)
+    probe = hip.alloc(1024)
+    hip.check(lib.clv_fill_random_nibbles(probe.ptr, 1024, 0xC5, (parts - 1) * shard * cols // 2, None))
+    assert same(probe.download(np.uint8), _download(hip, A.ptr + (parts - 1) * shard * cols // 2, 1024, np.uint8))
+
+
 def test_mvm_few_row_groups_streaming_matrix(hip, oracle):
     """a matrix that streams from HBM (> 256 MiB) but has only 16 row groups takes the 8-lanes-per-row kernel; 11 LDS chunks
     of columns; plain and fused-with-scaleAndAdd, against the whole oracle result"""
@@ -112,8 +155,10 @@ def test_mvm_few_row_groups_streaming_matrix(hip, oracle):
     assert same(r2.download(np.uint8), r2o) and same(sr2.download(np.float32), sr2o)
 
 
-def test_gemm_2048_sampled(hip, oracle):
-    M = N = K = 2048
+@pytest.mark.parametrize("G", [2048, 8192])
+def test_gemm_sampled_against_definition(hip, oracle, G):
+    """8192^3 is BASELINE config 4 -- the very call bench.py times"""
+    M = N = K = G
     kb = K // 64
     A, sA, _, _ = _device_matrix(hip, M, K, 0x6E)
     B, sB, _, _ = _device_matrix(hip, N, K, 0x6F)
