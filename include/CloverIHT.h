@@ -14,17 +14,19 @@
 #include "CloverMatrix4.h"
 #include "CloverVector4.h"
 
+/* Generic forms, for any container pair with the reference's method names (the five steps of 01_measure.h:930-944):
+ * residual r = y - Phi x, gradient g = Phi' r, step x += mu g, then (IHT only) keep the K largest entries. */
 template <class QMatrix, class QVector>
 inline void Q_IHT(QMatrix &Phi, QMatrix &PhiT, QVector &x, QVector &y, QVector &t1, QVector &t2, QVector &t3,
                   const uint64_t iterations, const uint64_t K, const float mu)
 {
     x.clear();
-    for (uint64_t i = 0; i < iterations; i += 1) {
-        Phi.mvm_parallel(x, t1);                 // t1 = Phi * x
-        y.scaleAndAdd_parallel(t1, -1.0f, t2);   // t2 = y - Phi * x
-        PhiT.mvm_parallel(t2, t3);               // t3 = Phi' * (y - Phi * x)
-        x.scaleAndAdd_parallel(t3, mu);          // x = x + mu * Phi' * (y - Phi * x)
-        x.threshold_parallel(K);                 // hard thresholding
+    for (uint64_t it = 0; it < iterations; ++it) {
+        Phi.mvm_parallel(x, t1);
+        y.scaleAndAdd_parallel(t1, -1.0f, t2);
+        PhiT.mvm_parallel(t2, t3);
+        x.scaleAndAdd_parallel(t3, mu);
+        x.threshold_parallel(K);
     }
 }
 
@@ -33,7 +35,7 @@ inline void Q_GD(QMatrix &Phi, QMatrix &PhiT, QVector &x, QVector &y, QVector &t
                  const uint64_t iterations, const float mu)
 {
     x.clear();
-    for (uint64_t i = 0; i < iterations; i += 1) {
+    for (uint64_t it = 0; it < iterations; ++it) {
         Phi.mvm_parallel(x, t1);
         y.scaleAndAdd_parallel(t1, -1.0f, t2);
         PhiT.mvm_parallel(t2, t3);
@@ -50,9 +52,9 @@ inline void Q_IHT(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, Clo
 {
     x.clear();
     for (uint64_t i = 0; i < iterations; i += 1) {
-        Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);      // t1 = Phi * x;  t2 = y - t1
-        PhiT.mvm_scaleAndAdd(t2, x, mu, t3);           // t3 = Phi' * t2;  x = x + mu * t3
-        x.threshold_parallel(K);                       // hard thresholding
+        Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);      /* residual:  t1 = Phi x,  t2 = y - t1   (one launch) */
+        PhiT.mvm_scaleAndAdd(t2, x, mu, t3);           /* gradient step:  t3 = Phi' t2,  x += mu t3   (one launch) */
+        x.threshold_parallel(K);                       /* keep the K largest magnitudes */
     }
 }
 

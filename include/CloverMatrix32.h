@@ -32,14 +32,14 @@ public:
     uint64_t getBitsLength() const { return 32; }
     uint64_t getBytes() const { return rows * cols * sizeof(float); }
 
-    float *getData() const { return reinterpret_cast<float *>(mem.host_rw()); }
+    float *getData() const { return reinterpret_cast<float *>(mem.host_ptr()); }      /* stays valid and current (clover_device.h) */
     float get(uint64_t i, uint64_t j) const { return reinterpret_cast<const float *>(mem.host_ro())[i * cols + j]; }
     void set(uint64_t i, uint64_t j, float v) { reinterpret_cast<float *>(mem.host_rw())[i * cols + j] = v; }
     void clear() { memset(mem.host_rw(), 0, rows * cols * sizeof(float)); }
 
     void setRandomInteger(float max_value, uint64_t seed = 0x9E3779B97F4A7C15ull)
     {
-        CloverVector32 view(rows * cols, getData());      /* non-owning view over the same buffer */
+        CloverVector32 view(rows * cols, reinterpret_cast<float *>(mem.host_rw()));      /* non-owning view over the same buffer */
         view.setRandomInteger(max_value, seed);
     }
 

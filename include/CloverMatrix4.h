@@ -11,8 +11,8 @@
  *   gemm (new)                       -> clm4_gemm     (the reference has no GEMM; semantics in DESIGN.md)
  *
  * As in the reference, values/scales are not exposed (they are `protected` there, :73-75); the matrix
- * lives in HBM once quantized.  transpose and the 4-bit x fp32 mixed mvm are here; the 4-bit x
- * 8-bit mvm is not (it needs the 8-bit container format).
+ * lives in HBM once quantized.  transpose and both mixed-precision mvm variants (4-bit x 8-bit with
+ * CloverVector8 operands, 4-bit x fp32) are here as well.
  */
 #ifndef CLOVER_MATRIX4_H
 #define CLOVER_MATRIX4_H
@@ -47,8 +47,8 @@ public:
     uint64_t getBytes() const { return value_bytes + (rows >> 6) * (cols >> 6) * sizeof(float); }
 
     /* host views of the packed values and of the tile scales (the reference keeps them protected; exposed for interop) */
-    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
-    float *getScales() const { return reinterpret_cast<float *>(mem.host_rw() + value_bytes); }
+    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_ptr()); }
+    float *getScales() const { return reinterpret_cast<float *>(mem.host_ptr() + value_bytes); }
 
     float get(uint64_t i, uint64_t j) const
     {
@@ -61,6 +61,9 @@ public:
     }
 
     void setRandomKeys(const uint64_t key1[4], const uint64_t key2[4]) { random.set(key1, key2); }
+#ifdef CLOVER_HIP_M256_KEYS
+    void setRandomKeys(__m256i key1, __m256i key2) { clover_hip::set_keys_m256(random, key1, key2); }   /* CloverRandom.h:90-94 */
+#endif
     void seedRandomKeys(uint64_t key1, uint64_t key2) { random.seed(key1, key2); }
 
     void quantize(const CloverMatrix32 &m)
@@ -101,6 +104,7 @@ public:
         const float *sx = productVector.dev_scales_ro();
         clover_hip::check(clm4_mvm(dev_values(), dev_scales(), rows, cols, x, sx, resultVector.dev_values_wo(),
                                    resultVector.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr), "CloverMatrix4::mvm");
+        resultVector.commit();
     }
     void mvm_parallel(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
     void check_fused(const CloverVector4 &x, const CloverVector4 &u, const CloverVector4 &t) const
@@ -122,6 +126,8 @@ public:
         clover_hip::check(clm4_mvm_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(),
                                                  u.dev_values_ro(), u.dev_scales_ro(), a, t.dev_values_wo(), t.dev_scales_wo(),
                                                  r.dev_values_wo(), r.dev_scales_wo(), nullptr, nullptr), "CloverMatrix4::mvm_scaleAndAdd");
+        t.commit();
+        r.commit();
 #else
         mvm(x, t);
         const_cast<CloverVector4 &>(u).scaleAndAdd(t, a, r);
@@ -137,6 +143,8 @@ public:
         clover_hip::check(clm4_mvm_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(), qu, su, a,
                                                  t.dev_values_wo(), t.dev_scales_wo(), qu, su, nullptr, nullptr),
                           "CloverMatrix4::mvm_scaleAndAdd");
+        t.commit();
+        u.commit();
 #else
         mvm(x, t);
         u.scaleAndAdd(t, a);
@@ -153,6 +161,7 @@ public:
         clover_hip::check(clm4_mvm_v8(dev_values(), dev_scales(), rows, cols, productVector.dev_values_ro(), productVector.dev_scales_ro(),
                                       resultVector.dev_values_wo(), resultVector.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
                           "CloverMatrix4::mvm");
+        resultVector.commit();
     }
     void mvm_parallel(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
     void mvm_scalar(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
@@ -165,6 +174,8 @@ public:
         clover_hip::check(clm4_mvm_v8_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(),
                                                     u.dev_values_ro(), u.dev_scales_ro(), a, t.dev_values_wo(), t.dev_scales_wo(),
                                                     r.dev_values_wo(), r.dev_scales_wo(), nullptr, nullptr), "CloverMatrix4::mvm_scaleAndAdd");
+        t.commit();
+        r.commit();
 #else
         mvm(x, t);
         const_cast<CloverVector8 &>(u).scaleAndAdd(t, a, r);
@@ -180,6 +191,8 @@ public:
         clover_hip::check(clm4_mvm_v8_scale_and_add(dev_values(), dev_scales(), rows, cols, x.dev_values_ro(), x.dev_scales_ro(), qu, su, a,
                                                     t.dev_values_wo(), t.dev_scales_wo(), qu, su, nullptr, nullptr),
                           "CloverMatrix4::mvm_scaleAndAdd");
+        t.commit();
+        u.commit();
 #else
         mvm(x, t);
         u.scaleAndAdd(t, a);
@@ -195,6 +208,7 @@ public:
         }
         clover_hip::check(clm4_mvm_f32(dev_values(), dev_scales(), rows, cols, productVector.device_ro(), resultVector.device_wo(), nullptr),
                           "CloverMatrix4::mvm");
+        resultVector.commit();
     }
     void mvm_parallel(const CloverVector32 &productVector, CloverVector32 &resultVector) { mvm(productVector, resultVector); }
     /* the reference's scalar variant accumulates in double (:423-432); the SIMD order is used here */

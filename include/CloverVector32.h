@@ -51,7 +51,7 @@ public:
     float get(uint64_t i) const { return reinterpret_cast<const float *>(mem.host_ro())[i]; }
     float getAbs(uint64_t i) const { float v = get(i); return v < 0 ? -v : v; }
     void set(uint64_t i, float v) { reinterpret_cast<float *>(mem.host_rw())[i] = v; }
-    float *getData() const { return reinterpret_cast<float *>(mem.host_rw()); }
+    float *getData() const { return reinterpret_cast<float *>(mem.host_ptr()); }      /* stays valid and current, see clover_device.h */
 
     void clear() { memset(mem.host_rw(), 0, length_pad * sizeof(float)); }
 
@@ -59,7 +59,7 @@ public:
      * [-max, max].  Uses a splitmix64 stream, not the reference's XORShift keys. */
     void setRandomInteger(float max_value, uint64_t seed = 0x2545F4914F6CDD1Dull)
     {
-        float *v = getData();
+        float *v = reinterpret_cast<float *>(mem.host_rw());
         const int64_t range = (int64_t)max_value;
         uint64_t z = seed;
         for (uint64_t i = 0; i < length; i++) {
@@ -83,6 +83,7 @@ public:
     /* device access for the 4-bit containers */
     const float *device_ro() const { return reinterpret_cast<const float *>(mem.dev_ro()); }
     float *device_wo() { return reinterpret_cast<float *>(mem.dev_wo()); }
+    void commit() { mem.commit(); }      /* after a launch that wrote through device_wo(): a view is written through */
 };
 
 #endif

@@ -43,7 +43,7 @@ protected:
         value_bytes = length_pad / 2;
         mem.allocate(value_bytes + blocks_pad * sizeof(float));
         split_view = false;
-        int8_t *v = reinterpret_cast<int8_t *>(mem.host_rw());
+        int8_t *v = values_rw();
         float *s = reinterpret_cast<float *>(v + value_bytes);
         for (uint64_t i = length >> 1; i < value_bytes; i++) v[i] = 0;          /* zeroed value padding  */
         for (uint64_t i = length / 64; i < blocks; i++) s[i] = 1;               /* padding scales = 1.0  */
@@ -73,8 +73,8 @@ public:
     CloverVector4(const CloverVector4 &other) : length(other.length), length_pad(other.length_pad)
     {
         allocate();
-        memcpy(getData(), other.values_ro(), value_bytes);
-        memcpy(getScales(), other.scales_ro(), (length_pad / 64) * sizeof(float));
+        memcpy(values_rw(), other.values_ro(), value_bytes);
+        memcpy(scales_rw(), other.scales_ro(), (length_pad / 64) * sizeof(float));
     }
 
     /* ---- support methods (CloverVector4.h:150-326) ------------------------------------------- */
@@ -83,17 +83,19 @@ public:
     uint64_t getBitsLength() const { return 4; }
     uint64_t getBytes() const { return length_pad / 2 + (length_pad / 64) * sizeof(float); }
 
-    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
+    /* Raw pointers as in the reference (:229-237): valid for the life of the object and always current -- reads through a
+     * kept pointer see the results of later device operations, writes through it reach the next one (clover_device.h). */
+    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_ptr()); }
     float *getScales() const
     {
-        if (split_view) return reinterpret_cast<float *>(view_scales.host_rw());
-        return reinterpret_cast<float *>(mem.host_rw() + value_bytes);
+        if (split_view) return reinterpret_cast<float *>(view_scales.host_ptr());
+        return reinterpret_cast<float *>(mem.host_ptr() + value_bytes);
     }
 
     int8_t getBits(uint64_t pos) const { return nibble(values_ro()[pos >> 1], pos); }
     void setBits(uint64_t pos, int8_t bits)
     {
-        int8_t *v = getData();
+        int8_t *v = values_rw();
         const int8_t qu = (int8_t)((bits & 0x0F) << ((1 - pos % 2) * 4));
         v[pos >> 1] = (int8_t)((v[pos >> 1] & (pos % 2 == 0 ? 0x0F : 0xF0)) | qu);
     }
@@ -111,8 +113,8 @@ public:
     }
     void clear()
     {
-        memset(getData(), 0, value_bytes);
-        float *s = getScales();
+        memset(values_rw(), 0, value_bytes);
+        float *s = scales_rw();
         for (uint64_t b = 0; b < length_pad / 64; b++) s[b] = 1.0f;
     }
     std::string toString() const
@@ -128,6 +130,9 @@ public:
 
     /* CloverRandom::setRandomKeys (CloverRandom.h:90-94): the four 64-bit lanes of each key register */
     void setRandomKeys(const uint64_t key1[4], const uint64_t key2[4]) { random.set(key1, key2); }
+#ifdef CLOVER_HIP_M256_KEYS
+    void setRandomKeys(__m256i key1, __m256i key2) { clover_hip::set_keys_m256(random, key1, key2); }   /* the reference's signature */
+#endif
     /* avx_xorshift128plus_init(key1, key2) + setRandomKeys in one call */
     void seedRandomKeys(uint64_t key1, uint64_t key2) { random.seed(key1, key2); }
 
@@ -141,6 +146,7 @@ public:
         const float *x = other.device_ro();
         clover_hip::check(clv4_quantize(x, length_pad, dev_values_wo(), dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
                           "CloverVector4::quantize");
+        commit();
     }
     void quantize_parallel(const CloverVector32 &other) { quantize(other); }
     /* the reference's scalar variant divides by zero on all-zero blocks (:478-479); the SIMD contract is used */
@@ -149,6 +155,7 @@ public:
     void restore(CloverVector32 &other) const
     {
         clover_hip::check(clv4_restore(dev_values_ro(), dev_scales_ro(), length_pad, other.device_wo(), nullptr), "CloverVector4::restore");
+        other.commit();
     }
     void restore_scalar(CloverVector32 &other) const { restore(other); }
 
@@ -181,6 +188,7 @@ public:
         float *su = dev_scales_rw();
         clover_hip::check(clv4_scale_and_add(u, su, v, sv, a, length_pad, u, su, clover_hip::rng_or_null(random), nullptr),
                           "CloverVector4::scaleAndAdd");
+        commit();
     }
     /* result = quantize(this + a * other) (CloverVector4.h:1207-1220) */
     void scaleAndAdd(const CloverVector4 &other, float a, CloverVector4 &result)
@@ -190,6 +198,7 @@ public:
         clover_hip::check(clv4_scale_and_add(dev_values_ro(), dev_scales_ro(), other.dev_values_ro(), other.dev_scales_ro(), a, length_pad,
                                              result.dev_values_wo(), result.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
                           "CloverVector4::scaleAndAdd");
+        result.commit();
     }
     void scaleAndAdd_parallel(const CloverVector4 &other, float a) { scaleAndAdd(other, a); }
     void scaleAndAdd_parallel(const CloverVector4 &other, float a, CloverVector4 &result) { scaleAndAdd(other, a, result); }
@@ -200,6 +209,7 @@ public:
     void threshold(uint64_t k)
     {
         clover_hip::check(clv4_threshold(dev_values_rw(), dev_scales_ro(), length, length_pad, k, nullptr, nullptr), "CloverVector4::threshold");
+        commit();
     }
     void threshold_parallel(uint64_t k) { threshold(k); }
 
@@ -223,6 +233,12 @@ public:
         if (split_view) return reinterpret_cast<float *>(view_scales.dev_rw());
         return reinterpret_cast<float *>(mem.dev_rw() + value_bytes);
     }
+    /* after a launch that wrote through dev_*_wo()/dev_*_rw(): a view copies the result into the caller's memory now */
+    void commit()
+    {
+        mem.commit();
+        if (split_view) view_scales.commit();
+    }
 
 private:
     void same_size(const CloverVector4 &other) const
@@ -231,6 +247,12 @@ private:
             std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
             exit(1);
         }
+    }
+    int8_t *values_rw() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
+    float *scales_rw() const
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.host_rw());
+        return reinterpret_cast<float *>(mem.host_rw() + value_bytes);
     }
     const int8_t *values_ro() const { return reinterpret_cast<const int8_t *>(mem.host_ro()); }
     const float *scales_ro() const
@@ -244,14 +266,10 @@ private:
             std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
             exit(1);
         }
-        void *out = nullptr;
-        clover_hip::check(clv_malloc(&out, sizeof(float)), "device allocation");
+        clover_hip::ResultSlot &slot = clover_hip::result_slot();          /* per-thread device word + pinned host word */
         clover_hip::check(clv4_dot(dev_values_ro(), dev_scales_ro(), other.dev_values_ro(), other.dev_scales_ro(), length_pad, mode,
-                                   static_cast<float *>(out), nullptr, nullptr), "CloverVector4::dot");
-        float r = 0;
-        clover_hip::check(clv_memcpy_d2h(&r, out, sizeof(float), nullptr), "device->host copy");
-        clv_free(out);
-        return r;
+                                   slot.device(), nullptr, nullptr), "CloverVector4::dot");
+        return slot.fetch();
     }
 };
 

@@ -38,7 +38,7 @@ protected:
         value_bytes = length_pad;
         mem.allocate(value_bytes + blocks_pad * sizeof(float));
         split_view = false;
-        int8_t *v = reinterpret_cast<int8_t *>(mem.host_rw());
+        int8_t *v = values_rw();
         float *s = reinterpret_cast<float *>(v + value_bytes);
         for (uint64_t i = length; i < length_pad; i++) v[i] = 0;                /* zeroed value padding  */
         for (uint64_t i = length / 64; i < blocks; i++) s[i] = 1;               /* padding scales = 1.0  */
@@ -66,8 +66,8 @@ public:
     CloverVector8(const CloverVector8 &other) : length(other.length), length_pad(other.length_pad)
     {
         allocate();
-        memcpy(getData(), other.values_ro(), value_bytes);
-        memcpy(getScales(), other.scales_ro(), (length_pad / 64) * sizeof(float));
+        memcpy(values_rw(), other.values_ro(), value_bytes);
+        memcpy(scales_rw(), other.scales_ro(), (length_pad / 64) * sizeof(float));
     }
 
     uint64_t size() const { return length; }
@@ -75,21 +75,22 @@ public:
     uint64_t getBitsLength() const { return 8; }
     uint64_t getBytes() const { return length_pad + (length_pad / 64) * sizeof(float); }
 
-    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
+    /* raw pointers as in the reference: valid for the life of the object and always current (clover_device.h) */
+    int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_ptr()); }
     float *getScales() const
     {
-        if (split_view) return reinterpret_cast<float *>(view_scales.host_rw());
-        return reinterpret_cast<float *>(mem.host_rw() + value_bytes);
+        if (split_view) return reinterpret_cast<float *>(view_scales.host_ptr());
+        return reinterpret_cast<float *>(mem.host_ptr() + value_bytes);
     }
 
     /* CloverVector8.h:137-140 */
     float get(uint64_t i) const { return values_ro()[i] * scales_ro()[i >> 6] / 127.0f; }
     int8_t getBits(uint64_t i) const { return values_ro()[i]; }
-    void setBits(uint64_t i, int8_t bits) { getData()[i] = bits; }
+    void setBits(uint64_t i, int8_t bits) { values_rw()[i] = bits; }
     void clear()
     {
-        memset(getData(), 0, value_bytes);
-        float *s = getScales();
+        memset(values_rw(), 0, value_bytes);
+        float *s = scales_rw();
         for (uint64_t b = 0; b < length_pad / 64; b++) s[b] = 1.0f;
     }
     std::string toString() const
@@ -102,6 +103,9 @@ public:
     }
 
     void setRandomKeys(const uint64_t key1[4], const uint64_t key2[4]) { random.set(key1, key2); }
+#ifdef CLOVER_HIP_M256_KEYS
+    void setRandomKeys(__m256i key1, __m256i key2) { clover_hip::set_keys_m256(random, key1, key2); }   /* CloverRandom.h:90-94 */
+#endif
     void seedRandomKeys(uint64_t key1, uint64_t key2) { random.seed(key1, key2); }
 
     void quantize(const CloverVector32 &other)
@@ -112,6 +116,7 @@ public:
         }
         clover_hip::check(clv8_quantize(other.device_ro(), length_pad, dev_values_wo(), dev_scales_wo(), clover_hip::rng_or_null(random),
                                         nullptr), "CloverVector8::quantize");
+        commit();
     }
     void quantize_parallel(const CloverVector32 &other) { quantize(other); }
     void quantize_scalar(const CloverVector32 &other) { quantize(other); }
@@ -119,6 +124,7 @@ public:
     void restore(CloverVector32 &other) const
     {
         clover_hip::check(clv8_restore(dev_values_ro(), dev_scales_ro(), length_pad, other.device_wo(), nullptr), "CloverVector8::restore");
+        other.commit();
     }
     void restore_scalar(CloverVector32 &other) const { restore(other); }
 
@@ -132,6 +138,7 @@ public:
         float *su = dev_scales_rw();
         clover_hip::check(clv8_scale_and_add(u, su, v, sv, a, length_pad, u, su, clover_hip::rng_or_null(random), nullptr),
                           "CloverVector8::scaleAndAdd");
+        commit();
     }
     /* result = quantize(this + a * other) (CloverVector8.h:1074-1087) */
     void scaleAndAdd(const CloverVector8 &other, float a, CloverVector8 &result)
@@ -141,6 +148,7 @@ public:
         clover_hip::check(clv8_scale_and_add(dev_values_ro(), dev_scales_ro(), other.dev_values_ro(), other.dev_scales_ro(), a, length_pad,
                                              result.dev_values_wo(), result.dev_scales_wo(), clover_hip::rng_or_null(random), nullptr),
                           "CloverVector8::scaleAndAdd");
+        result.commit();
     }
     void scaleAndAdd_parallel(const CloverVector8 &other, float a) { scaleAndAdd(other, a); }
     void scaleAndAdd_parallel(const CloverVector8 &other, float a, CloverVector8 &result) { scaleAndAdd(other, a, result); }
@@ -151,6 +159,7 @@ public:
     void threshold(uint64_t k)
     {
         clover_hip::check(clv8_threshold(dev_values_rw(), dev_scales_ro(), length, length_pad, k, nullptr, nullptr), "CloverVector8::threshold");
+        commit();
     }
     void threshold_parallel(uint64_t k) { threshold(k); }
 
@@ -174,6 +183,12 @@ public:
         if (split_view) return reinterpret_cast<float *>(view_scales.dev_rw());
         return reinterpret_cast<float *>(mem.dev_rw() + value_bytes);
     }
+    /* after a launch that wrote through dev_*_wo()/dev_*_rw(): a view copies the result into the caller's memory now */
+    void commit()
+    {
+        mem.commit();
+        if (split_view) view_scales.commit();
+    }
 
 private:
     void same_size(const CloverVector8 &other) const
@@ -182,6 +197,12 @@ private:
             std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
             exit(1);
         }
+    }
+    int8_t *values_rw() const { return reinterpret_cast<int8_t *>(mem.host_rw()); }
+    float *scales_rw() const
+    {
+        if (split_view) return reinterpret_cast<float *>(view_scales.host_rw());
+        return reinterpret_cast<float *>(mem.host_rw() + value_bytes);
     }
     const int8_t *values_ro() const { return reinterpret_cast<const int8_t *>(mem.host_ro()); }
     const float *scales_ro() const

@@ -309,7 +309,8 @@ def test_bad_sizes_are_rejected(hip):
     with pytest.raises(CloverHipError):
         hip.v4_quantize(np.zeros(100, np.float32))
     buf = hip.alloc(1024)
-    assert hip.lib.clm4_mvm(buf.ptr, buf.ptr, 192, 128, buf.ptr, buf.ptr, buf.ptr, buf.ptr, None, None) == -1
+    assert hip.lib.clm4_mvm(buf.ptr, buf.ptr, 160, 128, buf.ptr, buf.ptr, buf.ptr, buf.ptr, None, None) == -1      # not a whole number of 64-row blocks
+    assert hip.lib.clm4_mvm(buf.ptr, buf.ptr, 128, 192, buf.ptr, buf.ptr, buf.ptr, buf.ptr, None, None) == -1      # cols: multiples of 128 only
 
 
 def test_degenerate_sizes(hip):

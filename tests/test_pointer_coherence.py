@@ -1,0 +1,57 @@
+"""The reference's raw-pointer contract over two copies (include/clover_device.h): getData()/getScales() pointers stay valid and
+current across device operations, views write through.  CPU: the state machine against a fake device; GPU: the containers."""
+import signal
+import subprocess
+
+import pytest
+
+from clover_amd.build import build_hip_library, repo_root
+
+ROOT = repo_root()
+CPP = ROOT / "tests" / "cpp"
+
+
+def _link_flags():
+    lib = build_hip_library()
+    return [f"-L{lib.parent}", "-lclover_hip", f"-Wl,-rpath,{lib.parent}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def _build_coherence(tmp_path, extra=()):
+    exe = tmp_path / "pointer_coherence"
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}", *extra,
+                    str(CPP / "pointer_coherence.cpp"), "-o", str(exe), *_link_flags()], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("opt", ["-O0", "-O2", "-O3"])
+def test_mirror_state_machine_with_fake_device(tmp_path, opt):
+    obj, exe = tmp_path / "fake_clv.o", tmp_path / "mirror_states"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-c", f"-I{ROOT / 'include'}", str(CPP / "fake_clv.c"), "-o", str(obj)], check=True)
+    subprocess.run(["g++", "-std=c++11", opt, "-Wall", "-Wextra", f"-I{ROOT / 'include'}", str(CPP / "mirror_states.cpp"), str(obj), "-o", str(exe)], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "mirror ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+def test_coherence_client_builds_and_a_wild_access_still_crashes(tmp_path):
+    exe = _build_coherence(tmp_path, extra=("-mavx2",))          # -mavx2: the setRandomKeys(__m256i, __m256i) overloads compile
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and ("no_device" in p.stdout or "coherence ok" in p.stdout), (p.returncode, p.stdout, p.stderr)
+    p = subprocess.run([str(exe), "crash"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == -signal.SIGSEGV and "not reached" not in p.stdout, (p.returncode, p.stdout)
+
+
+def test_m256_key_overload_exists_only_with_avx(tmp_path):
+    src = tmp_path / "keys.cpp"
+    src.write_text('#include "CloverMatrix4.h"\n#include <immintrin.h>\nvoid f(CloverVector4 &v, CloverVector8 &w, CloverMatrix4 &m, __m256i a, __m256i b)'
+                   " { v.setRandomKeys(a, b); w.setRandomKeys(a, b); m.setRandomKeys(a, b); }\n")
+    subprocess.run(["g++", "-std=c++11", "-mavx2", "-fsyntax-only", f"-I{ROOT / 'include'}", str(src)], check=True)
+
+
+@pytest.mark.gpu
+def test_kept_pointers_and_views_behave_like_the_reference(tmp_path):
+    exe = _build_coherence(tmp_path)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "coherence ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
+    us = float(p.stdout.split("c1_header_dot_us=")[1].split()[0])
+    print(f"C1 (n=128) dot through the C++ headers: {us:.1f} us per call")
+    assert us < 200.0
