@@ -43,7 +43,8 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // number of compute units of the current device (cached per device)
 int clv_cu_count();
 // grow-only per-device scratch buffer used when the caller passes workspace == NULL
-int clv_internal_workspace(void **ptr, uint64_t bytes);
+int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream);      // grow-only scratch per (device, stream)
+void clv_internal_workspace_forget(hipStream_t stream);
 
 // ---- device helpers ---------------------------------------------------------------------------
 #define CLV_RCP49 (1.0f / 49.0f)   // 0x3CA72F05, the reference's clover_mm256_rcp_49_ps (CloverBase.h:88)

@@ -28,6 +28,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
@@ -238,20 +239,234 @@ __global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6(const uint8_t *__restric
             }
 }
 
-// workspace: the FP6 images of A and B, (M + N) * K * 3/4 bytes
+// ---- pass 2, hand-scheduled ---------------------------------------------------------------------------------------
+// Same tile, same LDS image, same DMA and the same arithmetic as k_m4_gemm_fp6 above; what differs is WHO orders the instructions.
+// hipcc issues a K-block's MFMAs first and its folds after, hoists fragment reads across K-blocks until it spills, and pairs the
+// fold into v_pk_fma_f32, which serialises with the matrix pipe (profiles/r02_mfma_fold_probe*.txt).  Here the whole main loop and
+// the store of C are ONE asm statement generated by tools/gen_gemm6_loop.py (schedule and register map are documented there):
+// the fold of a result runs two MFMAs behind it, half scalar (beside the MFMA just issued) and half packed; fragments are
+// single-buffered with re-loads placed right behind their last reader; one barrier per stage, placed so that the next stage's
+// fragments are requested before the current stage's last two MFMAs.
+#include "gemm6_loop.inc"
+
+// stage0 / nstages: the range of stages (pairs of K-blocks) to contract -- all of them for the GEMM, a sub-range for clm4_gemm_i32
+template <int V>
+__global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6_asm(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
+                                                                const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint32_t stage0,
+                                                                uint64_t N, uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n,
+                                                                uint32_t nstages)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t nwg = tiles_m * tiles_n;
+    uint32_t id = blockIdx.x;
+    {
+        const uint32_t q = nwg / 8, r = nwg % 8, xcd = id % 8, s = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+    }
+    const uint32_t GROUP = 8;
+    const uint32_t per_group = GROUP * tiles_n;
+    const uint32_t group = id / per_group;
+    const uint32_t first_m = group * GROUP;
+    const uint32_t gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const uint32_t tm = first_m + (id % per_group) % gsize;
+    const uint32_t tn = (id % per_group) / gsize;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    constexpr int SUB = G6_TILE * 48;
+    const uint64_t m0 = (uint64_t)tm * G6_TILE, n0 = (uint64_t)tn * G6_TILE;
+    const uint64_t kbn = K / 64;
+    const uint64_t image_stages = kbn / 2;                       // stages per tile in the FP6 images
+    const uint32_t npairs = nstages;
+
+    // wave-uniform addresses (SGPRs inside the loop)
+    const uint64_t ga = (uint64_t)(A6 + ((uint64_t)tm * image_stages + stage0) * (2 * SUB) + 1024 * wave);
+    const uint64_t gb = (uint64_t)(B6 + ((uint64_t)tn * image_stages + stage0) * (2 * SUB) + 1024 * wave);
+    const uint64_t sa = (uint64_t)(sA + ((m0 >> 6) + wr) * kbn + 2 * (uint64_t)stage0);
+    const uint64_t sb = (uint64_t)(sB + ((n0 >> 6) + wc) * kbn + 2 * (uint64_t)stage0);
+    const uint64_t cb = (uint64_t)(C + (m0 + wr * 64) * N + n0 + wc * 64);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;                       // LDS byte address of the stage buffers
+    const uint32_t dma = lds0 + 1024 * wave;
+    const uint32_t cstride = (uint32_t)(N * sizeof(float));
+    // per-lane: fragment addresses in buffer 0 (row = lane & 31 of a 32-row tile, half = lane >> 5 of the K-block; see k_m4_gemm_fp6)
+    const int frow = lane & 31, h = lane >> 5;
+    const int tail = 32 + 8 * (h ^ ((lane >> 4) & 1));
+    uint32_t a16 = lds0 + (wr * 64 + frow) * 48 + 16 * h;
+    uint32_t a8 = lds0 + (wr * 64 + frow) * 48 + tail;
+    uint32_t b16 = lds0 + 2 * SUB + (wc * 64 + frow) * 48 + 16 * h;
+    uint32_t b8 = lds0 + 2 * SUB + (wc * 64 + frow) * 48 + tail;
+    const uint32_t voff = 16 * lane;
+    const uint32_t coff = (uint32_t)((4 * (uint64_t)(lane >> 5) * N + (lane & 31)) * sizeof(float));
+
+#define G6_RUN(STR)                                                                                                                     \
+    asm volatile(STR : [a16] "+v"(a16), [a8] "+v"(a8), [b16] "+v"(b16), [b8] "+v"(b8)                                                   \
+                 : [voff] "v"(voff), [coff] "v"(coff), [ga] "s"(ga), [gb] "s"(gb), [sa] "s"(sa), [sb] "s"(sb), [cb] "s"(cb), [np] "s"(npairs), \
+                   [dma] "s"(dma), [cstride] "s"(cstride)                                                                                  \
+                 : G6_LOOP_CLOBBERS)
+    if constexpr (V == 0) G6_RUN(G6_LOOP_ASM);
+    else if constexpr (V == 100) G6_RUN(G6_LOOP_ASM_I32);        // no scales: the MFMAs accumulate over the K-blocks, C leaves as int32
+#ifdef G6_LOOP_EXPERIMENTS      // timing-only variants with parts of the loop left out (tools/gen_gemm6_loop.py ... experiments)
+    else if constexpr (V == 1) G6_RUN(G6_LOOP_ASM_NODMA);
+    else if constexpr (V == 2) G6_RUN(G6_LOOP_ASM_NOLDS);
+    else if constexpr (V == 3) G6_RUN(G6_LOOP_ASM_NODMA_NOLDS);
+    else if constexpr (V == 4) G6_RUN(G6_LOOP_ASM_NOBARRIER);
+    else if constexpr (V == 5) G6_RUN(G6_LOOP_ASM_NOFOLD);
+    else if constexpr (V == 6) G6_RUN(G6_LOOP_ASM_ARITH);
+    else if constexpr (V == 7) G6_RUN(G6_LOOP_ASM_DMAFIXED);
+    else if constexpr (V == 8) G6_RUN(G6_LOOP_ASM_DMABONLY);
+#endif
+#undef G6_RUN
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+// An operand's FP6 image (rows * K * 3/4 bytes, staging order).  clm4_gemm re-codes both operands per call into the stream's
+// scratch; clm4_gemm_prepare does it once into a buffer of its own for an operand that is multiplied many times.
+struct clm4_gemm_operand {
+    uint8_t *image;
+    uint64_t rows, K;
+    int device;
+};
+
+static int recode(const int8_t *A, uint8_t *A6, uint64_t M, const int8_t *B, uint8_t *B6, uint64_t N, uint64_t K, hipStream_t st)
+{
+    // one launch for whichever operands still need it (a NULL source = already prepared)
+    const uint64_t ra = A ? M : 0, rb = B ? N : 0;
+    if (!ra && !rb) return CLV_OK;
+    hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)((K / 64 + F6_KB - 1) / F6_KB), (unsigned)((ra + rb) / F6_ROWS)), dim3(256), 0, st, (const u32x4 *)A, A6,
+                       (uint32_t)(ra / F6_ROWS), (const u32x4 *)B, B6, K / 64);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clm4_gemm_prepare(const int8_t *q, uint64_t rows, uint64_t K, clm4_gemm_operand **op, void *stream)
+{
+    CLV_REQUIRE(q && op, "clm4_gemm_prepare: null pointer");
+    CLV_REQUIRE(rows && K && rows % 128 == 0 && K % 128 == 0, "clm4_gemm_prepare: rows=%llu K=%llu must be non-zero multiples of 128",
+                (unsigned long long)rows, (unsigned long long)K);
+    clm4_gemm_operand *o = new clm4_gemm_operand{nullptr, rows, K, 0};
+    if (hipGetDevice(&o->device) != hipSuccess || hipMalloc((void **)&o->image, rows * K / 4 * 3) != hipSuccess) {
+        clv_set_error("clm4_gemm_prepare: %s", hipGetErrorString(hipGetLastError()));
+        delete o;
+        return CLV_ERR_HIP;
+    }
+    int rc = recode(q, o->image, rows, nullptr, nullptr, 0, K, as_stream(stream));
+    if (rc) { (void)hipFree(o->image); delete o; return rc; }
+    *op = o;
+    return CLV_OK;
+}
+
+extern "C" int clm4_gemm_release(clm4_gemm_operand *op)
+{
+    if (!op) return CLV_OK;
+    if (op->image) CLV_HIP(hipFree(op->image));
+    delete op;
+    return CLV_OK;
+}
+
+// A / B: the nibbles (needed when the matching operand is NULL); opA / opB: prepared images or NULL
+static int gemm_fp6_run(const clm4_gemm_operand *opA, const int8_t *A, const float *sA, uint64_t M, uint64_t K, const clm4_gemm_operand *opB,
+                        const int8_t *B, const float *sB, uint64_t N, void *C, bool i32, uint64_t kb_begin, uint64_t kb_count, hipStream_t st)
+{
+    const uint64_t a_bytes = opA ? 0 : M * K / 4 * 3, b_bytes = opB ? 0 : N * K / 4 * 3;
+    uint8_t *A6 = opA ? opA->image : nullptr, *B6 = opB ? opB->image : nullptr;
+    if (a_bytes + b_bytes) {
+        void *ws = nullptr;
+        int rc = clv_internal_workspace(&ws, a_bytes + b_bytes, st);
+        if (rc) return rc;
+        if (!opA) A6 = reinterpret_cast<uint8_t *>(ws);
+        if (!opB) B6 = reinterpret_cast<uint8_t *>(ws) + a_bytes;
+        rc = recode(opA ? nullptr : A, A6, M, opB ? nullptr : B, B6, N, K, st);
+        if (rc) return rc;
+    }
+    const uint32_t tiles_m = (uint32_t)(M / G6_TILE), tiles_n = (uint32_t)(N / G6_TILE);
+    const dim3 grid(tiles_m * tiles_n), block(256);
+    if (i32) {
+        // K-blocks [kb_begin, kb_begin + kb_count), both even: whole stages of images that hold K / 128 stages per tile
+        hipLaunchKernelGGL(k_m4_gemm_fp6_asm<100>, grid, block, G6_LDS_BYTES, st, A6, (const float *)nullptr, B6, (const float *)nullptr, (uint32_t)(kb_begin / 2),
+                           N, K, (float *)C, tiles_m, tiles_n, (uint32_t)(kb_count / 2));
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
+    // CLV_GEMM_LOOP=hipcc: the compiler-scheduled main loop (A/B runs); default: the hand-scheduled one
+    static const bool hipcc_loop = [] { const char *e = getenv("CLV_GEMM_LOOP"); return e && !strcmp(e, "hipcc"); }();
+    if (hipcc_loop) {
+        hipLaunchKernelGGL(k_m4_gemm_fp6, grid, block, G6_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, (float *)C, tiles_m, tiles_n);
+    } else {
+#define G6_LAUNCH(V) hipLaunchKernelGGL(k_m4_gemm_fp6_asm<V>, grid, block, G6_LDS_BYTES, st, A6, sA, B6, sB, 0u, N, K, (float *)C, tiles_m, tiles_n, (uint32_t)(K / 128))
+#ifdef G6_LOOP_EXPERIMENTS
+        static const int variant = [] { const char *e = getenv("CLV_GEMM_LOOP"); return e && e[0] == 'v' ? atoi(e + 1) : 0; }();
+        switch (variant) {
+        case 1: G6_LAUNCH(1); break;
+        case 2: G6_LAUNCH(2); break;
+        case 3: G6_LAUNCH(3); break;
+        case 4: G6_LAUNCH(4); break;
+        case 5: G6_LAUNCH(5); break;
+        case 6: G6_LAUNCH(6); break;
+        case 7: G6_LAUNCH(7); break;
+        case 8: G6_LAUNCH(8); break;
+        default: G6_LAUNCH(0); break;
+        }
+#else
+        G6_LAUNCH(0);
+#endif
+#undef G6_LAUNCH
+    }
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
 int clm4_gemm_fp6(const int8_t *A, const float *sA, uint64_t M, uint64_t K, const int8_t *B, const float *sB, uint64_t N, float *C,
                   hipStream_t st)
 {
-    const uint64_t a_bytes = M * K / 4 * 3, b_bytes = N * K / 4 * 3;
-    void *ws = nullptr;
-    int rc = clv_internal_workspace(&ws, a_bytes + b_bytes);
-    if (rc) return rc;
-    uint8_t *A6 = reinterpret_cast<uint8_t *>(ws), *B6 = A6 + a_bytes;
-    hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)((K / 64 + F6_KB - 1) / F6_KB), (unsigned)((M + N) / F6_ROWS)), dim3(256), 0, st, (const u32x4 *)A, A6,
-                       (uint32_t)(M / F6_ROWS), (const u32x4 *)B, B6, K / 64);
-    CLV_LAUNCH_CHECK();
-    const uint32_t tiles_m = (uint32_t)(M / G6_TILE), tiles_n = (uint32_t)(N / G6_TILE);
-    hipLaunchKernelGGL(k_m4_gemm_fp6, dim3(tiles_m * tiles_n), dim3(256), G6_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, C, tiles_m, tiles_n);
-    CLV_LAUNCH_CHECK();
-    return CLV_OK;
+    return gemm_fp6_run(nullptr, A, sA, M, K, nullptr, B, sB, N, C, false, 0, 0, st);
+}
+
+extern "C" int clm4_gemm_prepared(const clm4_gemm_operand *opA, const int8_t *A, const float *sA, uint64_t M, uint64_t K,
+                                  const clm4_gemm_operand *opB, const int8_t *B, const float *sB, uint64_t N, float *C, void *stream)
+{
+    CLV_REQUIRE((opA || A) && (opB || B) && sA && sB && C, "clm4_gemm_prepared: null pointer");
+    CLV_REQUIRE(M && N && K && M % 128 == 0 && N % 128 == 0 && K % 128 == 0, "clm4_gemm_prepared: M=%llu N=%llu K=%llu must be non-zero multiples of 128",
+                (unsigned long long)M, (unsigned long long)N, (unsigned long long)K);
+    CLV_REQUIRE(!opA || (opA->rows == M && opA->K == K), "clm4_gemm_prepared: operand A was prepared as %llu x %llu", opA ? (unsigned long long)opA->rows : 0ull,
+                opA ? (unsigned long long)opA->K : 0ull);
+    CLV_REQUIRE(!opB || (opB->rows == N && opB->K == K), "clm4_gemm_prepared: operand B was prepared as %llu x %llu", opB ? (unsigned long long)opB->rows : 0ull,
+                opB ? (unsigned long long)opB->K : 0ull);
+    return gemm_fp6_run(opA, A, sA, M, K, opB, B, sB, N, C, false, 0, 0, as_stream(stream));
+}
+
+// exact integer sums of one K-block range, one thread per element (8 x v_dot8 per K-block): any range, used for odd ranges
+__global__ __launch_bounds__(256) void k_m4_gemm_i32_simple(const uint8_t *__restrict__ A, uint64_t M, uint64_t K, const uint8_t *__restrict__ B, uint64_t N,
+                                                            uint64_t kb0, uint64_t kbc, int32_t *__restrict__ S)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const uint64_t i = (uint64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= M || j >= N) return;
+    const u32x4 *a = reinterpret_cast<const u32x4 *>(A + i * (K / 2));
+    const u32x4 *b = reinterpret_cast<const u32x4 *>(B + j * (K / 2));
+    int acc = 0;
+    for (uint64_t blk = kb0; blk < kb0 + kbc; blk++) acc += dot32(a[2 * blk], b[2 * blk]) + dot32(a[2 * blk + 1], b[2 * blk + 1]);
+    S[i * N + j] = acc;
+}
+
+extern "C" int clm4_gemm_i32(const int8_t *A, uint64_t M, uint64_t K, const int8_t *B, uint64_t N, uint64_t kb_begin, uint64_t kb_count, int32_t *S,
+                             void *stream)
+{
+    CLV_REQUIRE(A && B && S, "clm4_gemm_i32: null pointer");
+    CLV_REQUIRE(M && N && K && M % 128 == 0 && N % 128 == 0 && K % 128 == 0, "clm4_gemm_i32: M=%llu N=%llu K=%llu must be non-zero multiples of 128",
+                (unsigned long long)M, (unsigned long long)N, (unsigned long long)K);
+    CLV_REQUIRE(kb_count && kb_begin + kb_count <= K / 64, "clm4_gemm_i32: K-blocks [%llu, +%llu) of %llu", (unsigned long long)kb_begin,
+                (unsigned long long)kb_count, (unsigned long long)(K / 64));
+    // fp32 accumulation of integers is exact below 2^24: 49 * 64 per K-block
+    CLV_REQUIRE(kb_count <= (1ull << 24) / (49 * 64), "clm4_gemm_i32: %llu K-blocks would leave the exact range of the matrix pipe", (unsigned long long)kb_count);
+    hipStream_t st = as_stream(stream);
+    static const bool simple = [] { const char *e = getenv("CLV_GEMM_KERNEL"); return e && !strcmp(e, "simple"); }();
+    if (((kb_begin | kb_count) & 1) || simple) {
+        hipLaunchKernelGGL(k_m4_gemm_i32_simple, dim3((unsigned)(N / 16), (unsigned)(M / 16)), dim3(256), 0, st, (const uint8_t *)A, M, K, (const uint8_t *)B, N,
+                           kb_begin, kb_count, S);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
+    return gemm_fp6_run(nullptr, A, nullptr, M, K, nullptr, B, nullptr, N, S, true, kb_begin, kb_count, st);
 }

@@ -1020,7 +1020,7 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
         return CLV_OK;
     }
     if (!workspace) {
-        int rc = clv_internal_workspace(&workspace, clv4_threshold_workspace_bytes(n_pad));
+        int rc = clv_internal_workspace(&workspace, clv4_threshold_workspace_bytes(n_pad), as_stream(stream));
         if (rc) return rc;
     }
     return threshold4_large((uint32_t *)q, s, n, n_pad, k, workspace, st);
@@ -1046,7 +1046,7 @@ extern "C" int clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
         return CLV_OK;
     }
     if (!workspace) {
-        int rc = clv_internal_workspace(&workspace, clv8_threshold_workspace_bytes(n_pad));
+        int rc = clv_internal_workspace(&workspace, clv8_threshold_workspace_bytes(n_pad), as_stream(stream));
         if (rc) return rc;
     }
     return threshold_large<8>((uint32_t *)q, s, n, k, workspace, st);

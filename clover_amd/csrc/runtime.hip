@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 // ---- errors -----------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -68,30 +69,57 @@ int clv_cu_count()
     return g_cu[dev];
 }
 
-// grow-only scratch per device; used only when a caller passes workspace == NULL
+// Grow-only scratch, one buffer per (device, stream): used when a caller passes workspace == NULL (clv4_dot, threshold) and by
+// clm4_gemm for the FP6 operand images.  Calls on DIFFERENT streams never share a buffer, so they may overlap; calls on one
+// stream are ordered by the stream.  Growing a buffer waits for that stream only (its old buffer may still be in use there).
+struct WsEntry {
+    int dev;
+    hipStream_t stream;
+    void *ptr;
+    uint64_t bytes;
+};
 static std::mutex g_ws_mutex;
-static void *g_ws_ptr[CLV_MAX_DEVICES];
-static uint64_t g_ws_bytes[CLV_MAX_DEVICES];
+static std::vector<WsEntry> g_ws;
 
-int clv_internal_workspace(void **ptr, uint64_t bytes)
+int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream)
 {
     int dev = 0;
     CLV_HIP(hipGetDevice(&dev));
-    CLV_REQUIRE(dev >= 0 && dev < CLV_MAX_DEVICES, "device index %d out of range", dev);
     std::lock_guard<std::mutex> lock(g_ws_mutex);
-    if (g_ws_bytes[dev] < bytes) {
-        if (g_ws_ptr[dev]) {
-            CLV_HIP(hipDeviceSynchronize());
-            CLV_HIP(hipFree(g_ws_ptr[dev]));
-            g_ws_ptr[dev] = nullptr;
-            g_ws_bytes[dev] = 0;
+    WsEntry *e = nullptr;
+    for (auto &w : g_ws)
+        if (w.dev == dev && w.stream == stream) { e = &w; break; }
+    if (!e) {
+        g_ws.push_back(WsEntry{dev, stream, nullptr, 0});
+        e = &g_ws.back();
+    }
+    if (e->bytes < bytes) {
+        if (e->ptr) {
+            CLV_HIP(hipStreamSynchronize(stream));
+            CLV_HIP(hipFree(e->ptr));
+            e->ptr = nullptr;
+            e->bytes = 0;
         }
         uint64_t want = bytes < (1ull << 20) ? (1ull << 20) : bytes;
-        CLV_HIP(hipMalloc(&g_ws_ptr[dev], want));
-        g_ws_bytes[dev] = want;
+        CLV_HIP(hipMalloc(&e->ptr, want));
+        e->bytes = want;
     }
-    *ptr = g_ws_ptr[dev];
+    *ptr = e->ptr;
     return CLV_OK;
+}
+
+// a destroyed stream's handle may be re-used by the runtime for a new stream: drop its scratch with it
+void clv_internal_workspace_forget(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (size_t k = 0; k < g_ws.size();) {
+        if (g_ws[k].stream == stream && stream != nullptr) {
+            if (g_ws[k].ptr) (void)hipFree(g_ws[k].ptr);
+            g_ws.erase(g_ws.begin() + (long)k);
+        } else {
+            k++;
+        }
+    }
 }
 
 // ---- memory / streams / events ------------------------------------------------------------------
@@ -139,7 +167,12 @@ extern "C" int clv_stream_create(void **stream)
     *stream = s;
     return CLV_OK;
 }
-extern "C" int clv_stream_destroy(void *stream) { CLV_HIP(hipStreamDestroy(as_stream(stream))); return CLV_OK; }
+extern "C" int clv_stream_destroy(void *stream)
+{
+    clv_internal_workspace_forget(as_stream(stream));
+    CLV_HIP(hipStreamDestroy(as_stream(stream)));
+    return CLV_OK;
+}
 extern "C" int clv_stream_sync(void *stream) { CLV_HIP(hipStreamSynchronize(as_stream(stream))); return CLV_OK; }
 extern "C" int clv_device_sync(void) { CLV_HIP(hipDeviceSynchronize()); return CLV_OK; }
 

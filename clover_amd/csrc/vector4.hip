@@ -381,7 +381,7 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
     hipStream_t st = as_stream(stream);
     if (!n_pad) { CLV_HIP(hipMemsetAsync(out_dev, 0, sizeof(float), st)); return CLV_OK; }
     if (!workspace) {
-        int rc = clv_internal_workspace(&workspace, clv4_dot_workspace_bytes(n_pad));
+        int rc = clv_internal_workspace(&workspace, clv4_dot_workspace_bytes(n_pad), as_stream(stream));
         if (rc) return rc;
     }
     if (mode == CLV_DOT_EXACT) {

@@ -26,8 +26,8 @@
  *    (rng == NULL); with an rng state the same XORShift stream as the reference's sequential methods is
  *    consumed (bit-identical nibbles for identical keys).  Exceptions are spelled out per function.
  *  - asynchrony: every call only enqueues work on `stream`; results are valid after clv_stream_sync / an event.
- *    clv4_dot and the threshold functions use a per-device scratch buffer when `workspace` is NULL: give each stream
- *    its own workspace (clv4_dot_workspace_bytes / clv*_threshold_workspace_bytes) if calls on different streams may overlap.
+ *    clv4_dot, the threshold functions (when `workspace` is NULL) and clm4_gemm use grow-only scratch owned by the library, one
+ *    buffer per (device, stream): calls on different streams never share scratch and may overlap.
  */
 #ifndef CLOVER_HIP_H
 #define CLOVER_HIP_H
@@ -123,10 +123,25 @@ int  clm4_rowdots(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols
                   const int8_t *x, const float *sx, float *d, void *stream);
 /* GEMM, build-defined (the reference has none; semantics in oracle/clover4_oracle.h and DESIGN.md):
  * A is M x K, B is N x K, C = A * B^T as fp32 M x N row-major, one fma chain over K-blocks per element.
- * Uses the library's internal per-device workspace ((M + N) * K * 3/4 bytes, grow-only): calls that share it must not
- * run concurrently on different streams of one device. */
+ * Uses grow-only scratch of (M + N) * K * 3/4 bytes that belongs to (device, stream): calls on different streams may overlap. */
 int  clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K,
                const int8_t *B, const float *sB, uint64_t N, float *C, void *stream);
+
+/* The matrix kernel behind clm4_gemm streams its operands as FP6 (E2M3) codes in staging order; clm4_gemm re-codes both of them on
+ * every call.  An operand that is multiplied many times (weights) can be re-coded once: clm4_gemm_prepare allocates rows*K*3/4
+ * bytes of HBM for the image (it keeps no reference to q: prepare again after q changes), clm4_gemm_prepared takes either operand
+ * prepared (op != NULL) or raw (op == NULL, nibbles in A / B).  Results are those of clm4_gemm, bit for bit. */
+typedef struct clm4_gemm_operand clm4_gemm_operand;
+int  clm4_gemm_prepare(const int8_t *q, uint64_t rows, uint64_t K, clm4_gemm_operand **op, void *stream);
+int  clm4_gemm_release(clm4_gemm_operand *op);
+int  clm4_gemm_prepared(const clm4_gemm_operand *opA, const int8_t *A, const float *sA, uint64_t M, uint64_t K,
+                        const clm4_gemm_operand *opB, const int8_t *B, const float *sB, uint64_t N, float *C, void *stream);
+/* The exact integer part of the GEMM (output (1)): S[i][j] = sum over K-blocks [kb_begin, kb_begin + kb_count) of the
+ * 64 nibble products, int32, row-major M x N.  With the full range this is the unscaled int4 x int4 -> int32 GEMM; with a range of
+ * one K-block it is the per-block sum the fp32 result folds.  Even kb_begin and kb_count run on the matrix kernel (accumulating
+ * across K-blocks inside the pipe: integers below 2^24 are exact there), other ranges on a VALU kernel. */
+int  clm4_gemm_i32(const int8_t *A, uint64_t M, uint64_t K, const int8_t *B, uint64_t N, uint64_t kb_begin, uint64_t kb_count,
+                   int32_t *S, void *stream);
 
 /* ---- callers either side of the hot path: the other steps of the quantized IHT/GD loops ---- */
 /* CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478; _parallel :1489-1791): r = quantize(u + a*v) per

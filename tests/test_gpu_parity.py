@@ -8,6 +8,8 @@ ragged / edge cases; big configurations are covered by properties in test_gpu_la
 import json
 from pathlib import Path
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -170,6 +172,70 @@ def test_gemm_bit_exact(hip, oracle, shape):
     sB = rng.uniform(0.5, 2.0, size=(N // 64) * (K // 64)).astype(np.float32)
     C = hip.m4_gemm(qA, sA, M, K, qB, sB, N)
     assert same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N))
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 128), (256, 128, 512), (128, 384, 768)])
+def test_gemm_integer_sums_exact(hip, oracle, shape):
+    """SURVEY 8(a8) output (1): the exact int32 K-block sums, through the C ABI.  Ranges with even begin and count run on the MFMA
+    kernel (accumulating across K-blocks inside the matrix pipe), the others on the VALU kernel; both must equal the oracle's
+    per-block sums added up, and the whole range is the unscaled int4 x int4 -> int32 GEMM."""
+    M, N, K = shape
+    rng = np.random.default_rng(7 * M + N + K)
+    qA, _ = random_packed(rng, M * K)
+    qB, _ = random_packed(rng, N * K)
+    S = oracle.m4_gemm_isums(qA, M, K, qB, N).astype(np.int64)            # [M][N][K / 64]
+    kb = K // 64
+    assert np.array_equal(hip.m4_gemm_i32(qA, M, K, qB, N), S.sum(2))
+    for b0, cnt in [(0, 2), (kb - 2, 2), (0, 1), (kb - 1, 1), (1, kb - 1), (2, kb - 2) if kb > 2 else (0, 2)]:
+        got = hip.m4_gemm_i32(qA, M, K, qB, N, b0, cnt)
+        assert np.array_equal(got, S[:, :, b0:b0 + cnt].sum(2)), (b0, cnt)
+    # all nibbles at +-7: the largest sums the format allows
+    q7 = np.full(M * K // 2, 0x77, np.uint8)
+    qm = np.full(N * K // 2, 0x99, np.uint8)
+    assert (hip.m4_gemm_i32(q7, M, K, qm, N) == -49 * K).all()
+
+
+@pytest.mark.parametrize("prepare", [("A",), ("B",), ("A", "B")])
+def test_gemm_with_prepared_operands_equals_gemm(hip, oracle, prepare):
+    M, N, K = 256, 384, 640
+    rng = np.random.default_rng(len(prepare) * 11 + ord(prepare[0]))
+    qA, _ = random_packed(rng, M * K)
+    qB, _ = random_packed(rng, N * K)
+    sA = rng.uniform(0.5, 2.0, size=(M // 64) * (K // 64)).astype(np.float32)
+    sB = rng.uniform(0.5, 2.0, size=(N // 64) * (K // 64)).astype(np.float32)
+    C = hip.m4_gemm_prepared(qA, sA, M, K, qB, sB, N, prepare=prepare)
+    assert same(C, hip.m4_gemm(qA, sA, M, K, qB, sB, N)) and same(C, oracle.m4_gemm(qA, sA, M, K, qB, sB, N))
+
+
+def test_gemm_calls_on_two_streams_do_not_share_scratch(hip, oracle):
+    """clm4_gemm keeps its FP6 images in scratch that belongs to (device, stream): two different products enqueued back to back
+    on two streams must both come out right (with one shared buffer the second re-code would overwrite the first one's operands)"""
+    lib = hip.lib
+    M = N = K = 1024
+    rng = np.random.default_rng(99)
+    data = []
+    for _ in range(2):
+        qA, _ = random_packed(rng, M * K)
+        qB, _ = random_packed(rng, N * K)
+        sA = rng.uniform(0.5, 2.0, size=(M // 64) * (K // 64)).astype(np.float32)
+        sB = rng.uniform(0.5, 2.0, size=(N // 64) * (K // 64)).astype(np.float32)
+        data.append((qA, sA, qB, sB))
+    streams = [C.c_void_p(), C.c_void_p()]
+    for st in streams:
+        hip.check(lib.clv_stream_create(C.byref(st)))
+    dev = [[hip.to_device(a) for a in d] for d in data]
+    out = [hip.alloc(M * N * 4), hip.alloc(M * N * 4)]
+    hip.sync()
+    for rep in range(3):
+        for k in (0, 1):
+            b = dev[k]
+            hip.check(lib.clm4_gemm(b[0].ptr, b[1].ptr, M, K, b[2].ptr, b[3].ptr, N, out[k].ptr, streams[k]))
+    for st in streams:
+        hip.check(lib.clv_stream_sync(st))
+    for k in (0, 1):
+        assert same(out[k].download(np.float32, M * N).reshape(M, N), hip.m4_gemm(*data[k][:2], M, K, *data[k][2:], N))
+    for st in streams:
+        hip.check(lib.clv_stream_destroy(st))
 
 
 def test_gemm_wide_scale_range(hip, oracle):
