@@ -61,9 +61,15 @@ def cpu_baseline_child(path: str) -> None:
         d = {k: z[k] for k in z.files}            # materialise once (NpzFile re-reads the zip on every access)
     rows, cols = int(d["rows"]), int(d["cols"])
     F = FastOracle()
+    F.set_kernel("maddubs")                       # the reference's instruction mix (CloverVector4.h:1136-1180)
     best = None
     cores = os.cpu_count() or 1
+    try:
+        runnable = len(os.sched_getaffinity(0))   # cpus this process may run on
+    except AttributeError:
+        runnable = cores
     out = (np.zeros(rows // 2, np.uint8), np.zeros(rows // 64, np.float32))
+    tried = {}
     for threads in sorted({1, min(16, cores), min(64, cores), max(1, cores // 2), cores}):
         if threads > rows // 64:
             continue
@@ -77,8 +83,9 @@ def cpu_baseline_child(path: str) -> None:
             F.m4_mvm(qA, d["sA"], rows, cols, d["qx"], d["sx"], out=out)
             ts.append(time.perf_counter() - t0)
         med = sorted(ts)[len(ts) // 2]
+        tried[threads] = round(med * 1e3, 3)
         if best is None or med < best[0]:
-            best = (med, threads)
+            best = (med, threads, min(ts), max(ts), len(ts))
     match = bool(np.array_equal(out[0], d["r"]) and np.array_equal(out[1].view(np.uint32), d["sr"].view(np.uint32)))
     # the other half of BASELINE's metric: dot (the reference's sequential `dot`, one core) on two vectors cut out of the sample
     dot = None
@@ -92,7 +99,8 @@ def cpu_baseline_child(path: str) -> None:
             F.v4_dot(qu, sc, qv, sc)
             ts.append(time.perf_counter() - t0)
         dot = {"n": n, "seconds": sorted(ts)[2]}
-    print(json.dumps({"seconds": best[0], "threads": best[1], "gpu_result_matches_cpu": match, "dot": dot}))
+    print(json.dumps({"seconds": best[0], "threads": best[1], "min_s": best[2], "max_s": best[3], "runs": best[4], "median_ms_by_threads": tried,
+                      "runnable_cpus": runnable, "gpu_result_matches_cpu": match, "dot": dot}))
 
 
 def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sample_rows: int) -> dict:
@@ -132,9 +140,12 @@ def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sampl
     return {
         "value": round(nbytes / res["seconds"] / 1e9, 3), "unit": "GB/s", "cores": res["threads"], "kind": "port",
         "sample": f"mvm of the first {sample_rows} rows x {cols} cols of the same matrix ({nbytes} B), median of <=15 runs, "
-                  f"AVX2+OpenMP restatement (oracle/clover4_fast.c, bound threads, NUMA first-touch placement, best of 1/16/64/half/all "
-                  f"threads) on {cpu_model}, {os.cpu_count()} cpus, {quota}",
-        "ms": round(res["seconds"] * 1e3, 3), "gpu_result_matches_cpu": res["gpu_result_matches_cpu"],
+                  f"AVX2+OpenMP restatement with the reference's vpmaddubsw instruction mix (oracle/clover4_fast.c, bound threads, NUMA "
+                  f"first-touch placement, best of 1/16/64/half/all threads) on {cpu_model}, {os.cpu_count()} cpus, "
+                  f"{res.get('runnable_cpus')} runnable by this process, {quota}",
+        "ms": round(res["seconds"] * 1e3, 3), "ms_min": round(res["min_s"] * 1e3, 3), "ms_max": round(res["max_s"] * 1e3, 3), "runs": res["runs"],
+        "threads_used": res["threads"], "runnable_cpus": res.get("runnable_cpus"), "cgroup": quota,
+        "median_ms_by_threads": res.get("median_ms_by_threads"), "gpu_result_matches_cpu": res["gpu_result_matches_cpu"],
         **({"dot": {"value": round(1.125 * res["dot"]["n"] / res["dot"]["seconds"] / 1e9, 3), "unit": "GB/s", "cores": 1,
                     "sample": f"CloverVector4::dot order (sequential, as the reference's dot), n = {res['dot']['n']}, median of 5"}}
            if res.get("dot") else {}),
@@ -145,9 +156,12 @@ def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sampl
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=65536)
+    ap.add_argument("--preset", choices=("c3", "c5-weak", "c5-strong"), default="c3",
+                    help="c3 (default): 65536 x 65536 per GPU, weak scaling (BASELINE configs[2] at N=1); c5-weak: 131072 x 65536 per GPU "
+                         "(= configs[4] at N=8); c5-strong: the 2^20 x 2^16 matrix of configs[4] split over the N GPUs (needs N * 288 GB >= 32 GiB: any N)")
     ap.add_argument("--cols", type=int, default=65536)
     ap.add_argument("--cpu-sample-rows", type=int, default=32768,
                     help="rows of the matrix the CPU baseline multiplies (32768 x 65536 = 1 GiB of nibbles: beyond the 2 x 256 MB of L3 "
@@ -197,8 +211,14 @@ def main() -> None:
     lib = hip.lib
     stream = torch.cuda.current_stream().cuda_stream
 
+    scaling = "weak"
+    if args.preset == "c5-weak":
+        args.rows_per_gpu = 131072
+    elif args.preset == "c5-strong":
+        assert (1 << 20) % (64 * world) == 0
+        args.rows_per_gpu, scaling = (1 << 20) // world, "strong"
     rows, cols = args.rows_per_gpu, args.cols
-    assert rows % 128 == 0 and cols % 128 == 0
+    assert rows % 64 == 0 and cols % 128 == 0
     rows_total = rows * world
     hb = cols // 64
     seed = 0xC10FE4
@@ -267,6 +287,23 @@ def main() -> None:
     if world > 1:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kern_avg_ms = float(kt.item())
+    per_rank_kernel_ms, gather_us, rccl_ranks = None, None, None
+    if world > 1:
+        pr = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(pr, torch.tensor([sum(kern_ms) / len(kern_ms)], dtype=torch.float64, device=red_dev))
+        per_rank_kernel_ms = [round(float(v.item()), 5) for v in pr]
+        rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+        # the exchange alone, outside the timed region: K blocking all-gathers of the packed result
+        reps = 50
+        dist.barrier()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        for _ in range(reps):
+            gather_packed(res.cpu() if debug_one_gpu else res, rows_total)
+        torch.cuda.synchronize()
+        gt = torch.tensor([(time.perf_counter() - g0) / reps * 1e6], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather_us = round(float(gt.item()), 1)
 
     # outside the timed region: every rank finds its own shard, bit for bit, at its place in the gathered vector
     gather_ok = None
@@ -295,13 +332,16 @@ def main() -> None:
     out = {
         "metric": "int4 GEMV (CloverMatrix4::mvm) effective GB/s, algorithmic operand bytes / time",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "int4", "data": "synthetic",
         "config": {
-            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 (BASELINE configs[2] per GPU), x and result CloverVector4, "
-                        f"STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
+            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 ({rows}x{cols} per GPU; preset {args.preset}: BASELINE "
+                        f"{'configs[2] per GPU' if args.preset == 'c3' else 'configs[4]' + (' at N=8' if args.preset == 'c5-weak' else '')}), "
+                        f"x and result CloverVector4, STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
             "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of every step's packed result, overlapped with the next step" if world > 1 else ""),
-            **({"gathered_result_verified": gather_ok} if world > 1 else {}),
+            **({"gathered_result_verified": gather_ok, "rccl_ranks": rccl_ranks, "backend": dist.get_backend(),
+                "per_rank_kernel_ms": per_rank_kernel_ms, "gather_us_blocking": gather_us,
+                "gather_bytes_per_rank": packed_bytes(rows)} if world > 1 else {}),
             **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all ranks on one GPU, gloo through the host -- not a measurement"} if debug_one_gpu else {}),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_step": bytes_total,
@@ -327,6 +367,8 @@ def main() -> None:
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
     if world == 1 and not args.no_extras:
+        del A, sA                                     # make room: the HBM-resident vector workloads below take 14 GiB
+        out["gemm"] = gemm_object(hip, torch, dev, stream)
         out["extras"] = extras(hip, torch, dev, stream)
 
     print(json.dumps(out))
@@ -336,7 +378,7 @@ def main() -> None:
 
 def gemm_main(args) -> None:
     """BASELINE configs[3]: CloverMatrix4::gemm G x G x G (default 8192) on one GPU.  A step = one clm4_gemm call (the FP6 re-coding
-    pass + the MFMA kernel); the matrix-pipe bound is the dense int8 peak BASELINE names (5 POP/s), the FP6 peak is quoted beside."""
+    pass + the MFMA kernel); the bound is the dense FP6 peak of the pipe the kernel uses (10 POP/s), the int8 figure is quoted beside."""
     import torch
 
     from clover_amd.lib_binding import CloverHip
@@ -385,19 +427,113 @@ def gemm_main(args) -> None:
         "config": {"workload": f"CloverMatrix4::gemm {G}x{G}x{G} int4 (BASELINE configs[3]), bit-exact against the build-defined "
                                "semantics (one fma chain over the 64-element K-blocks per element)", "M": G, "N": G, "K": G,
                    "parallelism": "1 GPU"},
-        "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": 5000.0, "unit": "TOP/s", "frac": round(ach / 5000.0, 4),
-                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6 (one clm4_gemm call)", "kernel_avg_ms": round(call_ms, 5),
-                     "peak_note": "5 POP/s = dense int8 MFMA, the pipe BASELINE names; the kernel runs on the FP6 block-scaled pipe "
-                                  "(10 PF dense): frac of that = " + str(round(ach / 10000.0, 4)) + "; matrix-pipe busy cycles from PMC in "
-                                  "profiles/r01_gemm_fp6_8192_pmc.txt"},
+        "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": FP6_PEAK_TOPS, "unit": "TOP/s", "frac": round(ach / FP6_PEAK_TOPS, 4),
+                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_asm (one clm4_gemm call)", "kernel_avg_ms": round(call_ms, 5),
+                     "frac_of_int8_peak": round(ach / INT8_PEAK_TOPS, 4),
+                     "peak_note": "10 POP/s = dense FP6 block-scaled MFMA, the pipe the kernel runs on; 5 POP/s = dense int8 MFMA, the pipe "
+                                  "BASELINE names; counters in profiles/"},
     }))
 
 
+def _timeit(torch, fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+FP6_PEAK_TOPS = 10000.0     # dense FP6/FP4 block-scaled MFMA (MI355X_MICROARCH.md): the pipe the GEMM kernel runs on
+INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA: the pipe BASELINE's wording names
+
+
+def gemm_object(hip, torch, dev, stream, G: int = 8192) -> dict:
+    """BASELINE configs[3]: CloverMatrix4::gemm 8192^3.  One clm4_gemm call = the FP6 re-coding pass over both operands + the matrix
+    kernel; timed with HIP events on the launch stream.  Normalised to the FP6 dense peak (the pipe in use); the int8 figure beside."""
+    import ctypes as C
+    lib = hip.lib
+    gA = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
+    gB = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
+    gsA = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
+    gsB = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
+    gC = torch.empty(G * G, dtype=torch.float32, device=dev)
+    for t, sd in ((gA, 21), (gB, 22)):
+        hip.check(lib.clv_fill_random_nibbles(t.data_ptr(), t.numel(), sd, 0, stream))
+    for t, sd in ((gsA, 23), (gsB, 24)):
+        hip.check(lib.clv_fill_random_scales(t.data_ptr(), t.numel(), sd, 0, stream))
+    ops = 2.0 * G ** 3
+    g_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm(gA.data_ptr(), gsA.data_ptr(), G, G, gB.data_ptr(), gsB.data_ptr(), G, gC.data_ptr(), stream)), 20)
+    opA, opB = C.c_void_p(), C.c_void_p()
+    hip.check(lib.clm4_gemm_prepare(gA.data_ptr(), G, G, C.byref(opA), stream))
+    hip.check(lib.clm4_gemm_prepare(gB.data_ptr(), G, G, C.byref(opB), stream))
+    p_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_prepared(opA, None, gsA.data_ptr(), G, G, opB, None, gsB.data_ptr(), G, gC.data_ptr(), stream)), 20)
+    hip.check(lib.clm4_gemm_release(opA))
+    hip.check(lib.clm4_gemm_release(opB))
+    i_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_i32(gA.data_ptr(), G, G, gB.data_ptr(), G, 0, G // 64, gC.data_ptr(), stream)), 20)
+    tops = ops / g_ms / 1e9
+    return {
+        "workload": f"CloverMatrix4::gemm {G}x{G}x{G} int4 x int4 -> fp32 (BASELINE configs[3]), both operands re-coded inside the call, "
+                    "bit-exact against the build-defined semantics (one fma chain over the 64-element K-blocks per element)",
+        "ms": round(g_ms, 4), "value": round(tops, 1), "unit": "TOP/s",
+        "roofline": {"bound": "mfma", "achieved": round(tops, 1), "peak": FP6_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / FP6_PEAK_TOPS, 4),
+                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_asm (one clm4_gemm call)", "kernel_avg_ms": round(g_ms, 4),
+                     "frac_of_int8_peak": round(tops / INT8_PEAK_TOPS, 4),
+                     "peak_note": "10 POP/s = dense FP6 block-scaled MFMA, the pipe the kernel runs on (nibbles are exact E2M3 values); "
+                                  "5 POP/s = dense int8 MFMA, the pipe BASELINE names"},
+        "prepared_operands": {"ms": round(p_ms, 4), "TOP/s": round(ops / p_ms / 1e9, 1), "frac_of_fp6_peak": round(ops / p_ms / 1e9 / FP6_PEAK_TOPS, 4),
+                              "note": "clm4_gemm_prepared: both FP6 images made once outside the timed region (weights-style reuse)"},
+        "int32_unscaled": {"ms": round(i_ms, 4), "TOP/s": round(ops / i_ms / 1e9, 1), "frac_of_fp6_peak": round(ops / i_ms / 1e9 / FP6_PEAK_TOPS, 4),
+                           "note": "clm4_gemm_i32 over all K-blocks: the exact int4 x int4 -> int32 contraction (no scales), accumulated inside "
+                                   "the matrix pipe; time includes the re-coding pass"},
+        "note": "CLV_GEMM_LOOP=hipcc runs the compiler-scheduled main loop, CLV_GEMM_KERNEL=i8 the int8-MFMA kernel (A/B runs)",
+    }
+
+
+def hbm_resident(hip, torch, dev, stream) -> dict:
+    """BASELINE configs[1]'s operations at a footprint that cannot live in the 256 MiB Infinity Cache: n = 2^30 (fp32 source 4 GiB,
+    a quantized vector 576 MiB).  Algorithmic bytes per call as in SURVEY 8(d); HIP events on the launch stream."""
+    from clover_amd.lib_binding import DOT_FAST
+    lib = hip.lib
+    n = 1 << 30
+    xs = torch.empty(n, dtype=torch.float32, device=dev)
+    hip.check(lib.clv_fill_random_ints_f32(xs.data_ptr(), n, 10, 11, 0, stream))
+    qa = torch.empty(n // 2, dtype=torch.uint8, device=dev)
+    qb = torch.empty(n // 2, dtype=torch.uint8, device=dev)
+    sa = torch.empty(n // 64, dtype=torch.float32, device=dev)
+    sb = torch.empty(n // 64, dtype=torch.float32, device=dev)
+    o = torch.empty(2, dtype=torch.float32, device=dev)
+    rng_state = hip.new_rng(5, 6)
+    q_ms = _timeit(torch, lambda: hip.check(lib.clv4_quantize(xs.data_ptr(), n, qa.data_ptr(), sa.data_ptr(), None, stream)), 10)
+    qs_ms = _timeit(torch, lambda: hip.check(lib.clv4_quantize(xs.data_ptr(), n, qb.data_ptr(), sb.data_ptr(), rng_state.ptr, stream)), 10)
+    f_ms = _timeit(torch, lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_FAST, o.data_ptr(), None, stream)), 10)
+    sa_ms = _timeit(torch, lambda: hip.check(lib.clv4_scale_and_add(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), 0.5, n, qb.data_ptr(), sb.data_ptr(), None, stream)), 10)
+    r_ms = _timeit(torch, lambda: hip.check(lib.clv4_restore(qa.data_ptr(), sa.data_ptr(), n, xs.data_ptr(), stream)), 10)
+
+    def obj(nbytes, ms, what):
+        gbs = nbytes / ms / 1e6
+        return {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes": int(nbytes), "what": what}
+    return {
+        "n": n,
+        "quantize": obj(4.5625 * n, q_ms, "CloverVector4::quantize, rounding disabled (4 B in, 0.5625 B out per element)"),
+        "quantize_stochastic": obj(4.5625 * n, qs_ms, "the same with the XORShift stream (the reference's default build)"),
+        "dot_fast": obj(1.125 * n, f_ms, "CloverVector4::dot, exact integer block sums, fp32 tree order (dot_parallel's role)"),
+        "scale_and_add": obj(3 * 0.5625 * n, sa_ms, "CloverVector4::scaleAndAdd in place (two vectors in, one out)"),
+        "restore": obj(4.5625 * n, r_ms, "CloverVector4::restore (0.5625 B in, 4 B out per element)"),
+    }
+
+
 def extras(hip, torch, dev, stream) -> dict:
-    """Secondary numbers of the same path (configs[1]): vector quantize + dot at n = 2^24.
-    These footprints fit the 256 MiB Infinity Cache, so they are NOT HBM-roofline claims."""
+    """Secondary numbers of the same path.  `hbm_resident`: configs[1]'s operations at n = 2^30, each with its own achieved / peak /
+    frac.  The n = 2^24 figures of configs[1] itself fit the 256 MiB Infinity Cache: cache-resident rates, kept as a footnote."""
     from clover_amd.lib_binding import DOT_EXACT, DOT_FAST
     lib = hip.lib
+    hbm = hbm_resident(hip, torch, dev, stream)
     n = 1 << 24
     xs = torch.empty(n, dtype=torch.float32, device=dev)
     ys = torch.empty(n, dtype=torch.float32, device=dev)
@@ -410,41 +546,13 @@ def extras(hip, torch, dev, stream) -> dict:
     o = torch.empty(2, dtype=torch.float32, device=dev)
 
     def timeit(fn, reps):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / reps
+        return _timeit(torch, fn, reps)
 
     q_ms = timeit(lambda: hip.check(lib.clv4_quantize(xs.data_ptr(), n, qa.data_ptr(), sa.data_ptr(), None, stream)), 50)
     hip.check(lib.clv4_quantize(ys.data_ptr(), n, qb.data_ptr(), sb.data_ptr(), None, stream))
     f_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_FAST, o.data_ptr(), None, stream)), 50)
     e_ms = timeit(lambda: hip.check(lib.clv4_dot(qa.data_ptr(), sa.data_ptr(), qb.data_ptr(), sb.data_ptr(), n, DOT_EXACT, o.data_ptr() + 4, None, stream)), 5)
     vals = o.cpu().numpy()
-    # configs[3]: gemm 8192^3 (block-scaled FP6 MFMA on exact E2M3 operands, one fma per element and K-block)
-    G = 8192
-    gA = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
-    gB = torch.empty(G * G // 2, dtype=torch.uint8, device=dev)
-    gsA = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
-    gsB = torch.empty((G // 64) ** 2, dtype=torch.float32, device=dev)
-    gC = torch.empty(G * G, dtype=torch.float32, device=dev)
-    for t, sd in ((gA, 21), (gB, 22)):
-        hip.check(lib.clv_fill_random_nibbles(t.data_ptr(), t.numel(), sd, 0, stream))
-    for t, sd in ((gsA, 23), (gsB, 24)):
-        hip.check(lib.clv_fill_random_scales(t.data_ptr(), t.numel(), sd, 0, stream))
-    g_ms = timeit(lambda: hip.check(lib.clm4_gemm(gA.data_ptr(), gsA.data_ptr(), G, G, gB.data_ptr(), gsB.data_ptr(), G, gC.data_ptr(), stream)), 10)
-    gemm = {"ms": round(g_ms, 4), "TOP/s": round(2.0 * G ** 3 / g_ms / 1e9, 1),
-            "frac_of_int8_mfma_peak": round(2.0 * G ** 3 / g_ms / 1e9 / 5000.0, 4),
-            "frac_of_fp6_mfma_peak": round(2.0 * G ** 3 / g_ms / 1e9 / 10000.0, 4),
-            "note": "int4 x int4, bit-exact: nibbles re-coded once as FP6 E2M3 (exact), v_mfma_scale_f32_32x32x64_f8f6f4 returns the "
-                    "integer block sums as fp32, one fma per element folds the block scale; time includes the re-coding pass; "
-                    "peaks: 5 POP/s dense int8 (the pipe BASELINE names), 10 PF dense FP6; CLV_GEMM_KERNEL=i8 runs the int8-MFMA kernel"}
-    del gA, gB, gC
     # the caller loop: one quantized IHT iteration, N = 8192 (m x 2m, K = 25 % of m), HBM-resident
     m, nn = 4096, 8192
     Phi = torch.empty(m * nn // 2, dtype=torch.uint8, device=dev)
@@ -529,14 +637,17 @@ def extras(hip, torch, dev, stream) -> dict:
                    "01_measure.h:1117-1125; _v8 = the published configuration (4-bit matrix, 8-bit vectors); reference published "
                    "19.5 GB/s with 4 threads (performance.txt:581)"}
     return {
+        "hbm_resident_n2^30": hbm,
         "iht_iteration_N8192": iht,
-        "gemm_8192^3": gemm,
-        "note": "n=2^24 operands (76.5 MB / 18.9 MB) fit the Infinity Cache: cache-resident rates, not HBM-roofline claims",
-        "quantize_n2^24": {"ms": round(q_ms, 5), "GB/s": round(4.5625 * n / q_ms / 1e6, 1)},
-        "dot_fast_n2^24": {"ms": round(f_ms, 5), "GB/s": round(1.125 * n / f_ms / 1e6, 1), "GFLOP/s": round(2 * n / f_ms / 1e6, 1)},
-        "dot_exact_n2^24": {"ms": round(e_ms, 5), "GB/s": round(1.125 * n / e_ms / 1e6, 1),
-                            "note": "reference's 16 sequential fma chains: latency-bound by definition"},
-        "dot_fast_minus_exact_rel": float(abs(vals[0] - vals[1]) / max(abs(vals[1]), 1e-30)),
+        "footnote_cache_resident_n2^24": {
+            "note": "BASELINE configs[1] sizes: the operands (76.5 MB / 18.9 MB) fit the 256 MiB Infinity Cache -- cache-resident, "
+                    "launch-bound rates, NOT HBM-roofline claims (those are hbm_resident_n2^30 above)",
+            "quantize": {"ms": round(q_ms, 5), "GB/s": round(4.5625 * n / q_ms / 1e6, 1)},
+            "dot_fast": {"ms": round(f_ms, 5), "GB/s": round(1.125 * n / f_ms / 1e6, 1), "GFLOP/s": round(2 * n / f_ms / 1e6, 1)},
+            "dot_exact": {"ms": round(e_ms, 5), "GB/s": round(1.125 * n / e_ms / 1e6, 1),
+                          "note": "the reference's 16 sequential fma chains (131072 dependent fmas each at this n): latency-bound by definition"},
+            "dot_fast_minus_exact_rel": float(abs(vals[0] - vals[1]) / max(abs(vals[1]), 1e-30)),
+        },
     }
 
 

@@ -225,6 +225,10 @@ class FastOracle:
     def set_threads(self, n: int) -> None:
         self.L.orcf_set_threads(C.c_int(n))
 
+    def set_kernel(self, name: str) -> None:
+        """"maddubs" (default): the reference's instruction mix (CloverVector4.h:1136-1180); "planes": int16 planes + vpmaddwd"""
+        self.L.orcf_set_kernel(C.c_int({"planes": 0, "maddubs": 1}[name]))
+
     def first_touch_copy(self, A: np.ndarray, rows: int) -> np.ndarray:
         """a copy of the packed matrix whose pages were first touched by the threads that will read them in m4_mvm"""
         out = np.empty(A.size, np.uint8)                 # np.empty does not touch the pages

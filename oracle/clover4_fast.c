@@ -3,7 +3,7 @@
  * TEST / BENCH INFRASTRUCTURE ONLY -- never linked into libclover_hip.so.
  *
  * Same results, bit for bit, as the scalar oracle (clover4_oracle.c) and therefore as the reference's
- * AVX2 path (rounding disabled); tests/test_oracle_fast.py asserts that.  It plays the role of
+ * AVX2 path (rounding disabled); tests/test_oracle_properties.py asserts that.  It plays the role of
  * "Clover's own AVX2 path on the host cores" next to the GPU numbers, because the reference sources
  * can neither be built in this image (IPP/MKL headers) nor travel to the GPU box.
  *
@@ -11,9 +11,12 @@
  * over threads (CloverMatrix4.h:1700-1705), quantize splits 64-element blocks (CloverVector4.h:818-828);
  * dot stays sequential because its fp32 order is part of the result (dot_parallel is not reproducible).
  *
- * The nibble arithmetic is written independently of the reference: nibbles are sign-extended into four
- * int16 "planes" with shifts and multiplied with vpmaddwd, which yields the exact per-32-bit-word integer
- * directly (the reference reaches the same integer through vpsignb/vpmaddubsw on 16x-scaled bytes).
+ * Two interchangeable kernels for the per-word integer sums (orcf_set_kernel), both own code:
+ *   1 "maddubs" (default, the timed one): the reference's INSTRUCTION MIX (CloverVector4.h:1136-1180) -- nibbles kept as
+ *     16x-scaled bytes (and 0xF0 / shift-left-4), |u| and sign(v, u) so that vpmaddubsw can multiply unsigned x signed,
+ *     arithmetic shift right 8 (the products are multiples of 256), add the two planes, vpmaddwd with ones -> int32 per word;
+ *   0 "planes": nibbles sign-extended into four int16 planes with shifts, multiplied with vpmaddwd.
+ * Same integers either way (tests/test_oracle_properties.py), so the fp32 results are bit-identical.
  */
 #include <immintrin.h>
 #include <math.h>
@@ -61,6 +64,24 @@ static inline __m256i block_word_isums(__m256i u, __m256i v)
     return _mm256_add_epi32(p32, p10);
 }
 
+/* the same integers with the reference's instruction mix: 16x-scaled nibble bytes through vpmaddubsw */
+static inline __m256i block_word_isums_maddubs(__m256i u, __m256i v)
+{
+    const __m256i hi_mask = _mm256_set1_epi8((char)0xF0);
+    const __m256i u_hi = _mm256_and_si256(u, hi_mask), v_hi = _mm256_and_si256(v, hi_mask);                   /* 16 * q(2i)   */
+    const __m256i u_lo = _mm256_and_si256(_mm256_slli_epi16(u, 4), hi_mask);                                  /* 16 * q(2i+1) */
+    const __m256i v_lo = _mm256_and_si256(_mm256_slli_epi16(v, 4), hi_mask);
+    /* |16 q| <= 112 fits the unsigned operand; the sign moves to the signed one.  2 * 112^2 < 32767: no saturation */
+    const __m256i p_hi = _mm256_maddubs_epi16(_mm256_abs_epi8(u_hi), _mm256_sign_epi8(v_hi, u_hi));
+    const __m256i p_lo = _mm256_maddubs_epi16(_mm256_abs_epi8(u_lo), _mm256_sign_epi8(v_lo, u_lo));
+    const __m256i s16 = _mm256_add_epi16(_mm256_srai_epi16(p_hi, 8), _mm256_srai_epi16(p_lo, 8));            /* 4 products each */
+    return _mm256_madd_epi16(s16, _mm256_set1_epi16(1));                                                      /* 8 per 32-bit word */
+}
+
+static int g_kernel = 1;
+void orcf_set_kernel(int k) { g_kernel = k ? 1 : 0; }
+int orcf_get_kernel(void) { return g_kernel; }
+
 /* the reference's final tree (CloverBase.h:149-157) on acc0 + acc1 */
 static inline float reduce_tree(__m256 acc0, __m256 acc1)
 {
@@ -71,22 +92,28 @@ static inline float reduce_tree(__m256 acc0, __m256 acc1)
     return y0 + y1;
 }
 
+#define DOT_ROW_BODY(ISUMS)                                                                     \
+    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();                             \
+    for (uint64_t b = 0; b < nb; b += 2) {                                                     \
+        const __m256i ua = _mm256_loadu_si256((const __m256i *)(qu + 32 * b));                 \
+        const __m256i va = _mm256_loadu_si256((const __m256i *)(qv + 32 * b));                 \
+        const __m256i ub = _mm256_loadu_si256((const __m256i *)(qu + 32 * b + 32));            \
+        const __m256i vb = _mm256_loadu_si256((const __m256i *)(qv + 32 * b + 32));            \
+        const float ca = (su[b] * RCP49) * sv[b];                                              \
+        const float cb = (su[b + 1] * RCP49) * sv[b + 1];                                      \
+        const __m256 fa = _mm256_cvtepi32_ps(ISUMS(ua, va));                                   \
+        const __m256 fb = _mm256_cvtepi32_ps(ISUMS(ub, vb));                                   \
+        acc0 = _mm256_fmadd_ps(_mm256_set1_ps(ca), fa, acc0);                                  \
+        acc1 = _mm256_fmadd_ps(_mm256_set1_ps(cb), fb, acc1);                                  \
+    }                                                                                          \
+    return reduce_tree(acc0, acc1);
+
+static float dot_row_planes(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t nb) { DOT_ROW_BODY(block_word_isums) }
+static float dot_row_maddubs(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t nb) { DOT_ROW_BODY(block_word_isums_maddubs) }
+
 static inline float dot_row(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t nb)
 {
-    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();
-    for (uint64_t b = 0; b < nb; b += 2) {
-        const __m256i ua = _mm256_loadu_si256((const __m256i *)(qu + 32 * b));
-        const __m256i va = _mm256_loadu_si256((const __m256i *)(qv + 32 * b));
-        const __m256i ub = _mm256_loadu_si256((const __m256i *)(qu + 32 * b + 32));
-        const __m256i vb = _mm256_loadu_si256((const __m256i *)(qv + 32 * b + 32));
-        const float ca = (su[b] * RCP49) * sv[b];
-        const float cb = (su[b + 1] * RCP49) * sv[b + 1];
-        const __m256 fa = _mm256_cvtepi32_ps(block_word_isums(ua, va));
-        const __m256 fb = _mm256_cvtepi32_ps(block_word_isums(ub, vb));
-        acc0 = _mm256_fmadd_ps(_mm256_set1_ps(ca), fa, acc0);
-        acc1 = _mm256_fmadd_ps(_mm256_set1_ps(cb), fb, acc1);
-    }
-    return reduce_tree(acc0, acc1);
+    return g_kernel ? dot_row_maddubs(qu, su, qv, sv, nb) : dot_row_planes(qu, su, qv, sv, nb);
 }
 
 float orcf_v4_dot(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad)

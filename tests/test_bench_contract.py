@@ -39,6 +39,15 @@ def test_mvm_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "GB/s" and cb["gpu_result_matches_cpu"] is True
+    assert cb["ms_min"] <= cb["ms"] <= cb["ms_max"] and cb["runnable_cpus"] >= 1 and cb["threads_used"] == cb["cores"]
+    # the second roofline-bearing object: BASELINE configs[3], normalised to the pipe the kernel runs on
+    g = d["gemm"]
+    assert g["roofline"]["bound"] == "mfma" and g["roofline"]["peak"] == 10000.0 and abs(g["roofline"]["frac"] - g["value"] / 10000.0) < 1e-3
+    assert g["prepared_operands"]["ms"] > 0 and g["int32_unscaled"]["ms"] > 0
+    # HBM-resident vector workloads, each with its own achieved / peak / frac
+    h = d["extras"]["hbm_resident_n2^30"]
+    for k in ("quantize", "quantize_stochastic", "dot_fast", "scale_and_add", "restore"):
+        assert h[k]["peak"] == 8000.0 and 0 < h[k]["frac"] < 1 and abs(h[k]["frac"] - h[k]["achieved"] / 8000.0) < 1e-3
 
 
 @pytest.mark.gpu

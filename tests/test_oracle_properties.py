@@ -146,14 +146,23 @@ def test_stochastic_stream(oracle):
     assert abs(float(np.mean(xr - x))) < 5e-3                 # stochastic rounding is (nearly) unbiased
 
 
+@pytest.mark.parametrize("kernel", ["maddubs", "planes"])
 @pytest.mark.parametrize("n", [128, 1024, 4096 + 128])
-def test_fast_oracle_equals_scalar(oracle, fast_oracle, n):
+def test_fast_oracle_equals_scalar(oracle, fast_oracle, n, kernel):
+    fast_oracle.set_kernel(kernel)
     rng = np.random.default_rng(n)
     x, y = (rng.normal(size=n) * 3).astype(np.float32), ints(rng, n, 10)
     a, b = oracle.v4_quantize(x), oracle.v4_quantize(y)
     fa, fb = fast_oracle.v4_quantize(x), fast_oracle.v4_quantize(y)
     assert np.array_equal(a[0], fa[0]) and np.array_equal(bits(a[1]), bits(fa[1])) and np.array_equal(b[0], fb[0])
     assert bits(oracle.v4_dot(*a, *b)) == bits(fast_oracle.v4_dot(*a, *b))
+    # every nibble pair incl. the extremes (+-7 x +-7): the 16x-scaled bytes of the maddubs kernel must not saturate
+    q = np.array([((a_ & 0xF) << 4) | (b_ & 0xF) for a_ in range(-7, 8) for b_ in range(-7, 8)] * 2, np.uint8)[: 128 * 3 // 2 * 2 // 2 * 2]
+    q = np.resize(q, 64 * 4)
+    s = np.ones(q.size * 2 // 64, np.float32)
+    for other in (q, q[::-1].copy(), np.full_like(q, 0x77), np.full_like(q, 0x99)):
+        assert bits(oracle.v4_dot(q, s, other, s)) == bits(fast_oracle.v4_dot(q, s, other, s))
+    fast_oracle.set_kernel("maddubs")
 
 
 def test_fast_oracle_mvm_equals_scalar(oracle, fast_oracle):

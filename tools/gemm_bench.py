@@ -20,7 +20,16 @@ for G in [int(g) for g in os.environ.get("GB_SIZES", "4096,8192").split(",")]:
         hip.check(lib.clv_fill_random_nibbles(t.ptr, t.nbytes, sd, 0, None))
     for t, sd in ((sA, 3), (sB, 4)):
         hip.check(lib.clv_fill_random_scales(t.ptr, t.nbytes // 4, sd, 0, None))
+    mode = os.environ.get("GB_MODE", "gemm")          # gemm | i32 (exact int32 GEMM, no scales) | prepared (both FP6 images cached) | preparedB
     fn = lambda: hip.check(lib.clm4_gemm(A.ptr, sA.ptr, G, G, B.ptr, sB.ptr, G, Cc.ptr, None))
+    if mode == "i32":
+        fn = lambda: hip.check(lib.clm4_gemm_i32(A.ptr, G, G, B.ptr, G, 0, G // 64, Cc.ptr, None))
+    elif mode.startswith("prepared"):
+        opA, opB = C.c_void_p(), C.c_void_p()
+        if mode == "prepared":
+            hip.check(lib.clm4_gemm_prepare(A.ptr, G, G, C.byref(opA), None))
+        hip.check(lib.clm4_gemm_prepare(B.ptr, G, G, C.byref(opB), None))
+        fn = lambda: hip.check(lib.clm4_gemm_prepared(opA, None if opA else A.ptr, sA.ptr, G, G, opB, None, sB.ptr, G, Cc.ptr, None))
     for _ in range(3):
         fn()
     hip.sync()
@@ -39,4 +48,4 @@ for G in [int(g) for g in os.environ.get("GB_SIZES", "4096,8192").split(",")]:
         ts.append(ms.value / 5)
     ms = sorted(ts)[2]
     chk = float(np.abs(Cc.download(np.float32, 4096)).sum())
-    print(f"kernel={os.environ.get('CLV_GEMM_KERNEL', 'fp6')} G={G} {ms:.4f} ms {2.0 * G ** 3 / ms / 1e9:.1f} TOP/s checksum={chk:.6e}")
+    print(f"mode={mode} kernel={os.environ.get('CLV_GEMM_KERNEL', 'fp6')} G={G} {ms:.4f} ms {2.0 * G ** 3 / ms / 1e9:.1f} TOP/s checksum={chk:.6e}")
