@@ -54,6 +54,10 @@ def mvm_bytes(rows: int, cols: int) -> int:
 # CPU baseline leg (runs in a child process so OpenMP binding env vars take effect)
 # ----------------------------------------------------------------------------------------------------
 def cpu_baseline_child(path: str) -> None:
+    try:
+        runnable = len(os.sched_getaffinity(0))   # cpus this process may run on -- read BEFORE the OpenMP runtime binds the main thread
+    except AttributeError:
+        runnable = os.cpu_count() or 1
     import numpy as np
 
     from oracle.binding import FastOracle          # test/bench infrastructure: the timed CPU port
@@ -64,10 +68,6 @@ def cpu_baseline_child(path: str) -> None:
     F.set_kernel("maddubs")                       # the reference's instruction mix (CloverVector4.h:1136-1180)
     best = None
     cores = os.cpu_count() or 1
-    try:
-        runnable = len(os.sched_getaffinity(0))   # cpus this process may run on
-    except AttributeError:
-        runnable = cores
     out = (np.zeros(rows // 2, np.uint8), np.zeros(rows // 64, np.float32))
     tried = {}
     for threads in sorted({1, min(16, cores), min(64, cores), max(1, cores // 2), cores}):
