@@ -123,119 +123,62 @@ __global__ __launch_bounds__(256) void k_v4_word_isums(const uint32_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// dot, reference order (CloverVector4.h:1095-1192): 16 sequential fp32 fma chains -- chain
-// j = word index mod 16 (accumulator = bit 3, AVX lane = bits 0..2) -- then the fixed add tree of
-// CloverBase.h:149-157.  The chains are sequential by definition (n/128 dependent fmas each), so the
-// floor is one fma latency per block pair on ONE wave.  Everything that is not the chain is moved out:
-//   k_v4_dot_prep   (all CUs)  : per word f = (float)sdot8(u,v), per block c = f32(f32(su/49)*sv), written
-//                                "chain-major": F[g][j][i] = f of word 16(4g+i)+j, C[g][a][i] = c of
-//                                block 2(4g+i)+a  (g = group of 4 block pairs), so a chain lane fetches
-//                                4 steps with one 16-byte read;
-//   k_v4_dot_chain  (one WG)   : 256 threads copy tile t+1 (512 pairs = 36 KiB) HBM->LDS while lanes 0..15
-//                                of wave 0 run the fma chains over tile t out of LDS.
+// dot, reference order (CloverVector4.h:1095-1192): 16 sequential fp32 fma chains -- chain l = 8 a + w
+// (accumulator a = block parity, AVX lane w = word of the block) -- then the fixed add tree of
+// CloverBase.h:149-157.  The chains are sequential by definition (n/128 dependent fmas each), so the floor is
+// one dependent v_fma_f32 (~2.3 ns) per block pair on ONE wave, and the job is to keep everything else out of
+// that wave's instruction issue:
+//   k_v4_dot_prep2  (all CUs) : both fma operands in chain order -- per block of 16 block pairs ("steps") and chain lane l:
+//                               80 bytes = f of the 16 steps (f = (float)sdot8 of the chain's word) + ONE float4 of
+//                               c = f32(f32(su/49)*sv) in quad layout; steps past the end hold zeros (fma(0, 0, acc) = acc);
+//   k_v4_dot_chain2 (one wave): five 16-byte loads per lane bring 16 steps of both operands straight into registers (c is
+//                               shared by the 8 lanes of an accumulator: each lane keeps a quarter of it and the fma reads
+//                               its factor through DPP quad_perm, a broadcast inside the instruction); DOTX_D blocks stay in
+//                               flight in a register ring, refilled in place behind the fmas that read them, with counted
+//                               vmcnt waits.  No LDS, no barrier, no helper waves: round 1 staged the operands through LDS
+//                               and the lone chain wave spent ~13 ns per ds_read_b128 (2 per 4 steps) -- 0.78 ms at
+//                               n = 2^24 against a floor of 0.30.  The loop is one asm statement generated by
+//                               tools/gen_dot_chain.py (layout and register map are documented there).
 // ------------------------------------------------------------------------------------------------
-#define DX_TILE_PAIRS 512
-#define DX_TILE_GROUPS (DX_TILE_PAIRS / 4)
-#define DX_TILE_F4 (DX_TILE_GROUPS * 16)            // float4 per tile of F
-#define DX_TILE_C4 (DX_TILE_GROUPS * 2)             // float4 per tile of C
-#define DX_BUF_F4 (DX_TILE_F4 + DX_TILE_C4)
+#include "dot_chain.inc"
 
-__global__ __launch_bounds__(256) void k_v4_dot_prep(const uint32_t *__restrict__ qu, const float *__restrict__ su,
-                                                     const uint32_t *__restrict__ qv, const float *__restrict__ sv,
-                                                     uint64_t npairs, uint64_t ngroups, f32x4 *__restrict__ F, f32x4 *__restrict__ Cc)
+__global__ __launch_bounds__(256) void k_v4_dot_prep2(const uint32_t *__restrict__ qu, const float *__restrict__ su,
+                                                      const uint32_t *__restrict__ qv, const float *__restrict__ sv,
+                                                      uint64_t npairs, uint64_t nblocks_padded, f32x4 *__restrict__ X)
 {
+    // thread = (block Q of 16 steps, chain lane l, piece 0..4): pieces 0..3 = f of steps 4 piece .. 4 piece + 3, piece 4 = the c quad
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ngroups * 16; t += stride) {
-        const uint64_t g = t >> 4;
-        const int j = (int)(t & 15);
-        float f[4], c[4];
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblocks_padded * 80; t += stride) {
+        const uint64_t Q = t / 80;
+        const int r = (int)(t - Q * 80), l = r / 5, piece = r - 5 * l, a = l >> 3, w = l & 7;
+        float v[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint64_t p = 4 * g + i;
+            const uint64_t p = piece < 4 ? 16 * Q + 4 * piece + i : 16 * Q + 4 * i + (l & 3);
+            v[i] = 0.0f;
             if (p < npairs) {
-                f[i] = (float)sdot8(qu[16 * p + j], qv[16 * p + j], 0);
-                const uint64_t blk = 2 * p + (j & 1);                  // lanes j = 0,1 also produce the c's
-                c[i] = j < 2 ? (su[blk] * CLV_RCP49) * sv[blk] : 0.0f;
-            } else {
-                f[i] = 0.0f;
-                c[i] = 0.0f;
+                const uint64_t blk = 2 * p + a;
+                v[i] = piece < 4 ? (float)sdot8(qu[8 * blk + w], qv[8 * blk + w], 0) : (su[blk] * CLV_RCP49) * sv[blk];
             }
         }
-        F[t] = f32x4{f[0], f[1], f[2], f[3]};
-        if (j < 2) Cc[2 * g + j] = f32x4{c[0], c[1], c[2], c[3]};
+        X[t] = f32x4{v[0], v[1], v[2], v[3]};              // (Q * 16 + l) * 5 + piece = t: 80 bytes per lane, 1280 per block
     }
 }
 
-__global__ __launch_bounds__(256) void k_v4_dot_chain(const f32x4 *__restrict__ F, const f32x4 *__restrict__ Cc,
-                                                      uint64_t npairs, uint64_t ngroups, float *__restrict__ out)
+__global__ __launch_bounds__(64) void k_v4_dot_chain2(const f32x4 *__restrict__ X, uint32_t iterations, float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *lds = reinterpret_cast<f32x4 *>(smem);          // 2 x DX_BUF_F4
-    const int tid = threadIdx.x;
-    const int j = tid & 15;
-    const uint64_t ntiles = (ngroups + DX_TILE_GROUPS - 1) / DX_TILE_GROUPS;
-    constexpr int NF = DX_TILE_F4 / 256;                   // 8 float4 of F per thread per tile
-
-    f32x4 rf[NF], rc;
-    auto fetch = [&](uint64_t tile) {
-        const uint64_t g0 = tile * DX_TILE_GROUPS;
-#pragma unroll
-        // unconditional loads: F and Cc are padded to whole tiles by k_v4_dot_prep (a per-load bounds check makes
-        // hipcc branch around every load and wait for each one separately)
-        for (int k = 0; k < NF; k++) rf[k] = F[g0 * 16 + tid + 256 * k];
-        rc = Cc[g0 * 2 + (tid & (DX_TILE_C4 - 1))];
-    };
-    auto stash = [&](int buf) {
-        f32x4 *b = lds + buf * DX_BUF_F4;
-#pragma unroll
-        for (int k = 0; k < NF; k++) b[tid + 256 * k] = rf[k];
-        if (tid < DX_TILE_C4) b[DX_TILE_F4 + tid] = rc;
-    };
-
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    float acc = 0.0f;
-    for (uint64_t tile = 0; tile < ntiles; tile++) {
-        const int buf = (int)(tile & 1);
-        if (tile + 1 < ntiles) fetch(tile + 1);            // in flight while the chains run
-        if (tid < 16) {
-            const f32x4 *bf = lds + buf * DX_BUF_F4;
-            const f32x4 *bc = bf + DX_TILE_F4;
-            const uint64_t g0 = tile * DX_TILE_GROUPS;
-            const uint64_t gend = (ngroups - g0) < DX_TILE_GROUPS ? (ngroups - g0) : DX_TILE_GROUPS;
-            const uint64_t full = (npairs / 4 > g0) ? ((npairs / 4 - g0) < gend ? (npairs / 4 - g0) : gend) : 0;
-            uint64_t g = 0;
-#pragma unroll 16
-            for (; g < full; g++) {
-                const f32x4 f = bf[g * 16 + j];
-                const f32x4 c = bc[g * 2 + (j >> 3)];
-                acc = __builtin_fmaf(c.x, f.x, acc);
-                acc = __builtin_fmaf(c.y, f.y, acc);
-                acc = __builtin_fmaf(c.z, f.z, acc);
-                acc = __builtin_fmaf(c.w, f.w, acc);
-            }
-            if (g < gend) {                                // the last, partial group of the vector
-                const f32x4 f = bf[g * 16 + j];
-                const f32x4 c = bc[g * 2 + (j >> 3)];
-                const uint64_t rem = npairs - 4 * (g0 + g);
-                acc = __builtin_fmaf(c.x, f.x, acc);
-                if (rem > 1) acc = __builtin_fmaf(c.y, f.y, acc);
-                if (rem > 2) acc = __builtin_fmaf(c.z, f.z, acc);
-            }
-        }
-        if (tile + 1 < ntiles) stash(buf ^ 1);
-        __syncthreads();
-    }
-    if (tid < 64) {
-        // lanes 0..15 hold chain j: accumulator a = j>>3, AVX lane w = j&7
-        const float v = acc + __shfl(acc, (j + 8) & 15);   // acc[0][w] + acc[1][w]          (:1190)
-        const float x = __shfl(v, (j + 4) & 15) + v;       // x[w] = v[w+4] + v[w], w = 0..3  (CloverBase.h:153)
-        const float x2 = __shfl(x, (j + 2) & 15);
-        const float y = x + x2;                            // y0 = x0 + x2 (lane 0), y1 = x1 + x3 (lane 1)
-        const float y1 = __shfl(y, 1);
-        if (tid == 0) *out = y + y1;
-    }
+    const int lane = threadIdx.x, j = lane & 15;
+    const uint32_t voff = 80u * j;                    // lanes 16..63 shadow lanes 0..15 (same addresses, same arithmetic)
+    const uint64_t x = (uint64_t)X;
+    float acc;
+    asm volatile(DOTX_LOOP_ASM : [acc] "=v"(acc) : [x] "s"(x), [voff] "v"(voff), [n] "s"(iterations) : DOTX_LOOP_CLOBBERS);
+    // lanes 0..15 hold chain l: accumulator a = l>>3, AVX lane w = l&7
+    const float v = acc + __shfl(acc, (j + 8) & 15);   // acc[0][w] + acc[1][w]          (:1190)
+    const float xx = __shfl(v, (j + 4) & 15) + v;      // x[w] = v[w+4] + v[w], w = 0..3  (CloverBase.h:153)
+    const float x2 = __shfl(xx, (j + 2) & 15);
+    const float y = xx + x2;                           // y0 = x0 + x2 (lane 0), y1 = x1 + x3 (lane 1)
+    const float y1 = __shfl(y, 1);
+    if (lane == 0) *out = y + y1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,17 +301,18 @@ static inline int dot_fast_grid(uint64_t n_pad)
     return stream_grid(n_pad / 32, DOT_FAST_THREADS, 4);
 }
 
-static inline uint64_t dot_exact_groups(uint64_t n_pad) { return (n_pad / 128 + 3) / 4; }
-// groups rounded up to whole LDS tiles: the chain kernel fetches tiles without bounds checks
-static inline uint64_t dot_exact_groups_padded(uint64_t n_pad)
+static inline uint64_t dot_exact_blocks(uint64_t n_pad) { return (n_pad / 128 + 15) / 16; }        // 16 block pairs each
+// rounded up to whole loop iterations of the chain kernel (DOTX_D blocks each)
+static inline uint64_t dot_exact_blocks_padded(uint64_t n_pad)
 {
-    return (dot_exact_groups(n_pad) + DX_TILE_GROUPS - 1) / DX_TILE_GROUPS * DX_TILE_GROUPS;
+    return (dot_exact_blocks(n_pad) + DOTX_D - 1) / DOTX_D * DOTX_D;
 }
 
 extern "C" uint64_t clv4_dot_workspace_bytes(uint64_t n_pad)
 {
     const uint64_t fast = (uint64_t)clv_cu_count() * 4 * sizeof(float) + 256;
-    const uint64_t exact = dot_exact_groups_padded(n_pad) * (16 + 2) * sizeof(f32x4) + 256;
+    // + DOTX_D blocks: the last iteration's refills read one iteration past the end (never consumed, but the memory must exist)
+    const uint64_t exact = (dot_exact_blocks_padded(n_pad) + DOTX_D) * 1280 + 256;
     return fast > exact ? fast : exact;
 }
 
@@ -385,21 +329,13 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
         if (rc) return rc;
     }
     if (mode == CLV_DOT_EXACT) {
-        const uint64_t npairs = n_pad / 128, ngroups = dot_exact_groups(n_pad), gpad = dot_exact_groups_padded(n_pad);
-        f32x4 *F = (f32x4 *)workspace;
-        f32x4 *Cc = F + gpad * 16;
-        hipLaunchKernelGGL(k_v4_dot_prep, dim3(stream_grid(gpad * 16, 256, 8)), dim3(256), 0, st, (const uint32_t *)qu, su,
-                           (const uint32_t *)qv, sv, npairs, gpad, F, Cc);
+        const uint64_t npairs = n_pad / 128, gpad = dot_exact_blocks_padded(n_pad);
+        CLV_REQUIRE(gpad / DOTX_D <= 0xFFFFFFFFull, "clv4_dot: vector too long");
+        f32x4 *X = (f32x4 *)workspace;
+        hipLaunchKernelGGL(k_v4_dot_prep2, dim3(stream_grid(gpad * 80, 256, 8)), dim3(256), 0, st, (const uint32_t *)qu, su,
+                           (const uint32_t *)qv, sv, npairs, gpad, X);
         CLV_LAUNCH_CHECK();
-        static const size_t lds = 2 * DX_BUF_F4 * sizeof(f32x4);      // 72 KiB: above the 64 KiB default
-        static bool attr_set[64] = {false};
-        int dev = 0;
-        CLV_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            CLV_HIP(hipFuncSetAttribute((const void *)k_v4_dot_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set[dev] = true;
-        }
-        hipLaunchKernelGGL(k_v4_dot_chain, dim3(1), dim3(256), lds, st, (const f32x4 *)F, (const f32x4 *)Cc, npairs, ngroups, out_dev);
+        hipLaunchKernelGGL(k_v4_dot_chain2, dim3(1), dim3(64), 0, st, (const f32x4 *)X, (uint32_t)(gpad / DOTX_D), out_dev);
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
