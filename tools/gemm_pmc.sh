@@ -11,4 +11,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTI
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d /tmp/gemm_pmc/p$i -- python $R/tools/gemm_probe.py > /tmp/gemm_pmc_o$i.txt 2>&1
 done
-python $R/tools/pmc_summary.py /tmp/gemm_pmc gemm
+python $R/tools/pmc_summary.py /tmp/gemm_pmc k_m4_gemm
