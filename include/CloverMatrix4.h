@@ -6,8 +6,11 @@
  * rows/cols padded to multiples of 128; :77-139).  Hot methods call libclover_hip.so:
  *
  *   quantize                         -> clm4_quantize (CloverMatrix4.h:512-766)
- *   mvm / mvm_parallel / mvm_scalar  -> clm4_mvm      (:777-1083, :1681-2006, :311-392 -- all three give
- *                                                      the same result in the reference, bit for bit)
+ *   mvm / mvm_parallel               -> clm4_mvm      (:777-1083, :1681-2006)
+ *   *_scalar                         -> scalar HOST code (clover_scalar.h), the reference's validation partners: quantize_scalar
+ *                                       (:178-264), restore_scalar (:266-301), mvm_scalar (:311-432; for 4-bit vectors: row views +
+ *                                       dot(), as there), transpose_scalar (:435-502); in the reference mvm == mvm_parallel ==
+ *                                       mvm_scalar bit for bit when rounding is disabled, and so here
  *   gemm (new)                       -> clm4_gemm     (the reference has no GEMM; semantics in DESIGN.md)
  *
  * As in the reference, values/scales are not exposed (they are `protected` there, :73-75); the matrix
@@ -16,6 +19,8 @@
  */
 #ifndef CLOVER_MATRIX4_H
 #define CLOVER_MATRIX4_H
+
+#include <cmath>
 
 #include "CloverMatrix32.h"
 #include "CloverVector4.h"
@@ -77,10 +82,37 @@ public:
         clover_hip::check(clm4_quantize(A, rows, cols, reinterpret_cast<int8_t *>(d), reinterpret_cast<float *>(d + value_bytes),
                                         clover_hip::rng_or_null(random), nullptr), "CloverMatrix4::quantize");
     }
-    void quantize_scalar(const CloverMatrix32 &m) { quantize(m); }
+    /* the reference's scalar twin (CloverMatrix4.h:178-264), on the host: tiles column-block outer, maximum over the 64 x 64 tile */
+    void quantize_scalar(const CloverMatrix32 &m)
+    {
+        if (m.getRows() != rows || m.getCols() != cols) {
+            std::cout << "Matrices do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        const float *u = m.host_ro();
+        uint8_t *h = mem.host_rw();
+        int8_t *r = reinterpret_cast<int8_t *>(h);
+        float *sr = reinterpret_cast<float *>(h + value_bytes);
+        const uint64_t hb = cols >> 6, vb = rows >> 6;
+        for (uint64_t bj = 0; bj < hb; bj++)
+            for (uint64_t bi = 0; bi < vb; bi++) {
+                const uint64_t off = (bi << 6) * cols + (bj << 6);
+                float mx = 0.0f;
+                for (uint64_t i = 0; i < 64; i++)
+                    for (uint64_t j = 0; j < 64; j++) { const float a = std::fabs(u[off + i * cols + j]); if (a > mx) mx = a; }
+                if (mx == 0.0f) mx = 1.0f;                         /* the SIMD contract (:598-603); the scalar code divides by zero */
+                sr[bi * hb + bj] = mx;
+                const float k = 7.0f / mx;
+                for (uint64_t i = 0; i < 64; i++)
+                    for (uint64_t j = 0; j < 64; j += 2) {
+                        const uint64_t idx = off + i * cols + j;
+                        r[idx >> 1] = (int8_t)((clover_hip::scalar::quant1(u[idx], k) << 4) | (clover_hip::scalar::quant1(u[idx + 1], k) & 0xF));
+                    }
+            }
+    }
 
-    /* CloverMatrix4.h:266-301 (the reference has only the scalar variant) */
-    void restore_scalar(CloverMatrix32 &other) const
+    /* CloverMatrix4.h:266-301: the reference has only the scalar variant.  restore() is the kernel, restore_scalar() the host loop. */
+    void restore(CloverMatrix32 &other) const
     {
         if (other.getRows() != rows || other.getCols() != cols) {
             std::cout << "Matrices do not have the same size. Exiting ..." << std::endl;
@@ -88,7 +120,16 @@ public:
         }
         clover_hip::check(clm4_restore(dev_values(), dev_scales(), rows, cols, other.device_wo(), nullptr), "CloverMatrix4::restore");
     }
-    void restore(CloverMatrix32 &other) const { restore_scalar(other); }
+    void restore_scalar(CloverMatrix32 &other) const
+    {
+        if (other.getRows() != rows || other.getCols() != cols) {
+            std::cout << "Matrices do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        float *out = other.host_rw();
+        for (uint64_t i = 0; i < rows; i++)
+            for (uint64_t j = 0; j < cols; j++) out[i * cols + j] = get(i, j);
+    }
 
     void mvm(const CloverVector4 &productVector, CloverVector4 &resultVector)
     {
@@ -112,7 +153,29 @@ public:
         if (x.size() != getCols() || t.size_pad() != getRows()) { std::cout << "MVM can not be performed. Exiting ..." << std::endl; exit(1); }
         if (u.size_pad() != getRows()) { std::cout << "Vectors do not have the same size. Exiting ..." << std::endl; exit(1); }
     }
-    void mvm_scalar(const CloverVector4 &productVector, CloverVector4 &resultVector) { mvm(productVector, resultVector); }
+    /* The reference's mvm_scalar (:311-392): every row wrapped in a non-owning CloverVector4 view over the matrix's own memory and
+     * multiplied with dot() (the SIMD order, here the exact-order kernel), then 64 results at a time quantised by scalar code.  An
+     * implementation independent of the mvm kernel: the validation partner of mvm / mvm_parallel. */
+    void mvm_scalar(const CloverVector4 &productVector, CloverVector4 &resultVector)
+    {
+        if (productVector.size() != getCols() || resultVector.size_pad() != getRows()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        int8_t *vals = getData();
+        float *scs = getScales();
+        int8_t *r = resultVector.getData();
+        float *sr = resultVector.getScales();
+        const uint64_t hb = cols >> 6;
+        for (uint64_t bi = 0; bi < (rows >> 6); bi++) {
+            float block[64];
+            for (uint64_t i = 0; i < 64; i++) {
+                CloverVector4 rowVector(cols, vals + (((bi << 6) + i) * cols >> 1), scs + bi * hb);
+                block[i] = rowVector.dot(productVector);
+            }
+            sr[bi] = clover_hip::scalar::quantize_block4(block, r + 32 * bi);
+        }
+    }
 
     /* Not in the reference: t = this * x immediately followed by r = quantize(u + a * t), the pair of steps the IHT / GD
      * loops repeat (01_measure.h:930-931, :932-933).  One launch when rounding is deterministic; with stochastic rounding
@@ -164,7 +227,21 @@ public:
         resultVector.commit();
     }
     void mvm_parallel(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
-    void mvm_scalar(const CloverVector8 &productVector, CloverVector8 &resultVector) { mvm(productVector, resultVector); }
+    /* :402-413: double accumulation of get(i, j) * x.get(j), cast to float, then the 8-bit quantiser (the kernel one, as there) */
+    void mvm_scalar(const CloverVector8 &productVector, CloverVector8 &resultVector)
+    {
+        if (productVector.size() != getCols() || resultVector.size_pad() != getRows()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        CloverVector32 resultVector32(rows);
+        for (uint64_t i = 0; i < rows; i++) {
+            double sum = 0;
+            for (uint64_t j = 0; j < cols; j++) sum += (double)get(i, j) * (double)productVector.get(j);
+            resultVector32.set(i, (float)sum);
+        }
+        resultVector.quantize(resultVector32);
+    }
     /* the same pairing as mvm_scaleAndAdd above, for 8-bit vectors */
     void mvm_scaleAndAdd(const CloverVector8 &x, const CloverVector8 &u, float a, CloverVector8 &t, CloverVector8 &r)
     {
@@ -211,8 +288,19 @@ public:
         resultVector.commit();
     }
     void mvm_parallel(const CloverVector32 &productVector, CloverVector32 &resultVector) { mvm(productVector, resultVector); }
-    /* the reference's scalar variant accumulates in double (:423-432); the SIMD order is used here */
-    void mvm_scalar(const CloverVector32 &productVector, CloverVector32 &resultVector) { mvm(productVector, resultVector); }
+    /* :423-432: double accumulation on the host */
+    void mvm_scalar(const CloverVector32 &productVector, CloverVector32 &resultVector)
+    {
+        if (productVector.size() != getCols() || resultVector.size_pad() != getRows()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        for (uint64_t i = 0; i < rows; i++) {
+            double sum = 0;
+            for (uint64_t j = 0; j < cols; j++) sum += (double)get(i, j) * (double)productVector.get(j);
+            resultVector.set(i, (float)sum);
+        }
+    }
 
     /* other = this^T  (CloverMatrix4.h:1549-1663; _parallel :2508-2640; _scalar :435-502) */
     void transpose(CloverMatrix4 &other) const
@@ -226,8 +314,27 @@ public:
                                          reinterpret_cast<float *>(d + other.value_bytes), nullptr), "CloverMatrix4::transpose");
     }
     void transpose_parallel(CloverMatrix4 &other) const { transpose(other); }
-    void transpose_scalar(CloverMatrix4 &other) const { transpose(other); }
-    void transpose_scalar_faster(CloverMatrix4 &other) const { transpose(other); }      /* CloverMatrix4.h:2649-2799 */
+    /* :435-502, element by element on the host */
+    void transpose_scalar(CloverMatrix4 &other) const
+    {
+        if (other.rows != cols || other.cols != rows) {
+            std::cout << "Matrix can not be transposed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        const uint8_t *h = mem.host_ro();
+        uint8_t *o = other.mem.host_rw();
+        const float *s = reinterpret_cast<const float *>(h + value_bytes);
+        float *so = reinterpret_cast<float *>(o + other.value_bytes);
+        for (uint64_t i = 0; i < rows; i++)
+            for (uint64_t j = 0; j < cols; j++) {
+                const uint64_t src = i * cols + j, dst = j * rows + i;
+                const uint8_t nib = (src & 1) ? (h[src >> 1] & 0xF) : (h[src >> 1] >> 4);
+                o[dst >> 1] = (dst & 1) ? (uint8_t)((o[dst >> 1] & 0xF0) | nib) : (uint8_t)((o[dst >> 1] & 0x0F) | (nib << 4));
+            }
+        for (uint64_t bi = 0; bi < (rows >> 6); bi++)
+            for (uint64_t bj = 0; bj < (cols >> 6); bj++) so[bj * (rows >> 6) + bi] = s[bi * (cols >> 6) + bj];
+    }
+    void transpose_scalar_faster(CloverMatrix4 &other) const { transpose_scalar(other); }      /* CloverMatrix4.h:2649-2799 */
 
     /* C = this * B^T, fp32: this is M x K, B is N x K, C is M x N (build-defined) */
     void gemm(const CloverMatrix4 &B, CloverMatrix32 &C) const

@@ -80,6 +80,9 @@ public:
         return sout.str();
     }
 
+    /* host access for the scalar validation twins (clover_scalar.h) */
+    const float *host_ro() const { return reinterpret_cast<const float *>(mem.host_ro()); }
+    float *host_rw() { return reinterpret_cast<float *>(mem.host_rw()); }
     /* device access for the 4-bit containers */
     const float *device_ro() const { return reinterpret_cast<const float *>(mem.dev_ro()); }
     float *device_wo() { return reinterpret_cast<float *>(mem.dev_wo()); }

@@ -11,7 +11,9 @@
  *   dot                            -> clv4_dot EXACT  (:1095-1192; bit-identical fp32 order)
  *   dot_parallel                   -> clv4_dot FAST   (:1793-1907; the reference's OpenMP reduction order is
  *                                                      unspecified, FAST is deterministic and tolerance-equal)
- *   dot_scalar                     -> host loop       (:555-595; the reference's own validation partner)
+ *   *_scalar                       -> scalar HOST loops (clover_scalar.h): the reference's validation partners of the methods
+ *                                     above (:336-595), kept as an independent implementation so that "kernel == scalar twin" means
+ *                                     something; no hot method calls them
  *
  * Results are bit-identical to the reference when built with -DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1; the
  * default build rounds stochastically from the same XORShift stream (setRandomKeys for determinism).
@@ -24,6 +26,7 @@
 #include <bitset>
 
 #include "CloverVector32.h"
+#include "clover_scalar.h"
 
 class CloverVector4 {
 protected:
@@ -149,15 +152,25 @@ public:
         commit();
     }
     void quantize_parallel(const CloverVector32 &other) { quantize(other); }
-    /* the reference's scalar variant divides by zero on all-zero blocks (:478-479); the SIMD contract is used */
-    void quantize_scalar(const CloverVector32 &other) { quantize(other); }
+    /* the reference's scalar twin (:452-517), on the host: the validation partner of quantize (clover_scalar.h) */
+    void quantize_scalar(const CloverVector32 &other)
+    {
+        if (other.size_pad() != length_pad) {
+            std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        clover_hip::scalar::quantize4(other.host_ro(), length_pad, values_rw(), scales_rw());
+    }
 
     void restore(CloverVector32 &other) const
     {
         clover_hip::check(clv4_restore(dev_values_ro(), dev_scales_ro(), length_pad, other.device_wo(), nullptr), "CloverVector4::restore");
         other.commit();
     }
-    void restore_scalar(CloverVector32 &other) const { restore(other); }
+    void restore_scalar(CloverVector32 &other) const      /* :519-553, on the host */
+    {
+        clover_hip::scalar::restore4(values_ro(), scales_ro(), length_pad, other.host_rw());
+    }
 
     float dot(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_EXACT); }
     float dot_parallel(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
@@ -202,8 +215,23 @@ public:
     }
     void scaleAndAdd_parallel(const CloverVector4 &other, float a) { scaleAndAdd(other, a); }
     void scaleAndAdd_parallel(const CloverVector4 &other, float a, CloverVector4 &result) { scaleAndAdd(other, a, result); }
-    void scaleAndAdd_scalar(const CloverVector4 &other, float a) { scaleAndAdd(other, a); }
-    void scaleAndAdd_scalar(CloverVector4 &other, float a, CloverVector4 &result) { scaleAndAdd(other, a, result); }
+    /* :336-449, on the host */
+    void scaleAndAdd_scalar(const CloverVector4 &other, float a)
+    {
+        same_size(other);
+        const int8_t *v = other.values_ro();
+        const float *sv = other.scales_ro();
+        int8_t *u = values_rw();
+        float *su = scales_rw();
+        clover_hip::scalar::scale_and_add4(u, su, v, sv, a, length_pad, u, su);
+    }
+    void scaleAndAdd_scalar(CloverVector4 &other, float a, CloverVector4 &result)
+    {
+        same_size(other);
+        same_size(result);
+        clover_hip::scalar::scale_and_add4(values_ro(), scales_ro(), other.values_ro(), other.scales_ro(), a, length_pad, result.values_rw(),
+                                           result.scales_rw());
+    }
 
     /* keep the k largest magnitudes, zero the rest (CloverVector4.h:1913-2060) */
     void threshold(uint64_t k)

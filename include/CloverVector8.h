@@ -20,6 +20,7 @@
 #define CLOVER_VECTOR8_H
 
 #include "CloverVector32.h"
+#include "clover_scalar.h"
 
 class CloverVector8 {
 protected:
@@ -119,14 +120,21 @@ public:
         commit();
     }
     void quantize_parallel(const CloverVector32 &other) { quantize(other); }
-    void quantize_scalar(const CloverVector32 &other) { quantize(other); }
+    void quantize_scalar(const CloverVector32 &other)      /* CloverVector8.h:205-253, on the host (clover_scalar.h) */
+    {
+        if (other.size_pad() != length_pad) {
+            std::cout << "Vectors do not have the same size. Exiting ..." << std::endl;
+            exit(1);
+        }
+        clover_hip::scalar::quantize8(other.host_ro(), length_pad, values_rw(), scales_rw());
+    }
 
     void restore(CloverVector32 &other) const
     {
         clover_hip::check(clv8_restore(dev_values_ro(), dev_scales_ro(), length_pad, other.device_wo(), nullptr), "CloverVector8::restore");
         other.commit();
     }
-    void restore_scalar(CloverVector32 &other) const { restore(other); }
+    void restore_scalar(CloverVector32 &other) const { clover_hip::scalar::restore8(values_ro(), scales_ro(), length_pad, other.host_rw()); }
 
     /* this = quantize(this + a * other)   (CloverVector8.h:1063-1072) */
     void scaleAndAdd(const CloverVector8 &other, float a)
@@ -152,8 +160,22 @@ public:
     }
     void scaleAndAdd_parallel(const CloverVector8 &other, float a) { scaleAndAdd(other, a); }
     void scaleAndAdd_parallel(const CloverVector8 &other, float a, CloverVector8 &result) { scaleAndAdd(other, a, result); }
-    void scaleAndAdd_scalar(const CloverVector8 &other, float a) { scaleAndAdd(other, a); }
-    void scaleAndAdd_scalar(const CloverVector8 &other, float a, CloverVector8 &result) { scaleAndAdd(other, a, result); }
+    void scaleAndAdd_scalar(const CloverVector8 &other, float a)      /* CloverVector8.h:311-391, on the host */
+    {
+        same_size(other);
+        const int8_t *v = other.values_ro();
+        const float *sv = other.scales_ro();
+        int8_t *u = values_rw();
+        float *su = scales_rw();
+        clover_hip::scalar::scale_and_add8(u, su, v, sv, a, length_pad, u, su);
+    }
+    void scaleAndAdd_scalar(const CloverVector8 &other, float a, CloverVector8 &result)
+    {
+        same_size(other);
+        same_size(result);
+        clover_hip::scalar::scale_and_add8(values_ro(), scales_ro(), other.values_ro(), other.scales_ro(), a, length_pad, result.values_rw(),
+                                           result.scales_rw());
+    }
 
     /* keep the k largest magnitudes, zero the rest (CloverVector8.h:1680-1740) */
     void threshold(uint64_t k)

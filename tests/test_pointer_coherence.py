@@ -55,3 +55,22 @@ def test_kept_pointers_and_views_behave_like_the_reference(tmp_path):
     us = float(p.stdout.split("c1_header_dot_us=")[1].split()[0])
     print(f"C1 (n=128) dot through the C++ headers: {us:.1f} us per call")
     assert us < 200.0
+
+
+def _build_validate(tmp_path):
+    exe = tmp_path / "validate_relations"
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}",
+                    str(CPP / "validate_relations.cpp"), "-o", str(exe), *_link_flags()], check=True)
+    return exe
+
+
+def test_validation_relations_client_builds(tmp_path):
+    p = subprocess.run([str(_build_validate(tmp_path))], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and ("no_device" in p.stdout or "validate ok" in p.stdout), (p.returncode, p.stdout[-2000:], p.stderr)
+
+
+@pytest.mark.gpu
+def test_device_methods_against_their_scalar_twins_like_the_reference_harness(tmp_path):
+    """test/validate/02_vector.cpp + 03_matrix.cpp: kernel vs `_scalar` host twin (include/clover_scalar.h), exact where the reference is exact"""
+    p = subprocess.run([str(_build_validate(tmp_path))], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "validate ok" in p.stdout, (p.returncode, p.stdout[-3000:], p.stderr[-1000:])
