@@ -104,13 +104,25 @@ __device__ __forceinline__ uint32_t pack8(const int q[8])
     return w;
 }
 
+// 8 quantised integers in [-7,7] -> one word: byte i = (q[2i] << 4) | (q[2i+1] & 0xF), the bytes gathered with v_perm_b32
+// (11 VALU instead of 16).  The upper 24 bits of the per-byte intermediates hold sign-extension garbage, which v_perm drops.
+__device__ __forceinline__ uint32_t pack8_perm(const int q[8])
+{
+    uint32_t b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) b[i] = ((uint32_t)q[2 * i] << 4) | ((uint32_t)q[2 * i + 1] & 0xFu);
+    const uint32_t lo = __builtin_amdgcn_perm(b[1], b[0], 0x0C0C0400u);      // [0, 0, b1.byte0, b0.byte0]
+    const uint32_t hi = __builtin_amdgcn_perm(b[3], b[2], 0x04000C0Cu);      // [b3.byte0, b2.byte0, 0, 0]
+    return lo | hi;
+}
+
 // quantise + pack 8 consecutive elements (one output dword); noise == nullptr <=> rounding disabled
 __device__ __forceinline__ uint32_t quant_pack8(const float v[8], float k, const float *noise)
 {
     int q[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) q[e] = noise ? quant1_st(v[e], k, noise[e]) : quant1_det(v[e], k);
-    return k < __builtin_inff() ? pack8(q) : 0u;
+    return k < __builtin_inff() ? pack8_perm(q) : 0u;
 }
 
 // maximum over the 16 lanes of a DPP row (rotations inside the row), result in every lane
@@ -151,6 +163,41 @@ __device__ __forceinline__ void quad_transpose4(uint32_t &v0, uint32_t &v1, uint
         const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0x4E, 0xF, 0xF, false);
         v0 = b ? r0 : v0; v1 = b ? r1 : v1; v2 = b ? v2 : r0; v3 = b ? v3 : r1;
     }
+}
+
+// ---- cheaper nibble <-> float conversions for the VALU-bound kernels ------------------------------------------------------
+// The 8 nibbles of a word as floats, SIXTEEN TIMES their value: f[e] = 16 * q_e (exact).  `w & 0xF0F0F0F0` leaves the even
+// elements as signed bytes 16 q, `(w << 4) & 0xF0F0F0F0` the odd ones, and v_cvt_f32_i32 with an SDWA byte select + sign
+// extension converts a byte in ONE instruction: 11 VALU per word instead of 16 (v_bfe_i32 + v_cvt_f32_i32 per nibble).  The
+// caller folds the 1/16 into its scale (exact: a power of two) -- see scaled_by_16th().  hipcc does not form these SDWA
+// conversions itself (it splits them into v_and_b32_sdwa + v_cvt), hence the asm; it is not volatile, hipcc may schedule it.
+#define CLV_SBYTE_TO_F32(K)                                                                                                     \
+    __device__ __forceinline__ float sbyte##K##_to_f32(uint32_t w)                                                              \
+    {                                                                                                                           \
+        float f;                                                                                                                \
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #K : "=v"(f) : "v"(w));     \
+        return f;                                                                                                               \
+    }
+CLV_SBYTE_TO_F32(0)
+CLV_SBYTE_TO_F32(1)
+CLV_SBYTE_TO_F32(2)
+CLV_SBYTE_TO_F32(3)
+#undef CLV_SBYTE_TO_F32
+
+__device__ __forceinline__ void unpack8_x16(uint32_t w, float f[8])
+{
+    const uint32_t even = w & 0xF0F0F0F0u, odd = (w << 4) & 0xF0F0F0F0u;
+    f[0] = sbyte0_to_f32(even); f[1] = sbyte0_to_f32(odd);
+    f[2] = sbyte1_to_f32(even); f[3] = sbyte1_to_f32(odd);
+    f[4] = sbyte2_to_f32(even); f[5] = sbyte2_to_f32(odd);
+    f[6] = sbyte3_to_f32(even); f[7] = sbyte3_to_f32(odd);
+}
+
+// s / 16 is exact unless it falls into the denormals: true when (16 q) * (s / 16) rounds exactly like q * s
+__device__ __forceinline__ bool sixteenth_is_exact(float s)
+{
+    const float a = __builtin_fabsf(s);
+    return a >= 0x1p-120f || a == 0.0f;
 }
 
 // signed nibble e of word w

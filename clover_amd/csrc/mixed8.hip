@@ -49,17 +49,17 @@ __global__ __launch_bounds__(256) void k_v8_quantize_st(const f32x4 *__restrict_
     __shared__ uint64_t base[4];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    SegRows<S> segs;
-    segs.load(T.seg_rows, wave * S);
+    SegRows<Sh::NSEG> segs;
+    segs.load(Sh::seg_table(T), wave * Sh::NSEG);
     rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
     uint64_t *raw = raw_all[wave];
-    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (Sh::SEGLEN * Sh::NSEG);
     const int seg = lane >> 2, k = lane & 3;
     uint64_t a = segs.starts(base);
     const int rho = lane & 7;
 
     for (int r = 0; r < Sh::ROUNDS; r++) {
-        if (lane < 4 * S) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+        if (lane < 4 * Sh::NSEG) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
         f32x4 lo[Sh::STEPS], hi[Sh::STEPS];
 #pragma unroll
@@ -203,16 +203,16 @@ __global__ __launch_bounds__(256) void k_v8_scale_and_add_st(const u32x4 *qu, co
     __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][Sh::NBR * 2 * 4];
     __shared__ uint64_t base[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    SegRows<S> segs;
-    segs.load(T.seg_rows, wave * S);
+    SegRows<Sh::NSEG> segs;
+    segs.load(Sh::seg_table(T), wave * Sh::NSEG);
     rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
     uint64_t *raw = raw_all[wave];
-    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (Sh::SEGLEN * Sh::NSEG);
     const int seg = lane >> 2, k = lane & 3, c = lane & 3;
     uint64_t st = segs.starts(base);
     constexpr int STEPS = Sh::NBR / 16 > 0 ? Sh::NBR / 16 : 1;           // 16 blocks (64 lanes x 16 elements) per step
     for (int rr = 0; rr < Sh::ROUNDS; rr++) {
-        if (lane < 4 * S) st = gen_blocks(st, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+        if (lane < 4 * Sh::NSEG) st = gen_blocks(st, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
         u32x4 wu[STEPS], wv[STEPS];
         float fu[STEPS], fv[STEPS];
@@ -478,10 +478,11 @@ extern "C" int clv8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s
 #define Q8_LAUNCH(S)                                                                                                           \
     hipLaunchKernelGGL(k_v8_quantize_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const f32x4 *)x, \
                        (u32x2 *)q, s, nb, rng_state_dev, seq, T)
-    switch (clv_st_segments(nb)) {
+    switch (clv_st_segments(nb, false)) {
     case 1: Q8_LAUNCH(1); break;
     case 4: Q8_LAUNCH(4); break;
-    default: Q8_LAUNCH(16); break;
+    case 16: Q8_LAUNCH(16); break;
+    default: Q8_LAUNCH(64); break;
     }
 #undef Q8_LAUNCH
     CLV_LAUNCH_CHECK();
@@ -532,10 +533,11 @@ extern "C" int clv8_scale_and_add(const int8_t *qu, const float *su, const int8_
 #define SAA8_LAUNCH(S)                                                                                                               \
     hipLaunchKernelGGL(k_v8_scale_and_add_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const u32x4 *)qu, su, \
                        (const u32x4 *)qv, sv, a, (u32x4 *)r, sr, nb, rng_state_dev, seq, T)
-    switch (clv_st_segments(nb)) {
+    switch (clv_st_segments(nb, true)) {
     case 1: SAA8_LAUNCH(1); break;
     case 4: SAA8_LAUNCH(4); break;
-    default: SAA8_LAUNCH(16); break;
+    case 16: SAA8_LAUNCH(16); break;
+    default: SAA8_LAUNCH(64); break;
     }
 #undef SAA8_LAUNCH
     CLV_LAUNCH_CHECK();

@@ -9,12 +9,24 @@
 //     val = fma((float)qv, f32(f32(sv*a)/7), (float)qu * f32(su/7));  lane = 4 dwords (half a block) of u and of v.
 //     algorithmic bytes: 3 * (1/2 + 1/16) = 1.6875 per element.
 // =================================================================================================
+// su7 = f32(su / 7), sv7 = f32(f32(sv * a) / 7).  Fast form: the nibbles come as 16 q (unpack8_x16) and the scales as s / 16 --
+// bit-identical as long as s / 16 is exact (sixteenth_is_exact); blocks whose scale sits at the bottom of the fp32 range take the
+// plain form.
 __device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, float sv7, float v[8])
 {
+    const float su16 = su7 * 0.0625f, sv16 = sv7 * 0.0625f;
+    float fu[8], fv[8];
+    unpack8_x16(wu, fu);
+    unpack8_x16(wv, fv);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const float du = (float)unpack1(wu, e) * su7;
-        v[e] = __builtin_fmaf((float)unpack1(wv, e), sv7, du);
+    for (int e = 0; e < 8; e++) v[e] = __builtin_fmaf(fv[e], sv16, fu[e] * su16);
+    // a WAVE-uniform branch around the plain form: hipcc would otherwise if-convert a per-lane one and run both forms everywhere
+    if (!__all(sixteenth_is_exact(su7) && sixteenth_is_exact(sv7))) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float du = (float)unpack1(wu, e) * su7;
+            v[e] = __builtin_fmaf((float)unpack1(wv, e), sv7, du);
+        }
     }
 }
 
@@ -65,15 +77,15 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
     __shared__ __attribute__((aligned(16))) uint64_t raw_all[4][Sh::NBR * 2 * 4];
     __shared__ uint64_t base[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    SegRows<S> segs;
-    segs.load(T.seg_rows, wave * S);
+    SegRows<Sh::NSEG> segs;
+    segs.load(Sh::seg_table(T), wave * Sh::NSEG);
     rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
     uint64_t *raw = raw_all[wave];
-    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (Sh::SEGLEN * Sh::NSEG);
     const int seg = lane >> 2, k = lane & 3, rho = lane & 7;
     uint64_t st = segs.starts(base);                          // workgroup base, then this segment's T^(16 e)
     for (int rr = 0; rr < Sh::ROUNDS; rr++) {
-        if (lane < 4 * S) st = gen_blocks(st, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+        if (lane < 4 * Sh::NSEG) st = gen_blocks(st, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
         if constexpr (S == 1) {
             // small vectors: lane = one dword, 8 blocks per wave
@@ -202,10 +214,11 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
 #define SAA_LAUNCH(S)                                                                                                                  \
     hipLaunchKernelGGL(k_v4_scale_and_add_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const uint32_t *)qu, \
                        su, (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, rng_state_dev, seq, T)
-    switch (clv_st_segments(nb)) {
+    switch (clv_st_segments(nb, true)) {
     case 1: SAA_LAUNCH(1); break;
     case 4: SAA_LAUNCH(4); break;
-    default: SAA_LAUNCH(16); break;
+    case 16: SAA_LAUNCH(16); break;
+    default: SAA_LAUNCH(64); break;
     }
 #undef SAA_LAUNCH
     CLV_LAUNCH_CHECK();

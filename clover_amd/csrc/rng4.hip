@@ -40,7 +40,7 @@ int clv_rng_tables(RngTables *t)
     std::lock_guard<std::mutex> lock(g_pow_mutex);
     if (!g_pow_dev[dev]) {
         // column form first (column i = image of bit i): P[k] = T^(2^k), then M_e = T^(16 e) = (T^16)^e
-        std::vector<uint64_t> P((size_t)(RNG_POW_LEVELS + RNG_SEG_MATS) * 64);
+        std::vector<uint64_t> P((size_t)(RNG_POW_LEVELS + 2 * RNG_SEG_MATS) * 64);
         for (int i = 0; i < 64; i++) P[i] = xs_T(1ull << i);
         for (int k = 1; k < RNG_POW_LEVELS; k++)
             for (int i = 0; i < 64; i++) P[64 * k + i] = gf2_matvec(&P[64 * (k - 1)], P[64 * (k - 1) + i]);
@@ -48,9 +48,14 @@ int clv_rng_tables(RngTables *t)
         for (int i = 0; i < 64; i++) M[i] = 1ull << i;
         for (int e = 1; e < RNG_SEG_MATS; e++)
             for (int i = 0; i < 64; i++) M[64 * e + i] = gf2_matvec(&P[64 * 4], M[64 * (e - 1) + i]);
+        // ... and ML_e = T^(64 e) = (T^64)^e for the 32-block segments of the large-vector shape
+        uint64_t *ML = &P[(size_t)(RNG_POW_LEVELS + RNG_SEG_MATS) * 64];
+        for (int i = 0; i < 64; i++) ML[i] = 1ull << i;
+        for (int e = 1; e < RNG_SEG_MATS; e++)
+            for (int i = 0; i < 64; i++) ML[64 * e + i] = gf2_matvec(&P[64 * 6], ML[64 * (e - 1) + i]);
         // the device wants rows
         std::vector<uint64_t> R(P.size());
-        for (int m = 0; m < RNG_POW_LEVELS + RNG_SEG_MATS; m++) gf2_transpose(&P[64 * m], &R[64 * m]);
+        for (int m = 0; m < RNG_POW_LEVELS + 2 * RNG_SEG_MATS; m++) gf2_transpose(&P[64 * m], &R[64 * m]);
         uint64_t *d = nullptr;
         CLV_HIP(hipMalloc(&d, R.size() * sizeof(uint64_t)));
         CLV_HIP(hipMemcpy(d, R.data(), R.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -58,6 +63,7 @@ int clv_rng_tables(RngTables *t)
     }
     t->pow_rows = g_pow_dev[dev];
     t->seg_rows = g_pow_dev[dev] + (size_t)RNG_POW_LEVELS * 64;
+    t->seg_rows_long = g_pow_dev[dev] + (size_t)(RNG_POW_LEVELS + RNG_SEG_MATS) * 64;
     return CLV_OK;
 }
 
@@ -76,18 +82,18 @@ __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict_
     __shared__ uint64_t base[4];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    SegRows<S> segs;
-    segs.load(T.seg_rows, wave * S);
+    SegRows<Sh::NSEG> segs;
+    segs.load(Sh::seg_table(T), wave * Sh::NSEG);
     rng_workgroup_begin(state, seq, T.pow_rows, blockIdx.x, Sh::SHIFT, 2 * nblocks, base);
     uint64_t *raw = raw_all[wave];
-    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (8 * S);
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * 4 + wave) * (Sh::SEGLEN * Sh::NSEG);
     const int seg = lane >> 2, k = lane & 3;
     // start of this lane's 8-block segment = T^(16 * e) applied to the workgroup's base state
     uint64_t a = segs.starts(base);
     const int rho = lane & 7;
 
     for (int r = 0; r < Sh::ROUNDS; r++) {
-        if (lane < 4 * S) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+        if (lane < 4 * Sh::NSEG) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
         f32x4 lo[Sh::STEPS], hi[Sh::STEPS];
 #pragma unroll
@@ -262,15 +268,19 @@ static int g_st_forced = [] { const char *e = getenv("CLV_ST_SEGMENTS"); return 
 
 extern "C" int clvx_set_st_segments(int s)
 {
-    CLV_REQUIRE(s == 0 || s == 1 || s == 4 || s == 16, "clvx_set_st_segments: %d is not one of 0, 1, 4, 16", s);
+    CLV_REQUIRE(s == 0 || s == 1 || s == 4 || s == 16 || s == 64, "clvx_set_st_segments: %d is not one of 0, 1, 4, 16, 64", s);
     g_st_forced = s;
     return CLV_OK;
 }
 
-int clv_st_segments(uint64_t nblocks)
+// long_ok: the 16 x 32-block shape pays only where the kernel is VALU-bound (scaleAndAdd: 0.57 -> 0.50 ms at n = 2^30); the
+// quantize kernels stream 8x the bytes per element and lose 15 % with it (more rounds, each with its barrier)
+int clv_st_segments(uint64_t nblocks, bool long_ok)
 {
-    if (g_st_forced == 1 || g_st_forced == 4 || g_st_forced == 16) return g_st_forced;
-    return nblocks <= 8192 ? 1 : nblocks <= (1u << 18) ? 4 : 16;
+    static const int env_forced = [] { const char *e = getenv("CLV_ST_SEGMENTS"); return e ? atoi(e) : 0; }();      // A/B runs
+    if (env_forced == 1 || env_forced == 4 || env_forced == 16 || env_forced == 64) return env_forced;
+    if (g_st_forced == 1 || g_st_forced == 4 || g_st_forced == 16 || g_st_forced == 64) return g_st_forced;
+    return nblocks <= 8192 ? 1 : nblocks <= (1u << 18) ? 4 : (nblocks <= (1u << 21) || !long_ok) ? 16 : 64;
 }
 
 int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng, hipStream_t st)
@@ -283,10 +293,11 @@ int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s
 #define QST_LAUNCH(S)                                                                                                          \
     hipLaunchKernelGGL(k_v4_quantize_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const f32x4 *)x, \
                        (uint32_t *)q, s, nb, rng, seq, T)
-    switch (clv_st_segments(nb)) {
+    switch (clv_st_segments(nb, false)) {
     case 1: QST_LAUNCH(1); break;
     case 4: QST_LAUNCH(4); break;
-    default: QST_LAUNCH(16); break;
+    case 16: QST_LAUNCH(16); break;
+    default: QST_LAUNCH(64); break;
     }
 #undef QST_LAUNCH
     CLV_LAUNCH_CHECK();

@@ -19,6 +19,7 @@
 
 #define RNG_POW_LEVELS 56
 #define RNG_SEG_MATS 64          // T^(16*e), e = 0..63: start of 8-block segment e relative to a workgroup base
+                                 // (and, in a second table, T^(64*e): 32-block segments of the large-vector shape)
 #define RNG_SLOT_WORDS 16        // u64 stride between the two state slots
 #define RNG_STAMP_WORD 8         // u64 index of the slot's sequence stamp
 
@@ -27,6 +28,7 @@
 struct RngTables {
     const uint64_t *pow_rows;
     const uint64_t *seg_rows;
+    const uint64_t *seg_rows_long;      // seg_rows_long[64][64] = T^(64 e)
 };
 int clv_rng_tables(RngTables *t);      // rng4.hip; builds the tables on first use per device
 uint64_t clv_rng_next_seq();           // runtime.hip; process-wide launch sequence number (>= 1)
@@ -93,10 +95,16 @@ __device__ __forceinline__ int rng_read_slot(const uint64_t *state, uint64_t seq
     return (s1 < seq && (s0 >= seq || s1 > s0)) ? 1 : 0;
 }
 
-// noise lane: byte `sh` of W, as the reference builds it (mask, shift left, int->float, * 2^-31)
+// noise lane: byte `sh` of W, as the reference builds it (mask 0x7F7F7F7F, shift left by 8 sh, int -> float, * 2^-31;
+// CloverVector4.h:690-734).  Computed without the shift: (V << 8 sh) as an int32 is (V & (0x7F7F7F7F >> 8 sh)) * 2^(8 sh) -- the
+// bytes shifted out are dropped, bit 31 is a cleared bit 7 -- and int -> float rounding commutes with a power of two, so
+//     noise = (float)(int)(W & (0x7F7F7F7F >> 8 sh)) * 2^(8 sh - 31)
+// bit for bit: three VALU (mask and factor are compile-time or per-lane constants) instead of four.
 __device__ __forceinline__ float noise_of(uint32_t W, int sh)
 {
-    return (float)(int)((W & 0x7F7F7F7Fu) << (8 * sh)) * (1.0f / 2147483648.0f);
+    const uint32_t mask = 0x7F7F7F7Fu >> (8 * sh);
+    const float scale = __uint_as_float((uint32_t)(96 + 8 * sh) << 23);       // 2^(8 sh - 31)
+    return (float)(int)(W & mask) * scale;
 }
 
 // generate the two draws of `nblk` consecutive blocks for generator lane k and store the raw 64-bit outputs
@@ -187,17 +195,24 @@ struct SegRows {
     }
 };
 
-// shape of the vector stochastic kernels (quantize, scaleAndAdd): wave = S segments of 8 blocks
+// shape of the vector stochastic kernels (quantize, scaleAndAdd): a wave = NSEG segments of SEGLEN consecutive blocks, each walked
+// by 4 generator lanes.  S = 1, 4, 16: S segments of 8 blocks (small vectors want many short waves: a wave walks its blocks
+// serially).  S = 64: 16 segments of 32 blocks -- the per-wave jump-ahead (64 whole-wave GF(2) products, ~450 VALU) is then
+// amortised over 512 blocks instead of 128: it was 16 % of the instructions of the VALU-bound scaleAndAdd.
 template <int S>
 struct StShape {
-    static constexpr int ROUNDS = S == 16 ? 2 : 1;
-    static constexpr int BPR = 8 / ROUNDS;              // blocks per segment per round
-    static constexpr int NBR = S * BPR;                 // blocks per wave per round (<= 64)
+    static constexpr bool LONG = S == 64;
+    static constexpr int NSEG = LONG ? 16 : S;
+    static constexpr int SEGLEN = LONG ? 32 : 8;
+    static constexpr int BPR = NSEG == 16 ? 4 : 8;      // blocks per segment per round
+    static constexpr int ROUNDS = SEGLEN / BPR;
+    static constexpr int NBR = NSEG * BPR;              // blocks per wave per round (<= 64)
     static constexpr int STEPS = NBR / 8;               // 8 blocks (64 lanes x 8 elements) per step
-    static constexpr int SHIFT = 6 + (S == 16 ? 4 : S == 4 ? 2 : 0);     // log2(draws per workgroup = 4 waves x 16 S)
+    static constexpr int SHIFT = LONG ? 12 : 6 + (S == 16 ? 4 : S == 4 ? 2 : 0);     // log2(draws per workgroup = 4 waves x NSEG x SEGLEN x 2)
     // global block of (round r, local block bl): segment bl / BPR, block BPR r + bl % BPR inside it
-    __device__ static __forceinline__ uint64_t block(uint64_t blk0, int r, int bl) { return blk0 + (uint64_t)(bl / BPR) * 8 + BPR * r + (bl % BPR); }
+    __device__ static __forceinline__ uint64_t block(uint64_t blk0, int r, int bl) { return blk0 + (uint64_t)(bl / BPR) * SEGLEN + BPR * r + (bl % BPR); }
+    __device__ static __forceinline__ const uint64_t *seg_table(const RngTables &T) { return LONG ? T.seg_rows_long : T.seg_rows; }
 };
 
-int clv_st_segments(uint64_t nblocks);     // rng4.hip: S by size
+int clv_st_segments(uint64_t nblocks, bool long_ok);     // rng4.hip: S by size (long_ok: may pick the 16 x 32-block shape)
 #endif

@@ -323,7 +323,7 @@ def test_stochastic_vector_quantize_same_stream(hip, oracle, n):
     assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
 
 
-@pytest.mark.parametrize("segments", [1, 4, 16])
+@pytest.mark.parametrize("segments", [1, 4, 16, 64])
 def test_stochastic_vector_ops_every_kernel_shape(hip, oracle, segments):
     """The size-picked kernel shape (segments per wave) must not change a bit: force each one on sizes that span several
     workgroups of that shape (32 * segments blocks each) with a ragged tail, for quantize and scaleAndAdd, two calls each."""

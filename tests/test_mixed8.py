@@ -85,7 +85,7 @@ def test_gpu_v8_quantize_restore_exact(hip, oracle, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("segments", [0, 1, 4, 16])
+@pytest.mark.parametrize("segments", [0, 1, 4, 16, 64])
 def test_gpu_v8_quantize_stochastic_same_stream(hip, oracle, segments):
     n = 64 * (32 * max(segments, 1) * 5 + 7 * max(segments, 1) + 3)
     n += (-n) % 128
@@ -206,7 +206,7 @@ def test_gpu_v8_scale_and_add_exact(hip, oracle, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("segments", [1, 4, 16])
+@pytest.mark.parametrize("segments", [1, 4, 16, 64])
 def test_gpu_v8_scale_and_add_stochastic_every_kernel_shape(hip, oracle, segments):
     n = 64 * (32 * segments * 5 + 7 * segments + 3)
     n += (-n) % 128
