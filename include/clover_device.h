@@ -82,10 +82,9 @@ inline Tracker &tracker()
     return t;
 }
 inline void fault_handler(int sig, siginfo_t *info, void *uctx);
-inline void install_handler()
+inline bool install_handler_once()
 {
     Tracker &t = tracker();
-    if (t.installed) return;
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
     sa.sa_sigaction = fault_handler;
@@ -93,6 +92,12 @@ inline void install_handler()
     sigemptyset(&sa.sa_mask);
     sigaction(SIGSEGV, &sa, &t.previous);
     t.installed = true;
+    return true;
+}
+inline void install_handler()
+{
+    static const bool once = install_handler_once();      /* C++11: initialised exactly once, also under concurrent first use */
+    (void)once;
 }
 
 /* Read (and for writes: rewrite) one byte at both ends of a host range on THIS thread before handing the pointer to the
