@@ -53,14 +53,18 @@ __device__ __forceinline__ uint32_t fp6_codes24(uint32_t t)
 // as [K-block][row][48 B], and each K-block's 64 x 48 = 3 KiB leave as one contiguous run.
 #define F6_ROWS 64
 #define F6_KB 8
+// tile_rows: 128 (k_m4_gemm_fp6*) or 256 (k_m4_gemm_fp6_t256); rows_a / rows_b: the real row counts -- the grid covers the images
+// padded to whole tiles, rows past the end are written as zeros (they are staged and multiplied, never stored).
 __global__ __launch_bounds__(256) void k_m4_to_fp6(const u32x4 *__restrict__ qa, uint8_t *__restrict__ wa, uint32_t row_groups_a,
-                                                   const u32x4 *__restrict__ qb, uint8_t *__restrict__ wb, uint64_t kbn)
+                                                   const u32x4 *__restrict__ qb, uint8_t *__restrict__ wb, uint64_t kbn, uint32_t tile_rows,
+                                                   uint64_t rows_a, uint64_t rows_b)
 {
     // both operands in one launch: blockIdx.y walks the 64-row groups of A, then those of B
     const bool second = blockIdx.y >= row_groups_a;
     const u32x4 *__restrict__ q = second ? qb : qa;
     uint8_t *__restrict__ w = second ? wb : wa;
     const uint32_t by = second ? blockIdx.y - row_groups_a : blockIdx.y;
+    const uint64_t rows_real = second ? rows_b : rows_a;
     __shared__ __attribute__((aligned(16))) uint8_t img[F6_KB * F6_ROWS * 48];
     const uint64_t row0 = (uint64_t)by * F6_ROWS, kb0 = (uint64_t)blockIdx.x * F6_KB;
     const int tid = threadIdx.x;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void k_m4_to_fp6(const u32x4 *__restrict__ qa,
         const int r = e >> 4, hh = e & 15, kb = hh >> 1, h = hh & 1;
         const uint64_t row = row0 + r;
         u32x4 p = {0u, 0u, 0u, 0u};
-        if (kb0 + kb < kbn) p = q[(row * kbn + kb0 + kb) * 2 + h];      // kbn is even, not a multiple of 8
+        if (kb0 + kb < kbn && row < rows_real) p = q[(row * kbn + kb0 + kb) * 2 + h];      // kbn is even, not a multiple of 8
         uint32_t x[8];
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -84,13 +88,13 @@ __global__ __launch_bounds__(256) void k_m4_to_fp6(const u32x4 *__restrict__ qa,
     }
     __syncthreads();
     // K-block kb of rows row0 .. row0 + 63: sub-image (tile, pair, j), rows r0 .. r0 + 63 of it
-    const uint64_t tile = row0 / G6_TILE, r0 = row0 % G6_TILE;
+    const uint64_t tile = row0 / tile_rows, r0 = row0 % tile_rows;
 #pragma unroll
     for (int it = 0; it < F6_KB * F6_ROWS * 48 / 16 / 256; it++) {
         const int e = tid + 256 * it;                         // 16-byte piece of the LDS image
         const int kb = e / (F6_ROWS * 3), off = e - kb * (F6_ROWS * 3);
         const uint64_t sub = (tile * (kbn / 2) + (kb0 + kb) / 2) * 2 + ((kb0 + kb) & 1);
-        if (kb0 + kb < kbn) *reinterpret_cast<u32x4 *>(w + (sub * G6_TILE + r0) * 48 + 16 * (uint64_t)off) = *reinterpret_cast<const u32x4 *>(img + 16 * e);
+        if (kb0 + kb < kbn) *reinterpret_cast<u32x4 *>(w + (sub * tile_rows + r0) * 48 + 16 * (uint64_t)off) = *reinterpret_cast<const u32x4 *>(img + 16 * e);
     }
 }
 
@@ -320,22 +324,101 @@ __global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6_asm(const uint8_t *__res
 #undef G6_RUN
 }
 
+// ---- pass 2, 256 x 256 tile, persistent ----------------------------------------------------------------------------
+// 16 waves (4 x 4 wave tiles of 64 x 64), ONE workgroup per CU, 144 KiB of LDS (three 48 KiB stage buffers), 128 VGPRs per wave.
+// Half the LDS-DMA requests and L2 bytes per MFMA of the 128 x 128 tile (see tools/gen_gemm6_loop256.py for the schedule).
+// A workgroup walks tiles id = blockIdx.x, + gridDim.x, ...; the asm statement is one tile: prologue, main loop, asynchronous
+// store of C.  Operand images are those of k_m4_to_fp6 with tile_rows = 256, padded with zero rows to whole tiles.
+#include "gemm6_loop256.inc"
+#define G6T_TILE 256
+#define G6T_LDS_BYTES (3 * 4 * G6T_TILE * 48)       // three stage buffers of 48 KiB
+
+template <bool I32>
+__global__ __launch_bounds__(1024) void k_m4_gemm_fp6_t256(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
+                                                             const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t M, uint64_t N,
+                                                             uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n, uint32_t stage0,
+                                                             uint32_t nstages)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..15
+    const int wr = wave >> 2, wc = wave & 3;
+    constexpr int SUB = G6T_TILE * 48;
+    const uint64_t kbn = K / 64, image_stages = kbn / 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint32_t cstride = (uint32_t)(N * sizeof(float));
+    // the wave's three of the 48 KiB-pieces of a stage image [A j0 | A j1 | B j0 | B j1]: pieces wave, 16 + wave, 32 + wave
+    const uint32_t l0 = 1024 * wave;
+    const uint32_t l1 = wave < 8 ? 1024 * (16 + wave) : 2 * SUB + 1024 * (wave - 8);
+    const uint32_t l2 = 2 * SUB + 1024 * (8 + wave);
+    const int frow = lane & 31, h = lane >> 5;
+    const int tail = 32 + 8 * (h ^ ((lane >> 4) & 1));
+    uint32_t a16 = lds0 + (wr * 64 + frow) * 48 + 16 * h;
+    uint32_t a8 = lds0 + (wr * 64 + frow) * 48 + tail;
+    uint32_t b16 = lds0 + 2 * SUB + (wc * 64 + frow) * 48 + 16 * h;
+    uint32_t b8 = lds0 + 2 * SUB + (wc * 64 + frow) * 48 + tail;
+    const uint32_t voff = 16 * lane;
+    const uint32_t ntiles = tiles_m * tiles_n;
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // column-major inside bands of 8 tile rows: the workgroups running together share A and B panels in L2
+        const uint32_t band = 8 * tiles_n, b0 = (t / band) * 8;
+        const uint32_t bh = (tiles_m - b0) < 8 ? (tiles_m - b0) : 8;
+        const uint32_t tm = b0 + (t % band) % bh, tn = (t % band) / bh;
+        const uint64_t m0 = (uint64_t)tm * G6T_TILE, n0 = (uint64_t)tn * G6T_TILE;
+        const uint8_t *ia = A6 + ((uint64_t)tm * image_stages + stage0) * (2 * SUB);
+        const uint8_t *ib = B6 + ((uint64_t)tn * image_stages + stage0) * (2 * SUB);
+        const uint64_t g0 = (uint64_t)(ia + 1024 * wave);
+        const uint64_t g1 = (uint64_t)(wave < 8 ? ia + 1024 * (16 + wave) : ib + 1024 * (wave - 8));
+        const uint64_t g2 = (uint64_t)(ib + 1024 * (8 + wave));
+        // scale rows of this wave's 64 rows / columns (clamped for waves outside the matrix: they compute, but never store)
+        const uint64_t ra = (m0 >> 6) + wr < (M >> 6) ? (m0 >> 6) + wr : (M >> 6) - 1;
+        const uint64_t rb = (n0 >> 6) + wc < (N >> 6) ? (n0 >> 6) + wc : (N >> 6) - 1;
+        const uint64_t sa = (uint64_t)(sA + ra * kbn + 2 * (uint64_t)stage0);
+        const uint64_t sb = (uint64_t)(sB + rb * kbn + 2 * (uint64_t)stage0);
+        const uint64_t cb = (uint64_t)(C + (m0 + wr * 64) * N + n0 + wc * 64);
+        const uint32_t flag = __builtin_amdgcn_readfirstlane((m0 + wr * 64 < M && n0 + wc * 64 < N) ? 1u : 0u);
+#define G6T_RUN(STR)                                                                                                                         \
+    asm volatile(STR : [a16] "+v"(a16), [a8] "+v"(a8), [b16] "+v"(b16), [b8] "+v"(b8)                                                       \
+                 : [voff] "v"(voff), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [sa] "s"(sa), [sb] "s"(sb), [cb] "s"(cb), [np] "s"(nstages), \
+                   [lds] "s"(lds0), [cstride] "s"(cstride), [l0] "s"(l0), [l1] "s"(l1), [l2] "s"(l2), [flag] "s"(flag)                    \
+                 : G6T_LOOP_CLOBBERS)
+        if constexpr (I32) G6T_RUN(G6T_LOOP_ASM_I32);
+        else G6T_RUN(G6T_LOOP_ASM);
+#undef G6T_RUN
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 // An operand's FP6 image (rows * K * 3/4 bytes, staging order).  clm4_gemm re-codes both operands per call into the stream's
 // scratch; clm4_gemm_prepare does it once into a buffer of its own for an operand that is multiplied many times.
 struct clm4_gemm_operand {
     uint8_t *image;
     uint64_t rows, K;
+    uint32_t tile;          // tile rows of the image layout (128 / 256)
     int device;
 };
 
-static int recode(const int8_t *A, uint8_t *A6, uint64_t M, const int8_t *B, uint8_t *B6, uint64_t N, uint64_t K, hipStream_t st)
+static inline uint64_t pad_rows(uint64_t rows, uint32_t tile) { return (rows + tile - 1) / tile * tile; }
+static inline uint64_t image_bytes(uint64_t rows, uint64_t K, uint32_t tile) { return pad_rows(rows, tile) * K / 4 * 3; }
+
+// which workgroup tile: 256 x 256 (persistent, one workgroup per CU) once there are enough tiles to occupy the chip, else 128 x 128.
+// CLV_GEMM_TILE=128|256 forces one (A/B runs, tests).
+static uint32_t pick_tile(uint64_t M, uint64_t N)
 {
-    // one launch for whichever operands still need it (a NULL source = already prepared)
-    const uint64_t ra = A ? M : 0, rb = B ? N : 0;
+    static const int forced = [] { const char *e = getenv("CLV_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 128 || forced == 256) return (uint32_t)forced;
+    const uint64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    return tiles >= (uint64_t)clv_cu_count() ? 256u : 128u;
+}
+
+static int recode(const int8_t *A, uint8_t *A6, uint64_t M, const int8_t *B, uint8_t *B6, uint64_t N, uint64_t K, uint32_t tile, hipStream_t st)
+{
+    // one launch for whichever operands still need it (a NULL source = already prepared); the grid covers the padded images
+    const uint64_t ra = A ? pad_rows(M, tile) : 0, rb = B ? pad_rows(N, tile) : 0;
     if (!ra && !rb) return CLV_OK;
     hipLaunchKernelGGL(k_m4_to_fp6, dim3((unsigned)((K / 64 + F6_KB - 1) / F6_KB), (unsigned)((ra + rb) / F6_ROWS)), dim3(256), 0, st, (const u32x4 *)A, A6,
-                       (uint32_t)(ra / F6_ROWS), (const u32x4 *)B, B6, K / 64);
+                       (uint32_t)(ra / F6_ROWS), (const u32x4 *)B, B6, K / 64, tile, M, N);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -345,13 +428,16 @@ extern "C" int clm4_gemm_prepare(const int8_t *q, uint64_t rows, uint64_t K, clm
     CLV_REQUIRE(q && op, "clm4_gemm_prepare: null pointer");
     CLV_REQUIRE(rows && K && rows % 128 == 0 && K % 128 == 0, "clm4_gemm_prepare: rows=%llu K=%llu must be non-zero multiples of 128",
                 (unsigned long long)rows, (unsigned long long)K);
-    clm4_gemm_operand *o = new clm4_gemm_operand{nullptr, rows, K, 0};
-    if (hipGetDevice(&o->device) != hipSuccess || hipMalloc((void **)&o->image, rows * K / 4 * 3) != hipSuccess) {
+    // the layout depends on the tile the product will use, which depends on the OTHER operand's size too: prepared operands use
+    // the 256-row layout when they are large enough on their own (rows >= 2048), and clm4_gemm_prepared follows them
+    const uint32_t tile = rows >= 2048 && pick_tile(rows, rows) == 256 ? 256u : 128u;
+    clm4_gemm_operand *o = new clm4_gemm_operand{nullptr, rows, K, tile, 0};
+    if (hipGetDevice(&o->device) != hipSuccess || hipMalloc((void **)&o->image, image_bytes(rows, K, tile)) != hipSuccess) {
         clv_set_error("clm4_gemm_prepare: %s", hipGetErrorString(hipGetLastError()));
         delete o;
         return CLV_ERR_HIP;
     }
-    int rc = recode(q, o->image, rows, nullptr, nullptr, 0, K, as_stream(stream));
+    int rc = recode(q, o->image, rows, nullptr, nullptr, 0, K, tile, as_stream(stream));
     if (rc) { (void)hipFree(o->image); delete o; return rc; }
     *op = o;
     return CLV_OK;
@@ -369,7 +455,10 @@ extern "C" int clm4_gemm_release(clm4_gemm_operand *op)
 static int gemm_fp6_run(const clm4_gemm_operand *opA, const int8_t *A, const float *sA, uint64_t M, uint64_t K, const clm4_gemm_operand *opB,
                         const int8_t *B, const float *sB, uint64_t N, void *C, bool i32, uint64_t kb_begin, uint64_t kb_count, hipStream_t st)
 {
-    const uint64_t a_bytes = opA ? 0 : M * K / 4 * 3, b_bytes = opB ? 0 : N * K / 4 * 3;
+    uint32_t tile = opA ? opA->tile : opB ? opB->tile : pick_tile(M, N);
+    CLV_REQUIRE(!(opA && opB) || opA->tile == opB->tile, "clm4_gemm_prepared: the operands were prepared for different tile shapes (%u, %u rows)",
+                opA ? opA->tile : 0, opB ? opB->tile : 0);
+    const uint64_t a_bytes = opA ? 0 : image_bytes(M, K, tile), b_bytes = opB ? 0 : image_bytes(N, K, tile);
     uint8_t *A6 = opA ? opA->image : nullptr, *B6 = opB ? opB->image : nullptr;
     if (a_bytes + b_bytes) {
         void *ws = nullptr;
@@ -377,8 +466,27 @@ static int gemm_fp6_run(const clm4_gemm_operand *opA, const int8_t *A, const flo
         if (rc) return rc;
         if (!opA) A6 = reinterpret_cast<uint8_t *>(ws);
         if (!opB) B6 = reinterpret_cast<uint8_t *>(ws) + a_bytes;
-        rc = recode(opA ? nullptr : A, A6, M, opB ? nullptr : B, B6, N, K, st);
+        rc = recode(opA ? nullptr : A, A6, M, opB ? nullptr : B, B6, N, K, tile, st);
         if (rc) return rc;
+    }
+    if (tile == 256) {
+        const uint32_t tm = (uint32_t)((M + 255) / 256), tn = (uint32_t)((N + 255) / 256);
+        const uint32_t grid256 = tm * tn < (uint32_t)clv_cu_count() ? tm * tn : (uint32_t)clv_cu_count();
+        const uint32_t s0 = i32 ? (uint32_t)(kb_begin / 2) : 0u, ns = i32 ? (uint32_t)(kb_count / 2) : (uint32_t)(K / 128);
+        static bool attr_set[2][64] = {};
+        int dev = 0;
+        CLV_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[i32][dev]) {
+            if (i32) CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6_t256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G6T_LDS_BYTES));
+            else CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6_t256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G6T_LDS_BYTES));
+            attr_set[i32][dev] = true;
+        }
+        if (i32)
+            hipLaunchKernelGGL(k_m4_gemm_fp6_t256<true>, dim3(grid256), dim3(1024), G6T_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, (float *)C, tm, tn, s0, ns);
+        else
+            hipLaunchKernelGGL(k_m4_gemm_fp6_t256<false>, dim3(grid256), dim3(1024), G6T_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, (float *)C, tm, tn, s0, ns);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
     }
     const uint32_t tiles_m = (uint32_t)(M / G6_TILE), tiles_n = (uint32_t)(N / G6_TILE);
     const dim3 grid(tiles_m * tiles_n), block(256);

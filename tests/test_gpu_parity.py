@@ -394,3 +394,52 @@ def test_degenerate_sizes(hip):
     assert lib.clv4_dot(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 0, 0, out.ptr, None, None) == 0
     assert out.download(np.float32, 1)[0] == 0.0
     hip.sync()
+
+
+@pytest.mark.parametrize("tile", ["128", "256"])
+def test_gemm_both_workgroup_tiles_bit_exact(tile):
+    """clm4_gemm picks the 256 x 256 persistent kernel for large products and the 128 x 128 one otherwise; CLV_GEMM_TILE forces
+    one (read once per process, hence the child).  Shapes that are multiples of 128 but not of 256 (partial tiles: waves outside
+    the matrix compute on zero rows and must not store), odd stage counts (the three stage buffers must end where they began,
+    tile after tile), more tiles than a grid of one workgroup per CU would take in one go, the int32 sums and prepared operands."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from clover_amd.lib_binding import CloverHip\n"
+        "from oracle.binding import Oracle\n"
+        "hip, o = CloverHip(), Oracle()\n"
+        "rng = np.random.default_rng(31)\n"
+        "def nib(n):\n"
+        "    q = rng.integers(0, 256, n).astype(np.uint8); q[(q >> 4) == 8] ^= 0x10; q[(q & 15) == 8] ^= 0x01; return q\n"
+        "for (M, N, K) in ((128, 128, 128), (384, 640, 384), (256, 256, 128), (896, 128, 640), (640, 1152, 256)):\n"
+        "    qA, qB = nib(M * K // 2), nib(N * K // 2)\n"
+        "    sA = rng.uniform(0.5, 2, (M // 64) * (K // 64)).astype(np.float32); sB = rng.uniform(0.5, 2, (N // 64) * (K // 64)).astype(np.float32)\n"
+        "    C = hip.m4_gemm(qA, sA, M, K, qB, sB, N); Co = o.m4_gemm(qA, sA, M, K, qB, sB, N)\n"
+        "    assert C.tobytes() == Co.tobytes(), (M, N, K)\n"
+        "    S = o.m4_gemm_isums(qA, M, K, qB, N).astype(np.int64)\n"
+        "    assert np.array_equal(hip.m4_gemm_i32(qA, M, K, qB, N), S.sum(2)), (M, N, K)\n"
+        "    if K >= 256: assert np.array_equal(hip.m4_gemm_i32(qA, M, K, qB, N, 2, K // 64 - 2), S[:, :, 2:].sum(2)), (M, N, K)\n"
+        "    assert hip.m4_gemm_prepared(qA, sA, M, K, qB, sB, N, prepare=('B',)).tobytes() == Co.tobytes(), (M, N, K)\n"
+        "# many tiles per workgroup of the persistent grid: 4352 x 4352 = 17 x 17 tiles of 256 (289 > 256 CUs), sampled against the definition\n"
+        "G, K = 4352, 256\n"
+        "qA, qB = nib(G * K // 2), nib(G * K // 2)\n"
+        "sA = rng.uniform(0.5, 2, (G // 64) * (K // 64)).astype(np.float32); sB = rng.uniform(0.5, 2, (G // 64) * (K // 64)).astype(np.float32)\n"
+        "C = hip.m4_gemm(qA, sA, G, K, qB, sB, G)\n"
+        "rows = [0, 63, 255, 256, 2047, 4095, 4096, 4351]\n"
+        "sub = np.concatenate([qA[r * K // 2:(r + 1) * K // 2] for r in rows])\n"
+        "ssub = np.concatenate([sA[(r >> 6) * (K // 64):((r >> 6) + 1) * (K // 64)] for r in rows])\n"
+        "for i, r in enumerate(rows):\n"
+        "    for c in (0, 255, 256, 4100, 4351):\n"
+        "        S = o.v4_word_isums(qA[r * K // 2:(r + 1) * K // 2], qB[c * K // 2:(c + 1) * K // 2]).reshape(K // 64, 8).sum(1)\n"
+        "        acc = np.float32(0)\n"
+        "        for b in range(K // 64):\n"
+        "            cb = np.float32(np.float32(sA[(r >> 6) * (K // 64) + b] * np.float32(1.0 / 49.0)) * sB[(c >> 6) * (K // 64) + b])\n"
+        "            acc = np.float32(np.float64(cb) * np.float64(S[b]) + np.float64(acc))\n"
+        "        assert acc.view(np.uint32) == C[r, c].view(np.uint32), (r, c)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CLV_GEMM_TILE=tile)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
