@@ -67,6 +67,15 @@ int clv_rng_tables(RngTables *t)
     return CLV_OK;
 }
 
+// the 4 nibbles of half an output dword with their noise: words W.x..W.w of one draw, byte `sh` (see k_m4_quantize_strip_st)
+__device__ __forceinline__ uint32_t quant_pack4_st(const f32x4 v, float k, const u32x4 W, int sh)
+{
+    const uint32_t h = (((uint32_t)quant1_st(v.x, k, noise_of(W.x, sh)) & 0xFu) << 4) | ((uint32_t)quant1_st(v.y, k, noise_of(W.y, sh)) & 0xFu) |
+                       (((uint32_t)quant1_st(v.z, k, noise_of(W.z, sh)) & 0xFu) << 12) |
+                       (((uint32_t)quant1_st(v.w, k, noise_of(W.w, sh)) & 0xFu) << 8);
+    return k < __builtin_inff() ? h : 0u;
+}
+
 // ---- vector quantize, stochastic (CloverVector4.h:605-807 with the rnd_* branch) --------------------
 // wave = S segments of 8 consecutive blocks; lane (seg = l>>2, k = l&3) generates its segment's draws into LDS
 // (S = 16: four blocks per round, two rounds); then lane = 8 elements quantises 8 blocks per sub-step, all loads of a
@@ -92,6 +101,43 @@ __global__ __launch_bounds__(256) void k_v4_quantize_st(const f32x4 *__restrict_
     uint64_t a = segs.starts(base);
     const int rho = lane & 7;
 
+    if constexpr (Sh::NSEG == 16) {
+        // Large vectors: lane = one float4, as in the deterministic kernel.  A round is 16 pieces of 4 consecutive blocks (one per
+        // segment): load j reads piece j = one contiguous KiB; a block is a DPP row of 16 lanes (maximum by row rotations); a lane
+        // quantises half an output dword -- elements 4c..4c+3 of its block, c = lane & 15: noise group g = c >> 1 (draw g >> 2, byte
+        // g & 3), words W[4 (c & 1) .. +3] -- and lane pairs swap halves so that even lanes store piece j, odd lanes piece j + 1.
+        const int c = lane & 15, g = c >> 1, odd = lane & 1, sub = lane >> 1;
+        for (int r = 0; r < Sh::ROUNDS; r++) {
+            f32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {                   // the round's loads first: in flight while the generator lanes step
+                const uint64_t blk = blk0 + (uint64_t)j * Sh::SEGLEN + Sh::BPR * r + (lane >> 4);
+                v[j] = __builtin_nontemporal_load(&x[blk < nblocks ? blk * 16 + c : 0]);
+            }
+            if (r) __syncthreads();                          // the previous round's noise has been consumed
+            a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+            __syncthreads();
+            const u32x4 *noise = reinterpret_cast<const u32x4 *>(raw) + (size_t)((lane >> 4) * 2 + (g >> 2)) * 2 + (c & 1);   // + 16 per piece
+            uint32_t half[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint64_t blk = blk0 + (uint64_t)j * Sh::SEGLEN + Sh::BPR * r + (lane >> 4);
+                float m = fmaxf(fmaxf(__builtin_fabsf(v[j].x), __builtin_fabsf(v[j].y)), fmaxf(__builtin_fabsf(v[j].z), __builtin_fabsf(v[j].w)));
+                m = fix_zero_max(row16_max(m));
+                half[j] = quant_pack4_st(v[j], 7.0f / m, noise[(size_t)Sh::BPR * 4 * j], g & 3);
+                if (c == 0 && blk < nblocks) s[blk] = m;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const uint32_t give = odd ? half[j] : half[j + 1];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+                const uint32_t word = odd ? (recv | (half[j + 1] << 16)) : (half[j] | (recv << 16));
+                const uint64_t pb = blk0 + (uint64_t)(j + odd) * Sh::SEGLEN + Sh::BPR * r;                          // first block of the piece
+                if (pb + (sub >> 3) < nblocks) __builtin_nontemporal_store(word, &q[pb * 8 + sub]);
+            }
+        }
+        return;
+    }
     for (int r = 0; r < Sh::ROUNDS; r++) {
         if (lane < 4 * Sh::NSEG) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();
@@ -193,14 +239,6 @@ __global__ __launch_bounds__(256) void k_m4_quantize_st(const float *__restrict_
 // strip form of the same (see k_m4_quantize_strip, matrix4.hip): workgroup = 64 rows x 4 tiles side by side.  Wave w
 // generates the draws of tile bj = 4 sj + w -- stream position t = bj * tiles_y + bi, all four generator lanes -- and
 // every lane then reads the 16 bytes of noise words its four elements of a row need.
-__device__ __forceinline__ uint32_t quant_pack4_st(const f32x4 v, float k, const u32x4 W, int sh)
-{
-    const uint32_t h = (((uint32_t)quant1_st(v.x, k, noise_of(W.x, sh)) & 0xFu) << 4) | ((uint32_t)quant1_st(v.y, k, noise_of(W.y, sh)) & 0xFu) |
-                       (((uint32_t)quant1_st(v.z, k, noise_of(W.z, sh)) & 0xFu) << 12) |
-                       (((uint32_t)quant1_st(v.w, k, noise_of(W.w, sh)) & 0xFu) << 8);
-    return k < __builtin_inff() ? h : 0u;
-}
-
 __global__ __launch_bounds__(256) void k_m4_quantize_strip_st(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
                                                               float *__restrict__ s, uint32_t strips_x, uint32_t tiles_x, uint64_t tiles_y,
                                                               uint64_t *state, uint64_t seq, RngTables T)
