@@ -157,7 +157,8 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before the timed ones (default 20; 80 for --workload gemm: the matrix "
+                                                               "pipe's clocks settle after about 50 calls)")
     ap.add_argument("--rows-per-gpu", type=int, default=65536)
     ap.add_argument("--preset", choices=("c3", "c5-weak", "c5-strong"), default="c3",
                     help="c3 (default): 65536 x 65536 per GPU, weak scaling (BASELINE configs[2] at N=1); c5-weak: 131072 x 65536 per GPU "
@@ -173,6 +174,8 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.warmup is None:
+        args.warmup = 80 if args.workload == "gemm" else 20
     if args.workload == "gemm":
         return gemm_main(args)
 
@@ -428,7 +431,7 @@ def gemm_main(args) -> None:
                                "semantics (one fma chain over the 64-element K-blocks per element)", "M": G, "N": G, "K": G,
                    "parallelism": "1 GPU"},
         "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": FP6_PEAK_TOPS, "unit": "TOP/s", "frac": round(ach / FP6_PEAK_TOPS, 4),
-                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_asm (one clm4_gemm call)", "kernel_avg_ms": round(call_ms, 5),
+                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_t256 (one clm4_gemm call)", "kernel_avg_ms": round(call_ms, 5),
                      "frac_of_int8_peak": round(ach / INT8_PEAK_TOPS, 4),
                      "peak_note": "10 POP/s = dense FP6 block-scaled MFMA, the pipe the kernel runs on; 5 POP/s = dense int8 MFMA, the pipe "
                                   "BASELINE names; counters in profiles/"},
@@ -436,6 +439,8 @@ def gemm_main(args) -> None:
 
 
 def _timeit(torch, fn, reps, warm=3):
+    """mean ms per call of `reps` calls after `warm` untimed ones.  Matrix-pipe kernels need a long warm-up: the first ~50 GEMM calls
+    (about 25 ms of work) run 10-20 % slower than the steady state the clocks settle at (profiles/r02_gemm_warmup_series.txt)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -467,21 +472,22 @@ def gemm_object(hip, torch, dev, stream, G: int = 8192) -> dict:
     for t, sd in ((gsA, 23), (gsB, 24)):
         hip.check(lib.clv_fill_random_scales(t.data_ptr(), t.numel(), sd, 0, stream))
     ops = 2.0 * G ** 3
-    g_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm(gA.data_ptr(), gsA.data_ptr(), G, G, gB.data_ptr(), gsB.data_ptr(), G, gC.data_ptr(), stream)), 20)
+    g_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm(gA.data_ptr(), gsA.data_ptr(), G, G, gB.data_ptr(), gsB.data_ptr(), G, gC.data_ptr(), stream)), 100, warm=80)
     opA, opB = C.c_void_p(), C.c_void_p()
     hip.check(lib.clm4_gemm_prepare(gA.data_ptr(), G, G, C.byref(opA), stream))
     hip.check(lib.clm4_gemm_prepare(gB.data_ptr(), G, G, C.byref(opB), stream))
-    p_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_prepared(opA, None, gsA.data_ptr(), G, G, opB, None, gsB.data_ptr(), G, gC.data_ptr(), stream)), 20)
+    p_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_prepared(opA, None, gsA.data_ptr(), G, G, opB, None, gsB.data_ptr(), G, gC.data_ptr(), stream)), 100, warm=40)
+    ip_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_i32_prepared(opA, None, G, G, opB, None, G, 0, G // 64, gC.data_ptr(), stream)), 100, warm=40)
     hip.check(lib.clm4_gemm_release(opA))
     hip.check(lib.clm4_gemm_release(opB))
-    i_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_i32(gA.data_ptr(), G, G, gB.data_ptr(), G, 0, G // 64, gC.data_ptr(), stream)), 20)
+    i_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_i32(gA.data_ptr(), G, G, gB.data_ptr(), G, 0, G // 64, gC.data_ptr(), stream)), 100, warm=40)
     tops = ops / g_ms / 1e9
     return {
         "workload": f"CloverMatrix4::gemm {G}x{G}x{G} int4 x int4 -> fp32 (BASELINE configs[3]), both operands re-coded inside the call, "
                     "bit-exact against the build-defined semantics (one fma chain over the 64-element K-blocks per element)",
         "ms": round(g_ms, 4), "value": round(tops, 1), "unit": "TOP/s",
         "roofline": {"bound": "mfma", "achieved": round(tops, 1), "peak": FP6_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / FP6_PEAK_TOPS, 4),
-                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_asm (one clm4_gemm call)", "kernel_avg_ms": round(g_ms, 4),
+                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_t256 (one clm4_gemm call)", "kernel_avg_ms": round(g_ms, 4),
                      "frac_of_int8_peak": round(tops / INT8_PEAK_TOPS, 4),
                      "peak_note": "10 POP/s = dense FP6 block-scaled MFMA, the pipe the kernel runs on (nibbles are exact E2M3 values); "
                                   "5 POP/s = dense int8 MFMA, the pipe BASELINE names"},
@@ -489,7 +495,10 @@ def gemm_object(hip, torch, dev, stream, G: int = 8192) -> dict:
                               "note": "clm4_gemm_prepared: both FP6 images made once outside the timed region (weights-style reuse)"},
         "int32_unscaled": {"ms": round(i_ms, 4), "TOP/s": round(ops / i_ms / 1e9, 1), "frac_of_fp6_peak": round(ops / i_ms / 1e9 / FP6_PEAK_TOPS, 4),
                            "note": "clm4_gemm_i32 over all K-blocks: the exact int4 x int4 -> int32 contraction (no scales), accumulated inside "
-                                   "the matrix pipe; time includes the re-coding pass"},
+                                   "the matrix pipe; time includes the re-coding pass",
+                           "prepared_operands": {"ms": round(ip_ms, 4), "TOP/s": round(ops / ip_ms / 1e9, 1),
+                                                 "frac_of_fp6_peak": round(ops / ip_ms / 1e9 / FP6_PEAK_TOPS, 4)}},
+        "timing": "mean of 100 calls after 40-80 untimed ones (steady-state clocks), HIP events on the launch stream",
         "note": "CLV_GEMM_LOOP=hipcc runs the compiler-scheduled main loop, CLV_GEMM_KERNEL=i8 the int8-MFMA kernel (A/B runs)",
     }
 

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6_asm(const uint8_t *__res
 #define G6T_TILE 256
 #define G6T_LDS_BYTES (3 * 4 * G6T_TILE * 48)       // three stage buffers of 48 KiB
 
-template <bool I32>
+template <bool I32, int V = 0>
 __global__ __launch_bounds__(1024) void k_m4_gemm_fp6_t256(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
                                                              const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t M, uint64_t N,
                                                              uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n, uint32_t stage0,
@@ -359,32 +359,56 @@ __global__ __launch_bounds__(1024) void k_m4_gemm_fp6_t256(const uint8_t *__rest
     uint32_t b16 = lds0 + 2 * SUB + (wc * 64 + frow) * 48 + 16 * h;
     uint32_t b8 = lds0 + 2 * SUB + (wc * 64 + frow) * 48 + tail;
     const uint32_t voff = 16 * lane;
-    const uint32_t ntiles = tiles_m * tiles_n;
-    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        // column-major inside bands of 8 tile rows: the workgroups running together share A and B panels in L2
-        const uint32_t band = 8 * tiles_n, b0 = (t / band) * 8;
-        const uint32_t bh = (tiles_m - b0) < 8 ? (tiles_m - b0) : 8;
-        const uint32_t tm = b0 + (t % band) % bh, tn = (t % band) / bh;
-        const uint64_t m0 = (uint64_t)tm * G6T_TILE, n0 = (uint64_t)tn * G6T_TILE;
+    // Tile order.  The grid is always 256 workgroups; they are dealt to the 8 XCDs round-robin, so blockIdx % 8 names the L2 a
+    // workgroup sits behind and blockIdx / 8 its slot (0..31) there.  The 32 workgroups of an XCD take a 4 x 8 block of tiles
+    // (tiles outside the matrix are skipped): 12 operand panels go through that L2 per block instead of 33 when the workgroups of
+    // one XCD hold a whole tile row (measured at 8192^3 with such an order: 50 % L2 hits, 1.7 GB of misses for 50 MB of operands).
+    // No division inside the loop and few live scalars: the asm statement owns all 128 VGPRs, so neither a hoisted reciprocal nor
+    // an SGPR spill has a register to go to.
+    const uint32_t blocks_m = (tiles_m + 3) >> 2, blocks_n = (tiles_n + 7) >> 3;
+    const uint32_t slot = blockIdx.x >> 3, sm = slot & 3, sn = slot >> 2;
+    uint32_t bi = __builtin_amdgcn_readfirstlane((blockIdx.x & 7) / blocks_n);
+    uint32_t bj = __builtin_amdgcn_readfirstlane((blockIdx.x & 7) % blocks_n);
+    for (; bi < blocks_m;) {
+        const uint32_t tm = 4 * bi + sm, tn = 8 * bj + sn;
+        bj += 8;
+        while (bj >= blocks_n) {
+            bj -= blocks_n;
+            ++bi;
+        }
+        // all scalar and 32-bit: 64-bit compares exist only on the VALU, and their operands would sit in VGPRs across the asm
+        if (tm >= tiles_m || tn >= tiles_n) continue;
         const uint8_t *ia = A6 + ((uint64_t)tm * image_stages + stage0) * (2 * SUB);
         const uint8_t *ib = B6 + ((uint64_t)tn * image_stages + stage0) * (2 * SUB);
         const uint64_t g0 = (uint64_t)(ia + 1024 * wave);
-        const uint64_t g1 = (uint64_t)(wave < 8 ? ia + 1024 * (16 + wave) : ib + 1024 * (wave - 8));
+        const uint64_t g1 = (uint64_t)((wave < 8 ? ia + 16 * 1024 : ib - 8 * 1024) + 1024 * wave);
         const uint64_t g2 = (uint64_t)(ib + 1024 * (8 + wave));
         // scale rows of this wave's 64 rows / columns (clamped for waves outside the matrix: they compute, but never store)
-        const uint64_t ra = (m0 >> 6) + wr < (M >> 6) ? (m0 >> 6) + wr : (M >> 6) - 1;
-        const uint64_t rb = (n0 >> 6) + wc < (N >> 6) ? (n0 >> 6) + wc : (N >> 6) - 1;
-        const uint64_t sa = (uint64_t)(sA + ra * kbn + 2 * (uint64_t)stage0);
-        const uint64_t sb = (uint64_t)(sB + rb * kbn + 2 * (uint64_t)stage0);
-        const uint64_t cb = (uint64_t)(C + (m0 + wr * 64) * N + n0 + wc * 64);
-        const uint32_t flag = __builtin_amdgcn_readfirstlane((m0 + wr * 64 < M && n0 + wc * 64 < N) ? 1u : 0u);
+        const uint32_t rows64_m = (uint32_t)(M >> 6), rows64_n = (uint32_t)(N >> 6);
+        const uint32_t wa = 4 * tm + wr, wb = 4 * tn + wc;
+        const uint32_t ra = wa < rows64_m ? wa : rows64_m - 1, rb = wb < rows64_n ? wb : rows64_n - 1;
+        const uint64_t sa = (uint64_t)(sA + (uint64_t)ra * kbn + 2 * (uint64_t)stage0);
+        const uint64_t sb = (uint64_t)(sB + (uint64_t)rb * kbn + 2 * (uint64_t)stage0);
+        const uint64_t cb = (uint64_t)(C + (uint64_t)wa * 64 * N + (uint64_t)wb * 64);
+        const uint32_t flag = __builtin_amdgcn_readfirstlane((wa < rows64_m && wb < rows64_n) ? 1u : 0u);
 #define G6T_RUN(STR)                                                                                                                         \
     asm volatile(STR : [a16] "+v"(a16), [a8] "+v"(a8), [b16] "+v"(b16), [b8] "+v"(b8)                                                       \
                  : [voff] "v"(voff), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [sa] "s"(sa), [sb] "s"(sb), [cb] "s"(cb), [np] "s"(nstages), \
                    [lds] "s"(lds0), [cstride] "s"(cstride), [l0] "s"(l0), [l1] "s"(l1), [l2] "s"(l2), [flag] "s"(flag)                    \
                  : G6T_LOOP_CLOBBERS)
-        if constexpr (I32) G6T_RUN(G6T_LOOP_ASM_I32);
-        else G6T_RUN(G6T_LOOP_ASM);
+        if constexpr (V == 0) {
+            if constexpr (I32) G6T_RUN(G6T_LOOP_ASM_I32);
+            else G6T_RUN(G6T_LOOP_ASM);
+        }
+#ifdef G6T_LOOP_EXPERIMENTS
+#define G6T_VARIANT(N)                                  \
+    else if constexpr (V == N) {                        \
+        if constexpr (I32) G6T_RUN(G6T_LOOP_ASM_I32_V##N); \
+        else G6T_RUN(G6T_LOOP_ASM_V##N);                \
+    }
+        G6T_VARIANT(1) G6T_VARIANT(2) G6T_VARIANT(3) G6T_VARIANT(4) G6T_VARIANT(5) G6T_VARIANT(6) G6T_VARIANT(7) G6T_VARIANT(8) G6T_VARIANT(9) G6T_VARIANT(10)
+#undef G6T_VARIANT
+#endif
 #undef G6T_RUN
     }
 }
@@ -471,20 +495,37 @@ static int gemm_fp6_run(const clm4_gemm_operand *opA, const int8_t *A, const flo
     }
     if (tile == 256) {
         const uint32_t tm = (uint32_t)((M + 255) / 256), tn = (uint32_t)((N + 255) / 256);
-        const uint32_t grid256 = tm * tn < (uint32_t)clv_cu_count() ? tm * tn : (uint32_t)clv_cu_count();
+        const uint32_t grid256 = 256;       // 8 XCDs x 32 slots: the kernel's tile order is built on it
         const uint32_t s0 = i32 ? (uint32_t)(kb_begin / 2) : 0u, ns = i32 ? (uint32_t)(kb_count / 2) : (uint32_t)(K / 128);
-        static bool attr_set[2][64] = {};
-        int dev = 0;
-        CLV_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 64 && !attr_set[i32][dev]) {
-            if (i32) CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6_t256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G6T_LDS_BYTES));
-            else CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6_t256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G6T_LDS_BYTES));
-            attr_set[i32][dev] = true;
+        int variant = 0;
+#ifdef G6T_LOOP_EXPERIMENTS
+        static const int env_variant = [] { const char *e = getenv("CLV_GEMM_LOOP"); return e && e[0] == 'v' ? atoi(e + 1) : 0; }();
+        variant = env_variant;
+#endif
+#define G6T_LAUNCH(I, V)                                                                                                                   \
+    do {                                                                                                                                   \
+        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6_t256<I, V>, hipFuncAttributeMaxDynamicSharedMemorySize, G6T_LDS_BYTES));     \
+        hipLaunchKernelGGL((k_m4_gemm_fp6_t256<I, V>), dim3(grid256), dim3(1024), G6T_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, (float *)C, tm, \
+                           tn, s0, ns);                                                                                                    \
+    } while (0)
+#define G6T_LAUNCH_V(V) do { if (i32) G6T_LAUNCH(true, V); else G6T_LAUNCH(false, V); } while (0)
+        switch (variant) {
+#ifdef G6T_LOOP_EXPERIMENTS
+        case 1: G6T_LAUNCH_V(1); break;
+        case 2: G6T_LAUNCH_V(2); break;
+        case 3: G6T_LAUNCH_V(3); break;
+        case 4: G6T_LAUNCH_V(4); break;
+        case 5: G6T_LAUNCH_V(5); break;
+        case 6: G6T_LAUNCH_V(6); break;
+        case 7: G6T_LAUNCH_V(7); break;
+        case 8: G6T_LAUNCH_V(8); break;
+        case 9: G6T_LAUNCH_V(9); break;
+        case 10: G6T_LAUNCH_V(10); break;
+#endif
+        default: G6T_LAUNCH_V(0); break;
         }
-        if (i32)
-            hipLaunchKernelGGL(k_m4_gemm_fp6_t256<true>, dim3(grid256), dim3(1024), G6T_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, (float *)C, tm, tn, s0, ns);
-        else
-            hipLaunchKernelGGL(k_m4_gemm_fp6_t256<false>, dim3(grid256), dim3(1024), G6T_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, (float *)C, tm, tn, s0, ns);
+#undef G6T_LAUNCH_V
+#undef G6T_LAUNCH
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
@@ -558,23 +599,41 @@ __global__ __launch_bounds__(256) void k_m4_gemm_i32_simple(const uint8_t *__res
     S[i * N + j] = acc;
 }
 
-extern "C" int clm4_gemm_i32(const int8_t *A, uint64_t M, uint64_t K, const int8_t *B, uint64_t N, uint64_t kb_begin, uint64_t kb_count, int32_t *S,
-                             void *stream)
+static int gemm_i32_checked(const char *who, const clm4_gemm_operand *opA, const int8_t *A, uint64_t M, uint64_t K, const clm4_gemm_operand *opB,
+                            const int8_t *B, uint64_t N, uint64_t kb_begin, uint64_t kb_count, int32_t *S, void *stream)
 {
-    CLV_REQUIRE(A && B && S, "clm4_gemm_i32: null pointer");
-    CLV_REQUIRE(M && N && K && M % 128 == 0 && N % 128 == 0 && K % 128 == 0, "clm4_gemm_i32: M=%llu N=%llu K=%llu must be non-zero multiples of 128",
+    CLV_REQUIRE((opA || A) && (opB || B) && S, "%s: null pointer", who);
+    CLV_REQUIRE(M && N && K && M % 128 == 0 && N % 128 == 0 && K % 128 == 0, "%s: M=%llu N=%llu K=%llu must be non-zero multiples of 128", who,
                 (unsigned long long)M, (unsigned long long)N, (unsigned long long)K);
-    CLV_REQUIRE(kb_count && kb_begin + kb_count <= K / 64, "clm4_gemm_i32: K-blocks [%llu, +%llu) of %llu", (unsigned long long)kb_begin,
+    CLV_REQUIRE(kb_count && kb_begin + kb_count <= K / 64, "%s: K-blocks [%llu, +%llu) of %llu", who, (unsigned long long)kb_begin,
                 (unsigned long long)kb_count, (unsigned long long)(K / 64));
     // fp32 accumulation of integers is exact below 2^24: 49 * 64 per K-block
-    CLV_REQUIRE(kb_count <= (1ull << 24) / (49 * 64), "clm4_gemm_i32: %llu K-blocks would leave the exact range of the matrix pipe", (unsigned long long)kb_count);
+    CLV_REQUIRE(kb_count <= (1ull << 24) / (49 * 64), "%s: %llu K-blocks would leave the exact range of the matrix pipe", who, (unsigned long long)kb_count);
+    CLV_REQUIRE(!opA || (opA->rows == M && opA->K == K), "%s: operand A was prepared as %llu x %llu", who, opA ? (unsigned long long)opA->rows : 0ull,
+                opA ? (unsigned long long)opA->K : 0ull);
+    CLV_REQUIRE(!opB || (opB->rows == N && opB->K == K), "%s: operand B was prepared as %llu x %llu", who, opB ? (unsigned long long)opB->rows : 0ull,
+                opB ? (unsigned long long)opB->K : 0ull);
     hipStream_t st = as_stream(stream);
     static const bool simple = [] { const char *e = getenv("CLV_GEMM_KERNEL"); return e && !strcmp(e, "simple"); }();
     if (((kb_begin | kb_count) & 1) || simple) {
+        // odd ranges run on the nibbles themselves
+        CLV_REQUIRE(A && B, "%s: an odd K-block range needs the nibbles of both operands (A, B), not only their prepared images", who);
         hipLaunchKernelGGL(k_m4_gemm_i32_simple, dim3((unsigned)(N / 16), (unsigned)(M / 16)), dim3(256), 0, st, (const uint8_t *)A, M, K, (const uint8_t *)B, N,
                            kb_begin, kb_count, S);
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
-    return gemm_fp6_run(nullptr, A, nullptr, M, K, nullptr, B, nullptr, N, S, true, kb_begin, kb_count, st);
+    return gemm_fp6_run(opA, A, nullptr, M, K, opB, B, nullptr, N, S, true, kb_begin, kb_count, st);
+}
+
+extern "C" int clm4_gemm_i32(const int8_t *A, uint64_t M, uint64_t K, const int8_t *B, uint64_t N, uint64_t kb_begin, uint64_t kb_count, int32_t *S,
+                             void *stream)
+{
+    return gemm_i32_checked("clm4_gemm_i32", nullptr, A, M, K, nullptr, B, N, kb_begin, kb_count, S, stream);
+}
+
+extern "C" int clm4_gemm_i32_prepared(const clm4_gemm_operand *opA, const int8_t *A, uint64_t M, uint64_t K, const clm4_gemm_operand *opB, const int8_t *B,
+                                      uint64_t N, uint64_t kb_begin, uint64_t kb_count, int32_t *S, void *stream)
+{
+    return gemm_i32_checked("clm4_gemm_i32_prepared", opA, A, M, K, opB, B, N, kb_begin, kb_count, S, stream);
 }

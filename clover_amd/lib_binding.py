@@ -59,6 +59,7 @@ SIGNATURES = {
     "clm4_gemm_release": (C.c_int, [_vp]),
     "clm4_gemm_prepared": (C.c_int, [_vp, _vp, _vp, _u64, _u64, _vp, _vp, _vp, _u64, _vp, _vp]),
     "clm4_gemm_i32": (C.c_int, [_vp, _u64, _u64, _vp, _u64, _u64, _u64, _vp, _vp]),
+    "clm4_gemm_i32_prepared": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "clv4_scale_and_add": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _u64, _vp, _vp, _vp, _vp]),
     "clm4_mvm_scale_and_add": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clv8_quantize": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
@@ -334,6 +335,22 @@ class CloverHip:
         c = self.alloc(max(M * N * 4, 4))
         self.check(self.lib.clm4_gemm_i32(b[0].ptr, M, K, b[1].ptr, N, kb_begin, K // 64 - kb_begin if kb_count is None else kb_count, c.ptr, None))
         return c.download(np.int32, M * N).reshape(M, N)
+
+    def m4_gemm_i32_prepared(self, qA, M, K, qB, N, kb_begin=0, kb_count=None, prepare=("A", "B")) -> np.ndarray:
+        b = [self.to_device(a) for a in (qA, qB)]
+        c = self.alloc(max(M * N * 4, 4))
+        ops = {"A": C.c_void_p(), "B": C.c_void_p()}
+        if "A" in prepare:
+            self.check(self.lib.clm4_gemm_prepare(b[0].ptr, M, K, C.byref(ops["A"]), None))
+        if "B" in prepare:
+            self.check(self.lib.clm4_gemm_prepare(b[1].ptr, N, K, C.byref(ops["B"]), None))
+        try:
+            self.check(self.lib.clm4_gemm_i32_prepared(ops["A"], None if "A" in prepare else b[0].ptr, M, K, ops["B"], None if "B" in prepare else b[1].ptr, N,
+                                                       kb_begin, K // 64 - kb_begin if kb_count is None else kb_count, c.ptr, None))
+            return c.download(np.int32, M * N).reshape(M, N)
+        finally:
+            for o in ops.values():
+                self.check(self.lib.clm4_gemm_release(o))
 
     def m4_gemm_prepared(self, qA, sA, M, K, qB, sB, N, prepare=("A", "B")) -> np.ndarray:
         b = [self.to_device(a) for a in (qA, sA, qB, sB)]

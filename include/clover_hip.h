@@ -142,6 +142,11 @@ int  clm4_gemm_prepared(const clm4_gemm_operand *opA, const int8_t *A, const flo
  * across K-blocks inside the pipe: integers below 2^24 are exact there), other ranges on a VALU kernel. */
 int  clm4_gemm_i32(const int8_t *A, uint64_t M, uint64_t K, const int8_t *B, uint64_t N, uint64_t kb_begin, uint64_t kb_count,
                    int32_t *S, void *stream);
+/* the same with either operand prepared once (clm4_gemm_prepare; op == NULL: raw nibbles in A / B).  An odd K-block range needs the
+ * nibbles of both operands besides any prepared image. */
+int  clm4_gemm_i32_prepared(const clm4_gemm_operand *opA, const int8_t *A, uint64_t M, uint64_t K,
+                            const clm4_gemm_operand *opB, const int8_t *B, uint64_t N, uint64_t kb_begin, uint64_t kb_count,
+                            int32_t *S, void *stream);
 
 /* ---- callers either side of the hot path: the other steps of the quantized IHT/GD loops ---- */
 /* CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478; _parallel :1489-1791): r = quantize(u + a*v) per

@@ -193,6 +193,10 @@ def test_gemm_integer_sums_exact(hip, oracle, shape):
     q7 = np.full(M * K // 2, 0x77, np.uint8)
     qm = np.full(N * K // 2, 0x99, np.uint8)
     assert (hip.m4_gemm_i32(q7, M, K, qm, N) == -49 * K).all()
+    # the same sums from operands prepared once (either or both), whole range and an even sub-range
+    for prepare in (("A",), ("B",), ("A", "B")):
+        assert np.array_equal(hip.m4_gemm_i32_prepared(qA, M, K, qB, N, prepare=prepare), S.sum(2)), prepare
+    assert np.array_equal(hip.m4_gemm_i32_prepared(qA, M, K, qB, N, kb - 2, 2), S[:, :, kb - 2:].sum(2))
 
 
 @pytest.mark.parametrize("prepare", [("A",), ("B",), ("A", "B")])

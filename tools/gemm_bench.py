@@ -30,7 +30,7 @@ for G in [int(g) for g in os.environ.get("GB_SIZES", "4096,8192").split(",")]:
             hip.check(lib.clm4_gemm_prepare(A.ptr, G, G, C.byref(opA), None))
         hip.check(lib.clm4_gemm_prepare(B.ptr, G, G, C.byref(opB), None))
         fn = lambda: hip.check(lib.clm4_gemm_prepared(opA, None if opA else A.ptr, sA.ptr, G, G, opB, None, sB.ptr, G, Cc.ptr, None))
-    for _ in range(3):
+    for _ in range(int(os.environ.get("GB_WARM", "80"))):     # the clocks settle after ~50 calls (profiles/r02_gemm_warmup_series.txt)
         fn()
     hip.sync()
     a, b = C.c_void_p(), C.c_void_p()

@@ -34,13 +34,16 @@ THREE stage buffers (144 KiB): with one workgroup per CU nobody else fills the m
 DMA, so a stage's requests go out TWO stages ahead and the wait before the barrier is vmcnt(3): the older three (next stage) have
 landed, this stage's three stay in flight.  s62 = index of the buffer the fragment bases name, s75 = index of the DMA target.
 """
+import os
 import sys
 
 SUB = 256 * 48            # one operand, one K-block: [row][48 B]
 BUF = 4 * SUB             # stage image [A j0][A j1][B j0][B j1] = 48 KiB; three of them
 STAGE_BYTES = 2 * SUB     # global bytes of one operand per stage
-NS = 8                    # scalar fmas per fold, the rest packed
+NS = int(os.environ.get("G6T_NS", "8"))     # scalar fmas per fold, the rest packed (even)
 MODE = "scaled"
+# timing-only experiment switches (results are wrong by construction): parts of the loop LEFT OUT
+OFF = set()               # subset of {"dma", "lds", "barrier", "store", "fold"}
 
 FRAG = {"A0": 96, "A1": 102, "B0": 108, "B1": 114}
 VS, VT, VC1 = 120, 121, 122
@@ -58,6 +61,8 @@ class Emit:
         r = FRAG[frag]
         op = "a" if frag[0] == "A" else "b"
         off = j * SUB + idx * 32 * 48
+        if "lds" in OFF:
+            return
         self(f"ds_read_b128 v[{r}:{r+3}], %[{op}16] offset:{off}")
         self(f"ds_read_b64 v[{r+4}:{r+5}], %[{op}8] offset:{off}")
         self.lds_q += [frag, frag]
@@ -84,7 +89,7 @@ def mfma(e, m, fa, fb, tile):
 
 
 def fold(e, m, tile, creg):
-    if MODE == "i32":
+    if MODE == "i32" or "fold" in OFF:
         return
     a, r = 16 * tile, 64 + 16 * (m & 1)
     for i in range(NS):
@@ -94,6 +99,8 @@ def fold(e, m, tile, creg):
 
 
 def dma(e, k):
+    if "dma" in OFF:
+        return
     e(f"s_add_u32 m0, s61, s{68 + k}")
     e("s_nop 0")
     e(f"global_load_lds_dwordx4 %[voff], s[{52 + 2 * k}:{53 + 2 * k}]")
@@ -129,6 +136,8 @@ Q0 = ["A0", "A0", "B0", "B0", "B1", "B1", "A1", "A1"]
 def advance_pointers(e, limit, images_only=False, scales_only=False):
     """the image pointers name the stage the NEXT DMA fetches, the scale pointers the stage whose scales are loaded next; both
     move on only while that following stage exists (s60 = stages left, the current one included)"""
+    if "salu" in OFF:
+        return
     ptrs = [] if scales_only else [(52, STAGE_BYTES), (54, STAGE_BYTES), (56, STAGE_BYTES)]
     if MODE != "i32" and not images_only:
         ptrs += [(58, 8), (72, 8)]
@@ -142,6 +151,8 @@ def advance_pointers(e, limit, images_only=False, scales_only=False):
 def rotate(e):
     """three stage buffers: the fragment bases move on to the next buffer (s62 = index of the one they name), and so does the DMA
     target (s75 = its index, always two ahead)"""
+    if "salu" in OFF:
+        return
     e("s_add_u32 s62, s62, 1")
     e("s_cmp_eq_u32 s62, 3")
     e("s_cselect_b32 s64, s76, s77")          # back by two buffers from the third, else one on
@@ -230,7 +241,8 @@ def generate():
             load_scales(e)                     # next stage's scales, covered by the wait before the barrier
             fold(e, 4, UNITS[4][2], CREG[4])
     e("s_waitcnt vmcnt(3) lgkmcnt(0)")         # the NEXT stage's image (requested a whole stage ago) has landed; this stage's requests fly on
-    e("s_barrier")
+    if "barrier" not in OFF:
+        e("s_barrier")
     advance_pointers(e, 3, images_only=True)   # the DMA pointers run two stages ahead
     advance_pointers(e, 2, scales_only=True)
     rotate(e)
@@ -245,7 +257,7 @@ def generate():
             e.ds_frag("B1", 0, 1)
             e.ds_frag("A1", 0, 1)
         fold(e, m - 1, UNITS[m - 1][2], CREG[m - 1])
-    assert e.lds_q == Q0, e.lds_q
+    assert e.lds_q == Q0 or "lds" in OFF, e.lds_q
     e("s_sub_u32 s60, s60, 1")
     e("s_cmp_lg_u32 s60, 0")
     e("s_cbranch_scc1 1b")
@@ -267,6 +279,8 @@ def generate():
     # ---------------- store C (skipped by waves whose 64 x 64 tile lies outside the matrix) ----------------
     e("s_cmp_eq_u32 s74, 0")
     e("s_cbranch_scc1 3f")
+    if "store" in OFF:
+        e("s_branch 3f")
     # lane offset: (4 (lane >> 5)) rows + (lane & 31) columns; the result sets are free now
     e("v_mbcnt_lo_u32_b32 v64, -1, 0")
     e("v_mbcnt_hi_u32_b32 v64, -1, v64")
@@ -291,13 +305,23 @@ def generate():
     return e.lines
 
 
+EXPERIMENTS = {1: {"dma"}, 2: {"lds"}, 3: {"dma", "lds"}, 4: {"barrier"}, 5: {"fold"}, 6: {"store"}, 7: {"dma", "lds", "barrier", "store"},
+               8: {"dma", "store"}, 9: {"dma", "lds", "barrier", "store", "salu"}, 10: {"dma", "lds", "store", "salu"}}
+
+
 def main():
-    global MODE
+    global MODE, OFF
     out = sys.argv[1] if len(sys.argv) > 1 else "clover_amd/csrc/gemm6_loop256.inc"
+    experiments = len(sys.argv) > 2 and sys.argv[2] == "experiments"
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_gemm6_loop256.py -- do not edit; see that file for the schedule and the register map.\n")
-        for name, mode in (("G6T_LOOP_ASM", "scaled"), ("G6T_LOOP_ASM_I32", "i32")):
-            MODE = mode
+        todo = [("G6T_LOOP_ASM", "scaled", set()), ("G6T_LOOP_ASM_I32", "i32", set())]
+        if experiments:
+            f.write("#define G6T_LOOP_EXPERIMENTS 1\n")
+            for v, off in EXPERIMENTS.items():
+                todo += [(f"G6T_LOOP_ASM_V{v}", "scaled", off), (f"G6T_LOOP_ASM_I32_V{v}", "i32", off)]
+        for name, mode, off in todo:
+            MODE, OFF = mode, off
             lines = generate()
             f.write(f"#define {name} \\\n")
             for ln in lines:
