@@ -16,7 +16,7 @@ timeout 600 python $R/bench.py --preset c5-weak --steps 100 --warmup 10 --no-ext
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/c5 -o b -- python $R/bench.py --preset c5-weak --steps 50 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/prof_$TAG/c5 -name "*.db" | head -1) > $OUT/${TAG}_mvm_c5shard_kernel_stats.txt 2>&1
 # 3. GEMM 8192^3 and the exact dot: kernel statistics
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/gemm -o b -- python $R/tools/gemm_probe.py > /dev/null 2>&1
+GP_CALLS=150 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/gemm -o b -- python $R/tools/gemm_probe.py > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/prof_$TAG/gemm -name "*.db" | head -1) > $OUT/${TAG}_gemm_fp6_8192_kernel_stats.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/dot -o b -- python $R/tools/dot_probe.py > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/prof_$TAG/dot -name "*.db" | head -1) > $OUT/${TAG}_dot_n2p24_kernel_stats.txt 2>&1
