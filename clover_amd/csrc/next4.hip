@@ -116,11 +116,13 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
                 const float kq = 7.0f / m;
                 const uint32_t *W32 = reinterpret_cast<const uint32_t *>(raw + (size_t)(bl * 2) * 4);
                 const uint32_t Wd[2] = {W32[rho], W32[8 + rho]};          // W[j = rho] of draw 0 and draw 1
-                float nz[8];
+                float n0[4], n1[4], nz[8];
+                noise4_of(Wd[0], n0);
+                noise4_of(Wd[1], n1);
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int g = e ^ 1;
-                    nz[e] = noise_of(Wd[g >> 2], g & 3);
+                    nz[e] = (g >> 2) ? n1[g & 3] : n0[g & 3];
                 }
                 const uint32_t packed = quant_pack8(v, kq, nz);
                 if (blk < nblocks) {
@@ -168,11 +170,13 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
                 uint32_t o[4];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
-                    float nz[8];
+                    float n0[4], n1[4], nz[8];
+                    noise4_of(W0[q4], n0);
+                    noise4_of(W1[q4], n1);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const int g = e ^ 1;
-                        nz[e] = noise_of((g >> 2) ? W1[q4] : W0[q4], g & 3);
+                        nz[e] = (g >> 2) ? n1[g & 3] : n0[g & 3];
                     }
                     o[q4] = quant_pack8(v[q4], kq, nz);
                 }

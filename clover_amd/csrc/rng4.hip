@@ -70,9 +70,9 @@ int clv_rng_tables(RngTables *t)
 // the 4 nibbles of half an output dword with their noise: words W.x..W.w of one draw, byte `sh` (see k_m4_quantize_strip_st)
 __device__ __forceinline__ uint32_t quant_pack4_st(const f32x4 v, float k, const u32x4 W, int sh)
 {
-    const uint32_t h = (((uint32_t)quant1_st(v.x, k, noise_of(W.x, sh)) & 0xFu) << 4) | ((uint32_t)quant1_st(v.y, k, noise_of(W.y, sh)) & 0xFu) |
-                       (((uint32_t)quant1_st(v.z, k, noise_of(W.z, sh)) & 0xFu) << 12) |
-                       (((uint32_t)quant1_st(v.w, k, noise_of(W.w, sh)) & 0xFu) << 8);
+#define ST_PRODUCT(x, w) __builtin_fmaf(x, k, __builtin_copysignf(noise_of(w, sh), x))       /* quant1_st before the conversion */
+    const uint32_t h = pack4_of_products(ST_PRODUCT(v.x, W.x), ST_PRODUCT(v.y, W.y), ST_PRODUCT(v.z, W.z), ST_PRODUCT(v.w, W.w));
+#undef ST_PRODUCT
     return k < __builtin_inff() ? h : 0u;
 }
 

@@ -107,6 +107,20 @@ __device__ __forceinline__ float noise_of(uint32_t W, int sh)
     return (float)(int)(W & mask) * scale;
 }
 
+// all four noises of one word (sh = 0..3), for kernels in which a lane uses every shift of its word: the 0x7F mask once for the
+// word, the two low fields picked by the conversion itself (SDWA source select) -- 6 VALU + 4 multiplies instead of 8 + 4.
+__device__ __forceinline__ void noise4_of(uint32_t W, float n[4])
+{
+    const uint32_t m = W & 0x7F7F7F7Fu;
+    float f2, f3;
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f2) : "v"(m));
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(f3) : "v"(m));
+    n[0] = (float)(int)m * __uint_as_float(96u << 23);                    // 2^-31
+    n[1] = (float)(int)(m & 0x00FFFFFFu) * __uint_as_float(104u << 23);   // 2^-23
+    n[2] = f2 * __uint_as_float(112u << 23);                              // 2^-15
+    n[3] = f3 * __uint_as_float(120u << 23);                              // 2^-7
+}
+
 // generate the two draws of `nblk` consecutive blocks for generator lane k and store the raw 64-bit outputs
 // at raw[(blk*2 + draw)*4 + k]  (so W[2k], W[2k+1] of a draw are the two dwords of entry k)
 __device__ __forceinline__ uint64_t gen_blocks(uint64_t a, int nblk, uint64_t *raw, int k)
