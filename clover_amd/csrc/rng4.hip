@@ -239,63 +239,79 @@ __global__ __launch_bounds__(256) void k_m4_quantize_st(const float *__restrict_
 // strip form of the same (see k_m4_quantize_strip, matrix4.hip): workgroup = 64 rows x 4 tiles side by side.  Wave w
 // generates the draws of tile bj = 4 sj + w -- stream position t = bj * tiles_y + bi, all four generator lanes -- and
 // every lane then reads the 16 bytes of noise words its four elements of a row need.
+//
+// NV = tiles a workgroup takes one BELOW the other (consecutive bi of one bj are consecutive in the stream).  The generator set-up
+// of a wave -- 4 jump-aheads T^(128 t) (~220 VALU) and one GF(2) product per generator lane for its segment start (9 VALU each) --
+// was ~60 % of the kernel's instructions with one tile per wave (32 lanes generate 16 draws each).  With NV = 2 the 64 lanes of a
+// wave generate 16 segments of 8 rows, the jump-ahead is paid once per two tiles and the generation itself runs at full width.
+template <int NV>
 __global__ __launch_bounds__(256) void k_m4_quantize_strip_st(const float *__restrict__ A, uint64_t cols, uint32_t *__restrict__ q,
                                                               float *__restrict__ s, uint32_t strips_x, uint32_t tiles_x, uint64_t tiles_y,
                                                               uint64_t *state, uint64_t seq, RngTables T)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t raw[4][64 * 2 * 4];       // per tile: 64 rows x 2 draws x 4 lanes
-    __shared__ float sh[4][4];
+    __shared__ __attribute__((aligned(16))) uint64_t raw[4][NV * 64 * 2 * 4];  // per tile column: NV x 64 rows x 2 draws x 4 lanes
+    __shared__ float sh[NV][4][4];
     const uint32_t sj = blockIdx.x % strips_x;
-    const uint64_t bi = blockIdx.x / strips_x;
+    const uint64_t bi0 = (uint64_t)(blockIdx.x / strips_x) * NV;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t col = (uint64_t)sj * 256 + 4 * lane;
     const bool live = col < cols;
-    const uint64_t row0 = bi * 64 + wave * 16;
 
-    // the loads first: the generator work below overlaps their latency
+    // the loads of the first tile row first: the generator work below overlaps their latency
     f32x4 v[16];
 #pragma unroll
     for (int r = 0; r < 16; r++)
-        v[r] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(A + (row0 + r) * cols + col)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        v[r] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(A + (bi0 * 64 + wave * 16 + r) * cols + col)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    SegRows<8> segs;
+    SegRows<8 * NV> segs;
     segs.load(T.seg_rows, 0);
     const int slot = rng_read_slot(state, seq);
     uint64_t a0[4], b[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) a0[k] = state[slot * RNG_SLOT_WORDS + 4 + k];
-    const uint64_t bj = (uint64_t)sj * 4 + wave;                      // this wave's tile (may lie beyond the matrix: then unused)
-    const uint64_t t = bj * tiles_y + bi;
+    const uint64_t bj = (uint64_t)sj * 4 + wave;                      // this wave's tile column (may lie beyond the matrix: then unused)
+    const uint64_t t = bj * tiles_y + bi0;
 #pragma unroll
     for (int k = 0; k < 4; k++) b[k] = wave_pow_apply(T.pow_rows, a0[k], bj < tiles_x ? t : 0, 7);      // tile = 64 rows = 2^7 draws
     const uint64_t st = segs.starts_from(b);
-    if (lane < 32) gen_blocks(st, 8, raw[wave] + (size_t)(8 * (lane >> 2)) * 8, lane & 3);
+    if (lane < 32 * NV) gen_blocks(st, 8, raw[wave] + (size_t)(8 * (lane >> 2)) * 8, lane & 3);
     const uint64_t a0w = wave == 0 ? a0[0] : wave == 1 ? a0[1] : wave == 2 ? a0[2] : a0[3];
     rng_commit(state, seq, slot, T.pow_rows, a0w, (uint64_t)tiles_x * tiles_y * 128);
 
-    float m = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-        m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v[r].x), __builtin_fabsf(v[r].y)), fmaxf(__builtin_fabsf(v[r].z), __builtin_fabsf(v[r].w))));
-    m = row16_max(m);
-    if ((lane & 15) == 0) sh[wave][lane >> 4] = m;
-    __syncthreads();                                               // tile maxima and every tile's draws are in LDS
     const int tl = lane >> 4;
-    m = fix_zero_max(fmaxf(fmaxf(sh[0][tl], sh[1][tl]), fmaxf(sh[2][tl], sh[3][tl])));
-    const float k = 7.0f / m;
-    if (wave == 0 && (lane & 15) == 0 && live) s[bi * tiles_x + sj * 4 + tl] = m;
     // elements 4c..4c+3 of a tile row (c = lane & 15): noise group g = c >> 1 (draw g >> 2, byte g & 3), words W[4 (c & 1) .. +3]
     const int c = lane & 15, g = c >> 1;
-    const u32x4 *noise = reinterpret_cast<const u32x4 *>(raw[tl]) + (g >> 2) * 2 + (c & 1);     // + 4 per tile row
     const int odd = lane & 1;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const int tr = wave * 16 + r;                              // tile row = stream block within the tile
-        const uint32_t h0 = quant_pack4_st(v[r], k, noise[4 * tr], g & 3), h1 = quant_pack4_st(v[r + 1], k, noise[4 * (tr + 1)], g & 3);
-        const uint32_t give = odd ? h0 : h1;
-        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-        const uint32_t word = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
-        if (live) __builtin_nontemporal_store(word, &q[((row0 + r + odd) * cols + (col & ~7ull)) / 8]);
+    for (int i = 0; i < NV; i++) {
+        const uint64_t bi = bi0 + i;
+        if (bi >= tiles_y) break;                                      // odd tile count: the last workgroup row has one tile
+        const uint64_t row0 = bi * 64 + wave * 16;
+        if (i > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(A + (row0 + r) * cols + col)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        float m = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v[r].x), __builtin_fabsf(v[r].y)), fmaxf(__builtin_fabsf(v[r].z), __builtin_fabsf(v[r].w))));
+        m = row16_max(m);
+        if ((lane & 15) == 0) sh[i][wave][lane >> 4] = m;
+        __syncthreads();                                               // tile maxima (and, the first time, every tile's draws) are in LDS
+        m = fix_zero_max(fmaxf(fmaxf(sh[i][0][tl], sh[i][1][tl]), fmaxf(sh[i][2][tl], sh[i][3][tl])));
+        const float k = 7.0f / m;
+        if (wave == 0 && (lane & 15) == 0 && live) s[bi * tiles_x + sj * 4 + tl] = m;
+        const u32x4 *noise = reinterpret_cast<const u32x4 *>(raw[tl] + (size_t)i * 64 * 8) + (g >> 2) * 2 + (c & 1);     // + 4 per tile row
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int tr = wave * 16 + r;                              // tile row = stream block within the tile
+            const uint32_t h0 = quant_pack4_st(v[r], k, noise[4 * tr], g & 3), h1 = quant_pack4_st(v[r + 1], k, noise[4 * (tr + 1)], g & 3);
+            const uint32_t give = odd ? h0 : h1;
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+            const uint32_t word = odd ? (recv | (h1 << 16)) : (h0 | (recv << 16));
+            if (live) __builtin_nontemporal_store(word, &q[((row0 + r + odd) * cols + (col & ~7ull)) / 8]);
+        }
     }
 }
 
@@ -351,8 +367,13 @@ int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_
     static const bool tile_kernel = getenv("CLV_M4Q_TILE") != nullptr;       // A/B switch: the older one-tile-per-workgroup kernel
     if (!tile_kernel) {
         const uint32_t strips_x = (uint32_t)((cols + 255) / 256);
-        hipLaunchKernelGGL(k_m4_quantize_strip_st, dim3((unsigned)((rows / 64) * strips_x)), dim3(256), 0, st, A, cols, (uint32_t *)q, s,
-                           strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_next_seq(), T);
+        static const bool one_tile = getenv("CLV_M4Q_NV1") != nullptr;       // A/B switch: one tile row per workgroup
+        if (one_tile || rows / 64 < 2)
+            hipLaunchKernelGGL(k_m4_quantize_strip_st<1>, dim3((unsigned)((rows / 64) * strips_x)), dim3(256), 0, st, A, cols, (uint32_t *)q, s,
+                               strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_next_seq(), T);
+        else
+            hipLaunchKernelGGL(k_m4_quantize_strip_st<2>, dim3((unsigned)(((rows / 64 + 1) / 2) * strips_x)), dim3(256), 0, st, A, cols, (uint32_t *)q,
+                               s, strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_next_seq(), T);
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }

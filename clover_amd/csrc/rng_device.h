@@ -59,7 +59,21 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 // bit j of M*v for the lane holding row j of M; the ballot of it over the wave is M*v
 __device__ __forceinline__ uint64_t wave_matvec(uint64_t row, uint64_t v)
 {
-    return __ballot(__popcll(row & v) & 1);
+    // parity(row & v) = parity((row.lo & v.lo) ^ (row.hi & v.hi)): one popcount instead of two (v_and, v_bitop3, v_bcnt, v_and, v_cmp)
+    const uint32_t x = ((uint32_t)row & (uint32_t)v) ^ ((uint32_t)(row >> 32) & (uint32_t)(v >> 32));
+    return __ballot(__builtin_popcount(x) & 1);
+}
+// the same, with the product written into lane DST of (lo, hi): v_writelane takes the ballot straight from its SGPR pair -- no lane
+// compare, no selects.  DST is an immediate: a second SGPR beside the ballot would break the one-constant-bus-read rule.
+template <int DST>
+__device__ __forceinline__ void wave_matvec_to_lane(uint64_t row, uint64_t v, uint32_t &lo, uint32_t &hi)
+{
+    const uint64_t r = wave_matvec(row, v);
+    // gfx940+: a VALU that reads an SGPR needs two wait states behind the VALU that wrote it (here: v_cmp -> VCC); hipcc inserts
+    // them for its own instructions, not inside an asm statement
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)r), "s"((uint32_t)(r >> 32)), "n"(DST));
 }
 
 // Whole-wave form: T^(e << k0)(v) for wave-uniform v and e.  Lane j holds ROW j of the level's matrix, so bit j of
@@ -192,20 +206,20 @@ struct SegRows {
         for (int k = 0; k < 4; k++) b[k] = uniform64(lds_base[k]);
         return starts_from(b);
     }
+    template <int I>
+    __device__ __forceinline__ void fill(const uint64_t (&b)[4], uint32_t &lo, uint32_t &hi) const
+    {
+        if constexpr (I < 4 * NSEG) {
+            wave_matvec_to_lane<I>(R[I / 4], b[I % 4], lo, hi);
+            fill<I + 1>(b, lo, hi);
+        }
+    }
     // b[k]: wave-uniform base of generator lane k
     __device__ __forceinline__ uint64_t starts_from(const uint64_t (&b)[4]) const
     {
-        const int lane = threadIdx.x & 63;
-        uint64_t a = 0;
-#pragma unroll
-        for (int s = 0; s < NSEG; s++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t v = wave_matvec(R[s], b[k]);
-                a = (lane == 4 * s + k) ? v : a;
-            }
-        }
-        return a;
+        uint32_t lo = 0, hi = 0;
+        fill<0>(b, lo, hi);
+        return ((uint64_t)hi << 32) | lo;
     }
 };
 
