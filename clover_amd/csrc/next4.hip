@@ -4,6 +4,8 @@
 // (test/performance/01_measure.h:923-946, 999-1021), so x, t1..t3 can stay in HBM across iterations.
 #include "rng_device.h"
 
+#include <type_traits>
+
 // =================================================================================================
 // f1  CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478):  r = quantize(u + a * v), per 64-block
 //     val = fma((float)qv, f32(f32(sv*a)/7), (float)qu * f32(su/7));  lane = 4 dwords (half a block) of u and of v.
@@ -1141,6 +1143,7 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
     for (uint64_t c0 = 0; c0 < cols; c0 += MVF_CHUNK) {
         const uint32_t cw = (uint32_t)((cols - c0) < MVF_CHUNK ? (cols - c0) : MVF_CHUNK);
         if (c0) __syncthreads();
+        int fast;
         {   // stage x and s/7: all loads first (one round trip), then the LDS writes
             constexpr int NX = MVF_CHUNK / 4 / 256;                       // 16 x 16 B per thread
             f32x4 xr[NX];
@@ -1151,34 +1154,51 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
 #pragma unroll
             for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) reinterpret_cast<f32x4 *>(mvf_x)[i] = xr[k]; }
             if (tid < nb) s7[tid] = sv / 7.0f;
+            fast = tid >= nb || sixteenth_is_exact(sv / 7.0f);
         }
-        __syncthreads();
+        // the barrier the staging needs anyway also tells whether every block factor c of the chunk survives a division by 16
+        // exactly: then the nibbles are taken as 16 q (one SDWA conversion each, common.h) and (16 q) * (c / 16) rounds like q * c
+        fast = __builtin_amdgcn_readfirstlane(__syncthreads_and(fast));      // scalar: a real branch, not two predicated bodies
         const u32x4 *Ap = Arow + c0 / 32;
         const uint32_t ngroups = cw / 128;                                // 16 words = 128 columns per quad and step
         constexpr int U = 4;
-        auto group = [&](const u32x4 av, uint32_t g) {
-            uint32_t w[4] = {av.x, av.y, av.z, av.w};
-            quad_transpose4(w[0], w[1], w[2], w[3], a);                   // words a, 4+a, 8+a, 12+a of group g
+        // FAST: every block factor c of the chunk survives c / 16 exactly (see the barrier above)
+        auto chunk = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            auto group = [&](const u32x4 av, uint32_t g) {
+                uint32_t w[4] = {av.x, av.y, av.z, av.w};
+                quad_transpose4(w[0], w[1], w[2], w[3], a);                   // words a, 4+a, 8+a, 12+a of group g
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t wi = 16 * g + 4 * i + a;                   // word index inside the chunk
-                const float sc = s7[wi >> 3];
-                const f32x4 xl = reinterpret_cast<const f32x4 *>(mvf_x)[2 * wi];
-                const f32x4 xh = reinterpret_cast<const f32x4 *>(mvf_x)[2 * wi + 1];
-                const float xv[8] = {xl.x, xl.y, xl.z, xl.w, xh.x, xh.y, xh.z, xh.w};
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t wi = 16 * g + 4 * i + a;                   // word index inside the chunk
+                    const float sc = s7[wi >> 3];
+                    const f32x4 xl = reinterpret_cast<const f32x4 *>(mvf_x)[2 * wi];
+                    const f32x4 xh = reinterpret_cast<const f32x4 *>(mvf_x)[2 * wi + 1];
+                    const float xv[8] = {xl.x, xl.y, xl.z, xl.w, xh.x, xh.y, xh.z, xh.w};
+                    if constexpr (FAST) {
+                        const float sc16 = sc * 0.0625f;
+                        float f16[8];
+                        unpack8_x16(w[i], f16);
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(xv[j], (float)unpack1(w[i], j) * sc, acc[j]);     // rounded product first
+                        for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(xv[j], f16[j] * sc16, acc[j]);     // rounded product first
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(xv[j], (float)unpack1(w[i], j) * sc, acc[j]);
+                    }
+                }
+            };
+            uint32_t g = 0;
+            for (; g + U <= ngroups; g += U) {
+                u32x4 av[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) av[u] = NT ? __builtin_nontemporal_load(&Ap[4 * (g + u) + a]) : Ap[4 * (g + u) + a];
+#pragma unroll
+                for (int u = 0; u < U; u++) group(av[u], g + u);
             }
+            for (; g < ngroups; g++) group(NT ? __builtin_nontemporal_load(&Ap[4 * g + a]) : Ap[4 * g + a], g);
         };
-        uint32_t g = 0;
-        for (; g + U <= ngroups; g += U) {
-            u32x4 av[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) av[u] = NT ? __builtin_nontemporal_load(&Ap[4 * (g + u) + a]) : Ap[4 * (g + u) + a];
-#pragma unroll
-            for (int u = 0; u < U; u++) group(av[u], g + u);
-        }
-        for (; g < ngroups; g++) group(NT ? __builtin_nontemporal_load(&Ap[4 * g + a]) : Ap[4 * g + a], g);
+        if (fast) chunk(std::true_type{});
+        else chunk(std::false_type{});
     }
     // (acc1 + acc2) + (acc3 + acc4) per AVX lane j, then the CloverBase.h:149-157 tree over the 8 lanes
     float s3[8];

@@ -230,6 +230,22 @@ def test_gpu_mixed_mvm_f32_bit_exact(hip, oracle, shape):
 
 
 @pytest.mark.gpu
+def test_gpu_mixed_mvm_f32_tiny_and_huge_scales(hip, oracle):
+    """scales at both ends of the fp32 range: the kernel's 16 q / (c / 16) form must step aside where c / 16 would be a denormal
+    (a whole 16384-column chunk then takes the plain form), and the result must not change"""
+    M, N = 128, 16384 + 256
+    rng = np.random.default_rng(77)
+    qA, _ = random_packed(rng, M * N)
+    sA = rng.uniform(0.5, 2, size=(M // 64) * (N // 64)).astype(np.float32)
+    sA[3] = np.float32(1e-37)            # f32(s / 7) / 16 is a denormal: first chunk, first row group
+    sA[(N // 64) + 5] = np.float32(3e-38)
+    sA[N // 64 - 1] = np.float32(1e37)   # second chunk (plain scales around it)
+    x = rng.normal(size=N).astype(np.float32)
+    x[200:260] *= np.float32(1e30)       # the tiny blocks' products are visible in the sum
+    assert same(hip.m4_mvm_f32(qA, sA, M, N, x), oracle.m4_mvm_f32(qA, sA, M, N, x))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 65536 + 128)])
 @pytest.mark.parametrize("stochastic", [False, True])
 def test_gpu_fused_mvm_scale_and_add_equals_the_two_calls(hip, oracle, shape, stochastic):
