@@ -242,16 +242,32 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
 #define TR_T 256                      // tile edge in elements
 #define TR_W (TR_T / 8)               // 32 words per tile row
 #define TR_S (TR_W + 1)               // padded LDS row stride in words
+#ifndef TR_BH
+#define TR_BH 8                      // tiles per XCD block: BH x BW (4x8: 0.214 ms, 8x8: 0.20-0.21, 16x8: 0.21, 8x16: 0.22, 2x16: 0.23 at 32768^2)
+#define TR_BW 8
+#endif
 
 __global__ __launch_bounds__(256) void k_m4_transpose(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t rows,
                                                       uint64_t cols, uint32_t *__restrict__ qt, float *__restrict__ st,
                                                       uint32_t tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tr_lds[];
-    uint32_t *tin = tr_lds;                       // [256][33]
-    uint32_t *tout = tr_lds + TR_T * TR_S;        // [256][33]
-    const uint32_t bj = blockIdx.x % tiles_x;
-    const uint64_t bi = blockIdx.x / tiles_x;
+    uint32_t *tin = tr_lds;                       // [256][33]: the input tile, then (in place) the output tile
+    uint32_t *tout = tr_lds;
+    // Tile order: workgroups are dealt to the 8 XCDs round-robin; the workgroups that run together on one XCD take 4 x 8 blocks of
+    // tiles, so that what goes through that L2 at one time is 1 KiB of every input row and 512 B of every output row, not 128 B.
+    uint32_t bj = blockIdx.x % tiles_x;
+    uint64_t bi = blockIdx.x / tiles_x;
+    {
+        const uint32_t ntiles = gridDim.x, tiles_y = ntiles / tiles_x;
+        constexpr uint32_t BH = TR_BH, BW = TR_BW;
+        if (ntiles % 8 == 0 && tiles_x % BW == 0 && tiles_y % BH == 0) {
+            const uint32_t t = (blockIdx.x & 7) * (ntiles / 8) + (blockIdx.x >> 3);
+            const uint32_t blk = t / (BH * BW), in = t % (BH * BW), bx = tiles_x / BW;
+            bi = (uint64_t)(blk / bx) * BH + in / BW;
+            bj = (blk % bx) * BW + in % BW;
+        }
+    }
     const int tid = threadIdx.x;
     const uint64_t wcols = cols / 8, wrows = rows / 8;
     const uint64_t r0 = bi * TR_T, c0w = (uint64_t)bj * TR_W;       // tile origin: row, word column
@@ -265,19 +281,27 @@ __global__ __launch_bounds__(256) void k_m4_transpose(const uint32_t *__restrict
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
-    // 2. 8x8 nibble blocks: block (bg, w) = rows 8bg..8bg+7, word w.  lanes: w_lo = tid&7, bg_lo = (tid>>3)&3
+    // 2. 8x8 nibble blocks: block (bg, w) = rows 8bg..8bg+7, word w.  lanes: w_lo = tid&7, bg_lo = (tid>>3)&3.  All four blocks of
+    //    a thread are read into registers before anything is written back: ONE tile buffer (33 KiB, four workgroups per CU
+    //    instead of two with separate in / out buffers)
+    uint32_t wd[4][8];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int w = (tid & 7) + 8 * ((tid >> 5) & 3);
         const int bg = ((tid >> 3) & 3) + 4 * ((tid >> 7) + 2 * k);
-        uint32_t wd[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) wd[r] = tin[(8 * bg + r) * TR_S + w];
+        for (int r = 0; r < 8; r++) wd[k][r] = tin[(8 * bg + r) * TR_S + w];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int w = (tid & 7) + 8 * ((tid >> 5) & 3);
+        const int bg = ((tid >> 3) & 3) + 4 * ((tid >> 7) + 2 * k);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             uint32_t acc = 0;
 #pragma unroll
-            for (int r = 0; r < 8; r++) acc |= ((wd[r] >> nib_shift(e)) & 0xFu) << nib_shift(r);
+            for (int r = 0; r < 8; r++) acc |= ((wd[k][r] >> nib_shift(e)) & 0xFu) << nib_shift(r);
             tout[(8 * w + e) * TR_S + bg] = acc;
         }
     }
@@ -332,8 +356,7 @@ extern "C" int clm4_transpose(const int8_t *q, const float *s, uint64_t rows, ui
     if (rows % TR_T == 0 && cols % TR_T == 0) {
         const uint64_t tiles = (rows / TR_T) * (cols / TR_T);
         CLV_REQUIRE(tiles <= 0x7FFFFFFFull, "clm4_transpose: too many tiles");
-        const size_t lds = 2 * TR_T * TR_S * sizeof(uint32_t);                 // 66 KiB: above the 64 KiB default
-        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t lds = TR_T * TR_S * sizeof(uint32_t);                     // 33 KiB
         hipLaunchKernelGGL(k_m4_transpose, dim3((unsigned)tiles), dim3(256), lds, as_stream(stream), (const uint32_t *)q, s, rows, cols,
                            (uint32_t *)qt, st, (uint32_t)(cols / TR_T));
     } else {

@@ -107,8 +107,9 @@ def test_gpu_scale_and_add_stochastic_same_stream(hip, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(128, 128), (128, 384), (640, 256), (1024, 2048)])
+@pytest.mark.parametrize("shape", [(128, 128), (128, 384), (640, 256), (1024, 2048), (2048, 4096), (4096, 2048), (2304, 2048)])
 def test_gpu_transpose_exact(hip, oracle, shape):
+    # from 2048 x 2048 (8 x 8 tiles of 256) on, the kernel walks the tiles in per-XCD 8 x 8 blocks; 2304 rows: plain order again
     M, N = shape
     rng = np.random.default_rng(M + N)
     q, _ = random_packed(rng, M * N)
