@@ -504,7 +504,13 @@ static int gemm_fp6_run(const clm4_gemm_operand *opA, const int8_t *A, const flo
 #endif
 #define G6T_LAUNCH(I, V)                                                                                                                   \
     do {                                                                                                                                   \
-        CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6_t256<I, V>, hipFuncAttributeMaxDynamicSharedMemorySize, G6T_LDS_BYTES));     \
+        static bool attr_set[64] = {};         /* once per device: the attribute call costs host time on every launch otherwise */         \
+        int dev = 0;                                                                                                                       \
+        CLV_HIP(hipGetDevice(&dev));                                                                                                       \
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                                      \
+            CLV_HIP(hipFuncSetAttribute((const void *)k_m4_gemm_fp6_t256<I, V>, hipFuncAttributeMaxDynamicSharedMemorySize, G6T_LDS_BYTES)); \
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                                \
+        }                                                                                                                                  \
         hipLaunchKernelGGL((k_m4_gemm_fp6_t256<I, V>), dim3(grid256), dim3(1024), G6T_LDS_BYTES, st, A6, sA, B6, sB, M, N, K, (float *)C, tm, \
                            tn, s0, ns);                                                                                                    \
     } while (0)
