@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <string.h>
 
 #include <vector>
 
@@ -84,6 +85,10 @@ struct clm4_shard_ctx {
     int ndev = 0;
     bool loopback = false;                  // some device listed twice: exchanges are plain copies, no RCCL (test layout)
     bool equal = false;                     // all shards have the same number of rows: the gather is one ncclAllGather pair
+    bool use_rccl = false;                  // exchanges go through RCCL: more than one device -- or ONE device under
+                                            // CLV_SHARDED_RCCL_SELFTEST=1 (a communicator of one rank: the same calls, groups and in-place
+                                            // buffers as on a node, so that the RCCL path has run at least once where only one GPU exists);
+                                            // CLV_SHARDED_RCCL_SELFTEST=ragged takes the per-owner broadcast form instead of the all-gather
     std::vector<hipEvent_t> ev;             // 3 per shard: before the kernel, after it, after the gather
     int rccl_ranks = 0;                     // communicator size RCCL reports having built (0: no communicator)
     uint64_t rows = 0, cols = 0;
@@ -172,7 +177,10 @@ extern "C" int clm4_sharded_create(clm4_shard_ctx **out, int ndev, const int *de
         }
     }
     c->equal = (rows / 64) % (uint64_t)ndev == 0;
-    if (rc == CLV_OK && ndev > 1 && !c->loopback) {
+    const char *selftest = getenv("CLV_SHARDED_RCCL_SELFTEST");
+    c->use_rccl = !c->loopback && (ndev > 1 || (selftest && selftest[0] && selftest[0] != '0'));
+    if (c->use_rccl && ndev == 1 && !strcmp(selftest, "ragged")) c->equal = false;
+    if (rc == CLV_OK && c->use_rccl) {
         if (!rccl()->ok) {
             clv_set_error("clm4_sharded_create: librccl.so could not be loaded");
             rc = CLV_ERR_UNSUPPORTED;
@@ -235,7 +243,7 @@ extern "C" int clm4_sharded_fill_random(clm4_shard_ctx *c, uint64_t seed)
 // replicate `bytes` at p[0] (already enqueued on st[0]) to p[d] for every shard
 static int replicate_from_0(clm4_shard_ctx *c, void *const *p, uint64_t bytes)
 {
-    if (c->ndev == 1) return CLV_OK;
+    if (c->ndev == 1 && !c->use_rccl) return CLV_OK;
     if (c->loopback) {
         // same-process test layout: order the copies behind shard 0's stream with an event
         CLV_HIP(hipSetDevice(c->dev[0]));
@@ -292,7 +300,7 @@ extern "C" int clm4_sharded_mvm(clm4_shard_ctx *c, const int8_t *x, const float 
                 CLV_HIP(hipMemcpyAsync(c->sr[d] + c->row_begin[o] / 64, c->sr[o] + c->row_begin[o] / 64, c->row_count[o] / 16, hipMemcpyDeviceToDevice, c->st[d]));
             }
         }
-    } else if (n > 1 && c->equal) {
+    } else if (c->use_rccl && c->equal) {
         // in place: rank d's contribution already sits at offset d * count of its receive buffer
         const uint64_t rc_rows = c->row_count[0];
         RcclGroup g;
@@ -302,7 +310,7 @@ extern "C" int clm4_sharded_mvm(clm4_shard_ctx *c, const int8_t *x, const float 
             CLV_NCCL(rccl()->AllGather(c->sr[d] + c->row_begin[d] / 64, c->sr[d], rc_rows / 64, ncclFloat32, c->comm[d], c->st[d]));
         }
         CLV_NCCL(g.end());
-    } else if (n > 1) {
+    } else if (c->use_rccl) {
         RcclGroup g;
         CLV_NCCL(g.start());
         for (int root = 0; root < n; root++)

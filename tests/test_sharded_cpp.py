@@ -34,6 +34,20 @@ def test_sharded_cpp_all_layouts_equal_unsharded(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "ragged"])
+def test_sharded_cpp_through_rccl_with_a_communicator_of_one_rank(tmp_path, mode):
+    """CLV_SHARDED_RCCL_SELFTEST: the node layout (one GPU here) takes the RCCL path -- librccl dlopen'ed, ncclCommInitAll, the
+    grouped broadcast of x, the in-place ncclAllGather pair ("1") or the per-owner broadcasts ("ragged") -- with a communicator of
+    one rank, and must still equal the unsharded call.  What an 8-GPU node adds is more ranks, not other calls."""
+    import os
+    env = dict(os.environ, CLV_SHARDED_RCCL_SELFTEST=mode)
+    p = subprocess.run([str(_build(tmp_path))], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "sharded all ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
+    node = [ln for ln in p.stdout.splitlines() if ln.startswith("node ")][0]
+    assert "rccl_ranks=1" in node and (f"equal={1 if mode == '1' else 0}" in node), node
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("blocks", [1, 3, 7, 13])
 def test_mvm_family_accepts_odd_64_row_shards(hip, oracle, blocks):
     """a shard with an odd number of 64-row blocks (rows % 128 != 0) must go through clm4_mvm / clm4_rowdots /
