@@ -68,6 +68,26 @@ __device__ __forceinline__ int dot32(const u32x4 &a, const u32x4 &b)
     return sdot8(a.w, b.w, s);
 }
 
+// x / 7.0f, correctly rounded, in 4 VALU instead of the ~12 of the IEEE division sequence (v_div_scale x2, v_rcp, 4 fma,
+// v_div_fmas, v_div_fixup): q = x * c; r = fma(-7, q, x) (exact residual); q += r * c -- the classic division by a constant
+// known in advance (Brisebarre, Muller, Raina 2004).  Checked EXHAUSTIVELY against x / 7.0f for all 2^32 bit patterns
+// (tools/check_div7.c): identical for every finite x except x = -0 (gives +0), which the sign copy at the end repairs.
+__device__ __forceinline__ float div7(float x)
+{
+    const float c = 1.0f / 7.0f;
+    const float q = x * c;
+    const float r = __builtin_fmaf(-7.0f, q, x);
+    return __builtin_copysignf(__builtin_fmaf(r, c, q), x);
+}
+// the same for CloverVector8's x / 127.0f (checked the same way: tools/check_div7.c 127)
+__device__ __forceinline__ float div127(float x)
+{
+    const float c = 1.0f / 127.0f;
+    const float q = x * c;
+    const float r = __builtin_fmaf(-127.0f, q, x);
+    return __builtin_copysignf(__builtin_fmaf(r, c, q), x);
+}
+
 // 0 -> 1.0 on the bit pattern (CloverVector4.h:661-663)
 __device__ __forceinline__ float fix_zero_max(float m)
 {

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * L) void k_m4_mvm64(const uint8_t *__restrict__
         float m;
         const int qv = requantize_wave(dsh[tid], noise, r ? r + rb * 8 : nullptr, r ? sr + rb : nullptr, &m);
         if (FUSE) {
-            const float su7 = fuse_s / 7.0f, sv7 = (m * fuse.a) / 7.0f;
+            const float su7 = div7(fuse_s), sv7 = div7(m * fuse.a);
             const float val = __builtin_fmaf((float)qv, sv7, (float)unpack1(fuse_w, tid & 7) * su7);
             float noise2 = 0.0f;
             if (ST) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_m4_restore(const uint32_t *__restrict__
     for (int j = 0; j < 4; j++) {
         const uint64_t f = f0 + 64 * j + lane;
         const uint32_t hw = wd[j] >> (16 * (lane & 1));         // the 4 nibbles of this half (f and lane have the same parity)
-        const float k = sc[j] / 7.0f;
+        const float k = div7(sc[j]);
         f32x4 v;
         v.x = (float)(((int)(hw << 24)) >> 28) * k;
         v.y = (float)(((int)(hw << 28)) >> 28) * k;

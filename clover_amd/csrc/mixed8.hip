@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_v8_restore(const uint32_t *__restrict__
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint64_t f = f0 + 64 * j + lane;
-        const float k = sc[j] / 127.0f;
+        const float k = div127(sc[j]);
         f32x4 v;
         v.x = (float)((int)(w[j] << 24) >> 24) * k;
         v.y = (float)((int)(w[j] << 16) >> 24) * k;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_v8_scale_and_add(const u32x4 *qu, const
         const u32x4 wu = NT ? __builtin_nontemporal_load(qu + i) : qu[i];
         const u32x4 wv = NT ? __builtin_nontemporal_load(qv + i) : qv[i];
         float v[16];
-        float m = saa8_values(wu, wv, su[b] / 127.0f, (sv[b] * a) / 127.0f, v);
+        float m = saa8_values(wu, wv, div127(su[b]), div127(sv[b] * a), v);
         m = fmaxf(m, __shfl_xor(m, 1));
         m = fmaxf(m, __shfl_xor(m, 2));
         m = fix_zero_max(m);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_v8_scale_and_add_st(const u32x4 *qu, co
             const int bl = 16 * u + (lane >> 2);
             const uint64_t blk = bl < Sh::NBR ? Sh::block(blk0, rr, bl) : nblocks;
             float v[16];
-            float m = saa8_values(wu[u], wv[u], fu[u] / 127.0f, (fv[u] * a) / 127.0f, v);
+            float m = saa8_values(wu[u], wv[u], div127(fu[u]), div127(fv[u] * a), v);
             m = fmaxf(m, __shfl_xor(m, 1));
             m = fmaxf(m, __shfl_xor(m, 2));
             m = fix_zero_max(m);
@@ -353,7 +353,7 @@ __device__ __forceinline__ void mvm8_epilogue(const Mvm8Tail &t, uint64_t rb, in
         }
         if (FUSE) {
             // CloverVector8::scaleAndAdd on this block (CloverVector8.h:1089-1358); element l: draw l>>5, byte l&3, word (l&31)>>2
-            const float val = __builtin_fmaf((float)qv, (mx * fuse.a) / 127.0f, (float)fuse_q * (fuse_s / 127.0f));
+            const float val = __builtin_fmaf((float)qv, div127(mx * fuse.a), (float)fuse_q * div127(fuse_s));
             float noise2 = 0.0f;
             if (ST) noise2 = noise_of(reinterpret_cast<const uint32_t *>(t.raw2 + (size_t)(tid >> 5) * 4)[(tid & 31) >> 2], tid & 3);
             float m2 = wave_max(__builtin_fabsf(val));

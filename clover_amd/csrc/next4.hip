@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const
         const uint64_t b = i >> 1;
         const u32x4 wu = NT ? __builtin_nontemporal_load(qu + i) : qu[i];
         const u32x4 wv = NT ? __builtin_nontemporal_load(qv + i) : qv[i];
-        const float su7 = su[b] / 7.0f;
-        const float sv7 = (sv[b] * a) / 7.0f;
+        const float su7 = div7(su[b]);
+        const float sv7 = div7(sv[b] * a);
         float v[4][8];
         saa_values(wu.x, wv.x, su7, sv7, v[0]);
         saa_values(wu.y, wv.y, su7, sv7, v[1]);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
                 const int bl = 8 * u + (lane >> 3);
                 const uint64_t blk = Sh::block(blk0, rr, bl);
                 float v[8];
-                saa_values(wu[u], wv[u], fu[u] / 7.0f, (fv[u] * a) / 7.0f, v);
+                saa_values(wu[u], wv[u], div7(fu[u]), div7(fv[u] * a), v);
                 float m = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[e]));
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
             for (int u = 0; u < STEPS4; u++) {
                 const int bl = 32 * u + (lane >> 1);
                 const uint64_t blk = Sh::block(blk0, rr, bl);
-                const float su7 = fu[u] / 7.0f, sv7 = (fv[u] * a) / 7.0f;
+                const float su7 = div7(fu[u]), sv7 = div7(fv[u] * a);
                 float v[4][8];
                 saa_values(wu[u].x, wv[u].x, su7, sv7, v[0]);
                 saa_values(wu[u].y, wv[u].y, su7, sv7, v[1]);
@@ -415,9 +415,9 @@ struct ThreshElems {
     __device__ static __forceinline__ uint32_t mask(int e) { return BITS == 4 ? 0xFu << nib_shift(e) : 0xFFu << (8 * e); }
     __device__ static __forceinline__ uint32_t key(uint32_t w, int e, float sc)
     {
-        if (BITS == 4) return mag_key(w, e, sc / 7.0f);
+        if (BITS == 4) return mag_key(w, e, div7(sc));
         const float q = (float)((int)(w << (24 - 8 * e)) >> 24);
-        return __float_as_uint(__builtin_fabsf(q * sc / 127.0f));
+        return __float_as_uint(__builtin_fabsf(div127(q * sc)));
     }
 };
 
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh_small(uint32_t *__restric
     const uint32_t W = (nwords + TS_THREADS - 1) / TS_THREADS;          // contiguous words per thread: index order = thread order
     const uint32_t w0 = tid * W, w1 = (w0 + W) < nwords ? (w0 + W) : nwords;
     for (uint32_t i = tid; i < nwords; i += TS_THREADS) words[i] = q[i];
-    for (uint32_t i = tid; i < nblocks; i += TS_THREADS) { s7[i] = s[i] / 7.0f; cnt[i] = 0ull; }
+    for (uint32_t i = tid; i < nblocks; i += TS_THREADS) { s7[i] = div7(s[i]); cnt[i] = 0ull; }
     hist[tid] = 0;
     __syncthreads();
 
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void k_th4_cand_hist(const unsigned long long 
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
         const unsigned long long c = cnt[b];
-        const float s7 = s[b] / 7.0f;
+        const float s7 = div7(s[b]);
 #pragma unroll
         for (int m = 0; m <= 8; m++) {
             const uint32_t wgt = (uint32_t)(c >> (7 * m)) & 0x7Fu;
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void k_th4_chunk_ties(const unsigned long long
 {
     __shared__ uint32_t wsum[4];
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t t = b < nblocks ? th4_block_ties(cnt[b], s[b] / 7.0f, ts->tau) : 0u;
+    uint32_t t = b < nblocks ? th4_block_ties(cnt[b], div7(s[b]), ts->tau) : 0u;
     t = wave_scan_incl(t);
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = t;
     __syncthreads();
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void k_th4_apply(u32x4 *__restrict__ q, const 
     const uint32_t tau = ts->tau, keep = ts->ties_keep;
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in = b < nblocks;
-    const float s7 = in ? s[b] / 7.0f : 1.0f;
+    const float s7 = in ? div7(s[b]) : 1.0f;
     const uint32_t mine = in ? th4_block_ties(cnt[b], s7, tau) : 0u;
     const uint32_t incl = wave_scan_incl(mine);
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
@@ -1176,8 +1176,8 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
             const float sv = su[c0 / 64 + (tid < nb ? tid : 0)];
 #pragma unroll
             for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) reinterpret_cast<f32x4 *>(mvf_x)[i] = xr[k]; }
-            if (tid < nb) s7[tid] = sv / 7.0f;
-            fast = tid >= nb || sixteenth_is_exact(sv / 7.0f);
+            if (tid < nb) s7[tid] = div7(sv);
+            fast = tid >= nb || sixteenth_is_exact(div7(sv));
         }
         // the barrier the staging needs anyway also tells whether every block factor c of the chunk survives a division by 16
         // exactly: then the nibbles are taken as 16 q (one SDWA conversion each, common.h) and (16 q) * (c / 16) rounds like q * c

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_v4_restore(const uint32_t *__restrict__
         for (int h = 0; h < 4; h++) {
             const uint64_t i = w + 32 * h + sub;
             const uint32_t hw = wd[h] >> (16 * half);           // the 4 nibbles of this half: elements 4*half .. 4*half+3
-            const float k = sc[h] / 7.0f;
+            const float k = div7(sc[h]);
             f32x4 v;
             v.x = (float)(((int)(hw << 24)) >> 28) * k;         // element 0 of the half: high nibble of byte 0
             v.y = (float)(((int)(hw << 28)) >> 28) * k;
