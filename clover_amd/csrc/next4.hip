@@ -852,13 +852,76 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
 // One pass turns every 64-element block into its 9 magnitude counts (8 bytes); the three radix levels then run over these
 // tables (12 bytes per block instead of 36 bytes of elements, 9 weighted histogram updates per block instead of 64), the tie
 // counts come from the tables as well, and only the final pass touches the elements again: 2 element passes instead of 5.
-__global__ __launch_bounds__(256) void k_th4_count(const u32x4 *__restrict__ q, uint64_t n, unsigned long long *__restrict__ cnt, uint64_t nblocks,
-                                                   uint32_t *hist, ThreshState *ts)
+// Radix levels: 12 + 12 + 8 bits (LEVEL 0 = most significant).  The fixed cost per workgroup of a level (16 KiB of LDS bins to
+// clear and to flush with global atomics, which serialise per address at ~50 ns) is what such a kernel costs, not the 12 bytes per
+// block it reads.  (A variant that let the last workgroup to finish do the selection was 6x slower: its one-ticket-per-workgroup
+// atomic serialises the same way.)
+// elements of block b equal to tau, from its table
+__device__ __forceinline__ uint32_t th4_block_ties(unsigned long long c, float s7, uint32_t tau)
 {
-    if (blockIdx.x == 0) {                                         // also: a clean slate for the selection passes that follow
-        for (int i = threadIdx.x; i < 4096; i += 256) hist[i] = 0;
-        if (threadIdx.x == 0) *ts = ThreshState{0, 0, 0x7F800000u, 0};         // k == 0 keeps this: tau beyond any magnitude, no ties
+    uint32_t t = 0;
+#pragma unroll
+    for (int m = 0; m <= 8; m++) t += cand_key(s7, m) == tau ? (uint32_t)(c >> (7 * m)) & 0x7Fu : 0u;
+    return t;
+}
+
+// ---- round 2: the same algorithm in 6 launches instead of 10 -------------------------------------------------------------------
+// The three one-workgroup select kernels and the one-workgroup scan are gone: every workgroup of a kernel that needs the outcome
+// of an earlier level recomputes it from that level's finished histogram (16 KiB out of L2, one block scan), and the apply kernel
+// adds up the tie counts in front of its chunk itself (group totals + prefixes inside a group).  Each level has its own
+// histogram, zeroed by the first kernel.  Same keys, same selection, same tie rule: results are unchanged bit for bit.
+struct Th4Sel {
+    uint32_t prefix, remaining;
+};
+
+// one 256-thread workgroup: from the top of `hist`, the bin in which the cumulative count reaches `need`
+template <int LEVEL>
+__device__ __forceinline__ Th4Sel th4_wg_select(const uint32_t *__restrict__ hist, uint32_t need, uint32_t prev, uint32_t *sel /* LDS[2] */,
+                                                uint32_t *wsum /* LDS[4] */)
+{
+    constexpr int nb = LEVEL == 2 ? 256 : 4096;
+    constexpr int per = nb / 256;
+    const int t = threadIdx.x;
+    const int top = (255 - t) * per + per - 1;                   // thread t owns the t-th run of `per` bins from the top
+    uint32_t bins[per], sum = 0;
+#pragma unroll
+    for (int i = 0; i < per; i++) { bins[i] = hist[top - i]; sum += bins[i]; }
+    uint32_t v = wave_scan_incl(sum);
+    __syncthreads();                                             // sel / wsum of an earlier call have been read
+    if ((t & 63) == 63) wsum[t >> 6] = v;
+    __syncthreads();
+    for (int w = 0; w < (t >> 6); w++) v += wsum[w];
+    if (v >= need && v - sum < need) {
+        uint32_t above = v - sum;
+        int i = 0;
+#pragma unroll
+        for (int j = 0; j < per - 1; j++)
+            if (i == j && above + bins[j] < need) { above += bins[j]; i = j + 1; }
+        const uint32_t bin = (uint32_t)(top - i);
+        sel[0] = LEVEL == 0 ? bin : (LEVEL == 1 ? (prev << 12) | bin : (prev << 8) | bin);
+        sel[1] = need - above;
     }
+    __syncthreads();
+    return Th4Sel{sel[0], sel[1]};
+}
+
+// the selections of levels 0 .. UPTO-1 (what level UPTO's histogram, or the tie count, needs)
+template <int UPTO>
+__device__ __forceinline__ Th4Sel th4_selected(const uint32_t *__restrict__ hists, uint32_t k, uint32_t *sel, uint32_t *wsum)
+{
+    Th4Sel r{0, k};
+    if (UPTO >= 1) r = th4_wg_select<0>(hists, k, 0, sel, wsum);
+    if (UPTO >= 2) r = th4_wg_select<1>(hists + 4096, r.remaining, r.prefix, sel, wsum);
+    if (UPTO >= 3) r = th4_wg_select<2>(hists + 8192, r.remaining, r.prefix, sel, wsum);
+    return r;
+}
+
+// every block's 9 magnitude counts, and a clean slate for all three histograms
+__global__ __launch_bounds__(256) void k_th4_count6(const u32x4 *__restrict__ q, uint64_t n, unsigned long long *__restrict__ cnt, uint64_t nblocks,
+                                                    uint32_t *hists)
+{
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 3 * 4096; i += 256) hists[i] = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
         const u32x4 lo = q[2 * b], hi = q[2 * b + 1];
@@ -877,19 +940,17 @@ __global__ __launch_bounds__(256) void k_th4_count(const u32x4 *__restrict__ q, 
     }
 }
 
-// Radix level over the candidate tables: 12 + 12 + 8 bits (LEVEL 0 = most significant).  Few, fat workgroups: the fixed cost
-// per workgroup (16 KiB of LDS bins to clear and to flush with global atomics, which serialise per address at ~50 ns) is what
-// this kernel costs, not the 12 bytes per block it reads.  (A variant that let the last workgroup to finish do the selection,
-// to save the launches of k_thresh_select, was 6x slower: its one-ticket-per-workgroup atomic serialises the same way.)
+// radix level LEVEL over the candidate tables, with the earlier levels' selections recomputed per workgroup
 template <int LEVEL>
-__global__ __launch_bounds__(256) void k_th4_cand_hist(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
-                                                       const ThreshState *__restrict__ ts, uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(256) void k_th4_hist6(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
+                                                   uint32_t *__restrict__ hists, uint32_t k)
 {
     __shared__ uint32_t lh[4096];
+    __shared__ uint32_t sel[2], wsum[4];
     constexpr int NB = LEVEL == 2 ? 256 : 4096;
     for (int i = threadIdx.x; i < NB; i += 256) lh[i] = 0;
-    __syncthreads();
-    const uint32_t prefix = LEVEL ? ts->prefix : 0;
+    const uint32_t prefix = th4_selected<LEVEL>(hists, k, sel, wsum).prefix;       // ends with a barrier: lh is clear for everybody
+    if (LEVEL == 0) __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
         const unsigned long long c = cnt[b];
@@ -906,38 +967,50 @@ __global__ __launch_bounds__(256) void k_th4_cand_hist(const unsigned long long 
         }
     }
     __syncthreads();
+    uint32_t *hist = hists + 4096 * LEVEL;
     for (int i = threadIdx.x; i < NB; i += 256) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-// elements of block b equal to tau, from its table
-__device__ __forceinline__ uint32_t th4_block_ties(unsigned long long c, float s7, uint32_t tau)
+// tie counts.  Workgroup g takes the chunks (of 256 blocks = one workgroup of the apply kernel) [g * cpg, (g + 1) * cpg): it
+// leaves the EXCLUSIVE prefix of every chunk inside its group in chunk_ties and the group's total in group_ties; workgroup 0
+// also publishes tau and the number of ties to keep.  k == 0: nothing survives (tau beyond any magnitude).
+__global__ __launch_bounds__(256) void k_th4_ties6(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
+                                                   const uint32_t *__restrict__ hists, uint32_t k, ThreshState *__restrict__ ts,
+                                                   uint32_t *__restrict__ chunk_ties, uint32_t *__restrict__ group_ties, uint32_t nchunks, uint32_t cpg)
 {
-    uint32_t t = 0;
-#pragma unroll
-    for (int m = 0; m <= 8; m++) t += cand_key(s7, m) == tau ? (uint32_t)(c >> (7 * m)) & 0x7Fu : 0u;
-    return t;
+    __shared__ uint32_t sel[2], wsum[4];
+    Th4Sel r{0x7F800000u, 0};
+    if (k != 0) r = th4_selected<3>(hists, k, sel, wsum);
+    const uint32_t tau = r.prefix, keep = r.remaining;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ts = ThreshState{tau, keep, tau, keep};
+    uint32_t run = 0;
+    const uint32_t c0 = blockIdx.x * cpg, c1 = c0 + cpg < nchunks ? c0 + cpg : nchunks;
+    for (uint32_t c = c0; c < c1; c++) {
+        const uint64_t b = (uint64_t)c * 256 + threadIdx.x;
+        uint32_t t = b < nblocks ? th4_block_ties(cnt[b], div7(s[b]), tau) : 0u;
+        t = wave_scan_incl(t);
+        __syncthreads();                                           // wsum of the previous chunk has been read
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_ties[c] = run;
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (threadIdx.x == 0) group_ties[blockIdx.x] = run;
 }
 
-// workgroup = 256 consecutive blocks = one chunk of k_th4_apply: tie count of the chunk
-__global__ __launch_bounds__(256) void k_th4_chunk_ties(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
-                                                        const ThreshState *__restrict__ ts, uint32_t *__restrict__ chunk_ties)
+// thread = one 64-element block: survivors above tau and the first `keep` ties in index order, whole words at a time; the rank of
+// the chunk's first tie is computed here: ties of all groups in front + the chunk's prefix inside its group
+__global__ __launch_bounds__(256) void k_th4_apply6(u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n, uint64_t nblocks,
+                                                    const unsigned long long *__restrict__ cnt, const ThreshState *__restrict__ ts,
+                                                    const uint32_t *__restrict__ chunk_ties, const uint32_t *__restrict__ group_ties, uint32_t cpg)
 {
-    __shared__ uint32_t wsum[4];
-    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t t = b < nblocks ? th4_block_ties(cnt[b], div7(s[b]), ts->tau) : 0u;
-    t = wave_scan_incl(t);
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_ties[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// thread = one 64-element block: survivors above tau and the first `keep` ties in index order, whole words at a time
-__global__ __launch_bounds__(256) void k_th4_apply(u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n, uint64_t nblocks,
-                                                   const unsigned long long *__restrict__ cnt, const ThreshState *__restrict__ ts,
-                                                   const uint32_t *__restrict__ chunk_ties)
-{
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[4], gsum[4];
     const uint32_t tau = ts->tau, keep = ts->ties_keep;
+    const uint32_t group = blockIdx.x / cpg;
+    uint32_t before = 0;
+    for (uint32_t g = threadIdx.x; g < group; g += 256) before += group_ties[g];
+    before = wave_scan_incl(before);
+    if ((threadIdx.x & 63) == 63) gsum[threadIdx.x >> 6] = before;
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in = b < nblocks;
     const float s7 = in ? div7(s[b]) : 1.0f;
@@ -945,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_th4_apply(u32x4 *__restrict__ q, const 
     const uint32_t incl = wave_scan_incl(mine);
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t rank = chunk_ties[blockIdx.x] + incl - mine;
+    uint32_t rank = gsum[0] + gsum[1] + gsum[2] + gsum[3] + chunk_ties[blockIdx.x] + incl - mine;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) rank += wsum[w];
     if (!in) return;
     uint32_t lo_t = 0, hi_t = 0;                                   // magnitudes >= hi_t are above tau, [lo_t, hi_t) equal it
@@ -975,30 +1048,34 @@ __global__ __launch_bounds__(256) void k_th4_apply(u32x4 *__restrict__ q, const 
     q[2 * b + 1] = u32x4{w[4], w[5], w[6], w[7]};
 }
 
-// workspace layout: [hist 4096 u32][ThreshState, 256 B][chunk_ties: nblocks/256 + 1 u32, padded to 256 B][cnt: nblocks u64]
+#define TH4_GROUPS 512u      // workgroups of the tie kernel (and entries the apply kernel adds up at most)
+
+// workspace layout: [3 histograms of 4096 u32][ThreshState, 256 B][group_ties: 512 u32][chunk_ties: nblocks/256 + 1 u32, padded to
+// 256 B][cnt: nblocks u64]
 static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, hipStream_t st)
 {
     const uint64_t nblocks = (n + 63) / 64;
     const uint32_t nchunks = (uint32_t)((nblocks + 255) / 256);
-    uint32_t *hist = (uint32_t *)workspace;
-    ThreshState *ts = (ThreshState *)(hist + 4096);
-    uint32_t *chunk_ties = (uint32_t *)((char *)ts + 256);
+    uint32_t *hists = (uint32_t *)workspace;
+    ThreshState *ts = (ThreshState *)(hists + 3 * 4096);
+    uint32_t *group_ties = (uint32_t *)((char *)ts + 256);
+    uint32_t *chunk_ties = group_ties + TH4_GROUPS;
     unsigned long long *cnt = (unsigned long long *)((char *)chunk_ties + (((uint64_t)(n_pad / 64 / 256 + 1) * 4 + 255) & ~255ull));
     const uint64_t want = (nblocks + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
-    hipLaunchKernelGGL(k_th4_count, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const u32x4 *)q, n, cnt, nblocks, hist, ts);
+    hipLaunchKernelGGL(k_th4_count6, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const u32x4 *)q, n, cnt, nblocks, hists);
     if (k != 0) {
-        const uint64_t hcap = (uint64_t)clv_cu_count();             // one workgroup per CU: see k_th4_cand_hist
-        const dim3 grid((unsigned)(want < hcap ? want : hcap));
-        hipLaunchKernelGGL(k_th4_cand_hist<0>, grid, dim3(256), 0, st, cnt, s, nblocks, ts, hist);
-        hipLaunchKernelGGL(k_thresh_select<0>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
-        hipLaunchKernelGGL(k_th4_cand_hist<1>, grid, dim3(256), 0, st, cnt, s, nblocks, ts, hist);
-        hipLaunchKernelGGL(k_thresh_select<1>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
-        hipLaunchKernelGGL(k_th4_cand_hist<2>, grid, dim3(256), 0, st, cnt, s, nblocks, ts, hist);
-        hipLaunchKernelGGL(k_thresh_select<2>, dim3(1), dim3(256), 0, st, hist, ts, (uint32_t)k);
+        // few, fat workgroups (every workgroup clears and flushes 16 KiB of bins): one per 1024 blocks, at most four per CU
+        // (n = 2^24: 256 workgroups, 39 us per call against 41-46 with more; n = 2^28: 1024, 206 us against 260 with 256)
+        const uint64_t hwant = (nblocks + 1023) / 1024, hcap = (uint64_t)clv_cu_count() * 4;
+        const dim3 grid((unsigned)(hwant < hcap ? hwant : hcap));
+        hipLaunchKernelGGL(k_th4_hist6<0>, grid, dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k);
+        hipLaunchKernelGGL(k_th4_hist6<1>, grid, dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k);
+        hipLaunchKernelGGL(k_th4_hist6<2>, grid, dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k);
     }
-    hipLaunchKernelGGL(k_th4_chunk_ties, dim3(nchunks), dim3(256), 0, st, cnt, s, nblocks, ts, chunk_ties);
-    hipLaunchKernelGGL(k_thresh_scan, dim3(1), dim3(256), 0, st, chunk_ties, nchunks);
-    hipLaunchKernelGGL(k_th4_apply, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties);
+    const uint32_t cpg = (nchunks + TH4_GROUPS - 1) / TH4_GROUPS;
+    const uint32_t groups = (nchunks + cpg - 1) / cpg;
+    hipLaunchKernelGGL(k_th4_ties6, dim3(groups), dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k, ts, chunk_ties, group_ties, nchunks, cpg);
+    hipLaunchKernelGGL(k_th4_apply6, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties, group_ties, cpg);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -1038,7 +1115,7 @@ static int threshold_large(uint32_t *q, const float *s, uint64_t n, uint64_t k, 
 extern "C" uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad)
 {
     const uint64_t chunk_bytes = ((n_pad / 64 / 256 + 1) * 4 + 255) & ~255ull;
-    return 4096 * sizeof(uint32_t) + 256 + chunk_bytes + (n_pad / 64) * sizeof(unsigned long long) + 256;
+    return 3 * 4096 * sizeof(uint32_t) + 256 + TH4_GROUPS * sizeof(uint32_t) + chunk_bytes + (n_pad / 64) * sizeof(unsigned long long) + 256;
 }
 
 extern "C" uint64_t clv8_threshold_workspace_bytes(uint64_t n_pad)
