@@ -183,6 +183,10 @@ def main() -> None:
         cpu_baseline_child(args.cpu_baseline_child)
         return
 
+    # the host driver of these boxes only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails with
+    # `hipIpcGetMemHandle: invalid argument`.  The environment exports it already; keep it even when a launcher drops it.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import numpy as np
     import torch
     import torch.distributed as dist
