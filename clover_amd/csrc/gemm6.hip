@@ -112,7 +112,7 @@ __device__ __forceinline__ i32x8 frag24(const char *p16, const char *p8)
 }
 
 __global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6(const uint8_t *__restrict__ A6, const float *__restrict__ sA,
-                                                            const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t M,
+                                                            const uint8_t *__restrict__ B6, const float *__restrict__ sB, uint64_t /* M */,
                                                             uint64_t N, uint64_t K, float *__restrict__ C, uint32_t tiles_m, uint32_t tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];

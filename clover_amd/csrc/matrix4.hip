@@ -390,7 +390,7 @@ static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t 
 {
     const size_t lds = MVM_LDS_BYTES;
     const dim3 grid((unsigned)(rows / 64)), block(256);
-    RngTables T = {nullptr, nullptr};
+    RngTables T = {nullptr, nullptr, nullptr};
     uint64_t seq = 0;
     if (rng) {
         int rc = clv_rng_tables(&T);

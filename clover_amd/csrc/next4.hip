@@ -1250,11 +1250,11 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
             const uint32_t nx = cw / 4, nb = cw / 64;
 #pragma unroll
             for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; xr[k] = reinterpret_cast<const f32x4 *>(x + c0)[i < nx ? i : 0]; }
-            const float sv = su[c0 / 64 + (tid < nb ? tid : 0)];
+            const float sv = su[c0 / 64 + ((uint32_t)tid < nb ? tid : 0)];
 #pragma unroll
             for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) reinterpret_cast<f32x4 *>(mvf_x)[i] = xr[k]; }
-            if (tid < nb) s7[tid] = div7(sv);
-            fast = tid >= nb || sixteenth_is_exact(div7(sv));
+            if ((uint32_t)tid < nb) s7[tid] = div7(sv);
+            fast = (uint32_t)tid >= nb || sixteenth_is_exact(div7(sv));
         }
         // the barrier the staging needs anyway also tells whether every block factor c of the chunk survives a division by 16
         // exactly: then the nibbles are taken as 16 q (one SDWA conversion each, common.h) and (16 q) * (c / 16) rounds like q * c
