@@ -125,7 +125,7 @@ class Mirror {
 public:
     enum State { HOST_DIRTY, SHARED, DEVICE_DIRTY };
 
-    Mirror() : host_(nullptr), dev_(nullptr), bytes_(0), span_(0), state_(HOST_DIRTY), owns_host_(true), pending_(false), next_(nullptr), prev_(nullptr) {}
+    Mirror() : host_(nullptr), dev_(nullptr), bytes_(0), span_(0), state_(HOST_DIRTY), owns_host_(true), pending_(false), version_(0), next_(nullptr), prev_(nullptr) {}
     ~Mirror() { release(); }
     Mirror(const Mirror &) = delete;
     Mirror &operator=(const Mirror &) = delete;
@@ -163,6 +163,10 @@ public:
 
     uint64_t bytes() const { return bytes_; }
     State state() const { return state_; }
+    /* counts every event after which the DEVICE copy may hold other bytes than before (an upload, a kernel that was handed a
+     * writable pointer): what is derived from the device copy -- CloverMatrix4's cached GEMM operand image -- is valid for one
+     * value of it.  Read it AFTER dev_ro(): a pending upload is counted there. */
+    uint64_t device_version() const { return version_; }
 
     /* the pointer getData() hands out: valid for the life of the object.  Tracked blocks: made readable now, later reads
      * and writes through it are caught by the page protection.  Untracked build: invalidates the device copy (the caller
@@ -199,10 +203,12 @@ public:
             detail::touch_for_read(host_, bytes_);
             check(clv_memcpy_h2d(dev_, host_, bytes_, nullptr), "host->device copy");
             check(clv_stream_sync(nullptr), "stream sync");
+            ++version_;
         } else if (state_ == HOST_DIRTY) {
             check(clv_memcpy_h2d(dev_, host_, bytes_, nullptr), "host->device copy");
             check(clv_stream_sync(nullptr), "stream sync");
             set_state(SHARED);
+            ++version_;
         }
         return dev_;
     }
@@ -210,6 +216,7 @@ public:
     uint8_t *dev_wo()
     {
         ensure_dev();
+        ++version_;
         if (owns_host_) set_state(DEVICE_DIRTY);
         else pending_ = true;
         return dev_;
@@ -218,6 +225,7 @@ public:
     uint8_t *dev_rw()
     {
         dev_ro();
+        ++version_;
         if (owns_host_) set_state(DEVICE_DIRTY);
         else pending_ = true;
         return dev_;
@@ -325,6 +333,7 @@ private:
     volatile State state_;             /* also written by the fault handler: always re-read */
     bool owns_host_;
     volatile bool pending_;
+    uint64_t version_;                 /* see device_version() */
     Mirror *next_, *prev_;             /* intrusive list of tracked blocks (detail::Tracker) */
 };
 

@@ -151,3 +151,29 @@ def test_error_convention_and_layout_without_gpu(tmp_path):
         assert p.returncode == 1 and msg in p.stdout and "not reached" not in p.stdout
     p = subprocess.run([str(exe), "layout"], capture_output=True, text=True)
     assert p.returncode == 0 and "layout ok" in p.stdout, (p.returncode, p.stdout)
+
+
+def _compile_gemm_cache(out: Path, extra=()):
+    lib = build_hip_library()
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}",
+                    str(ROOT / "tests" / "cpp" / "gemm_cache.cpp"), "-o", str(out), f"-L{lib.parent}", "-lclover_hip", f"-Wl,-rpath,{lib.parent}",
+                    "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", *extra], check=True)
+
+
+def test_gemm_cache_client_builds_and_reports_no_device_on_cpu(tmp_path):
+    exe = tmp_path / "gemm_cache"
+    _compile_gemm_cache(exe)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and ("no_device" in p.stdout or "gemm_cache ok" in p.stdout), (p.returncode, p.stdout, p.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracking", [True, False])
+def test_gemm_operand_cache_follows_the_matrix(tmp_path, tracking):
+    """CloverMatrix4::cacheGemmOperand: the FP6 image kept between gemm() calls is rebuilt after quantize() and after a write
+    through a kept getData() pointer (page tracking) -- and, without page tracking, after every getData() -- and never changes a
+    result."""
+    exe = tmp_path / "gemm_cache"
+    _compile_gemm_cache(exe, () if tracking else ("-DCLOVER_HIP_NO_PAGE_TRACKING",))
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "gemm_cache ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
