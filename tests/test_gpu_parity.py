@@ -383,6 +383,32 @@ def test_bad_sizes_are_rejected(hip):
     assert hip.lib.clm4_mvm(buf.ptr, buf.ptr, 128, 192, buf.ptr, buf.ptr, buf.ptr, buf.ptr, None, None) == -1      # cols: multiples of 128 only
 
 
+def test_gemm_prepared_operand_misuse_is_rejected(hip):
+    """prepared operands carry their shape: a call that disagrees with it, or an odd K-block range of the integer GEMM without
+    the nibbles, comes back as CLV_ERR_INVALID with a message, not as a wrong result"""
+    import ctypes as C
+    lib = hip.lib
+    M, N, K = 256, 128, 256
+    a, b, c = hip.alloc(M * K // 2), hip.alloc(N * K // 2), hip.alloc(M * N * 4)
+    sa, sb = hip.alloc((M // 64) * (K // 64) * 4), hip.alloc((N // 64) * (K // 64) * 4)
+    opA, opB = C.c_void_p(), C.c_void_p()
+    hip.check(lib.clm4_gemm_prepare(a.ptr, M, K, C.byref(opA), None))
+    hip.check(lib.clm4_gemm_prepare(b.ptr, N, K, C.byref(opB), None))
+    try:
+        assert lib.clm4_gemm_prepared(opA, None, sa.ptr, M + 128, K, opB, None, sb.ptr, N, c.ptr, None) == -1          # A was prepared as 256 rows
+        assert b"prepared as" in lib.clv_last_error()
+        assert lib.clm4_gemm_prepared(opA, None, sa.ptr, M, K, opA, None, sb.ptr, N, c.ptr, None) == -1                # "B" has M rows, not N
+        assert lib.clm4_gemm_i32_prepared(opA, None, M, K, opB, None, N, 1, 1, c.ptr, None) == -1                      # odd range: needs the nibbles
+        assert b"nibbles" in lib.clv_last_error()
+        assert lib.clm4_gemm_i32_prepared(opA, a.ptr, M, K, opB, b.ptr, N, 1, 1, c.ptr, None) == 0                     # ... and runs with them
+        assert lib.clm4_gemm_i32_prepared(opA, None, M, K, opB, None, N, 0, K // 64 + 2, c.ptr, None) == -1            # range beyond K
+        assert lib.clm4_gemm_prepared(None, None, sa.ptr, M, K, opB, None, sb.ptr, N, c.ptr, None) == -1               # neither image nor nibbles for A
+        hip.sync()
+    finally:
+        hip.check(lib.clm4_gemm_release(opA))
+        hip.check(lib.clm4_gemm_release(opB))
+
+
 def test_degenerate_sizes(hip):
     """n_pad == 0 / rows == 0 are accepted as no-ops (the reference's containers always hold >= 128 elements)"""
     buf = hip.alloc(256)
