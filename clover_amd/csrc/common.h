@@ -101,10 +101,19 @@ __device__ __forceinline__ float fix_zero_max(float m)
 // (v_cvt_i32_f32 truncates like cvttps).  The only input for which cvttps' out-of-range answer (0x80000000,
 // i.e. nibble 0) differs from v_cvt's saturation is k == inf (block maximum below 2.06e-38, 7/max overflows):
 // there every element becomes 0 in the reference, which the callers mirror per block with `k < INFINITY`.
+// copysign(noise, x) for noise >= +0: noise | (x & 0x80000000) as ONE v_bitop3_b32 ((s0 & s1) | s2 = table 0xEA).  hipcc emits
+// v_bfi_b32 for copysign, which occupies the VALU 4.3 cycles per wave; v_bitop3_b32 takes 2.9 like v_fma_f32 (tools/valu_rate.hip:
+// v_xor 2.4, v_fma / v_bitop3 2.9, conversions / v_bfi / v_max3 / 64-bit shifts 4.3-4.9, v_pk_fma_f32 5.1).
+__device__ __forceinline__ float sign_onto_nonneg(float noise, float x)
+{
+    float r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(x), "s"(0x80000000u), "v"(noise));
+    return r;
+}
 __device__ __forceinline__ int quant1_det(float x, float k) { return (int)(x * k); }
 __device__ __forceinline__ int quant1_st(float x, float k, float noise)
 {
-    return (int)__builtin_fmaf(x, k, __builtin_copysignf(noise, x));
+    return (int)__builtin_fmaf(x, k, sign_onto_nonneg(noise, x));
 }
 // single-element form with the overflow guard folded in (mvm epilogue: one value per lane)
 __device__ __forceinline__ int quant1(float x, float k, float noise)
@@ -167,7 +176,7 @@ __device__ __forceinline__ uint32_t quant_pack8(const float v[8], float k, const
 {
     float t[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) t[e] = noise ? __builtin_fmaf(v[e], k, __builtin_copysignf(noise[e], v[e])) : v[e] * k;      // quant1_st / quant1_det
+    for (int e = 0; e < 8; e++) t[e] = noise ? __builtin_fmaf(v[e], k, sign_onto_nonneg(noise[e], v[e])) : v[e] * k;      // quant1_st / quant1_det
     uint32_t even = cvt_i32_byte0_first(t[0]), odd = cvt_i32_byte0_first(t[1]);
     cvt_i32_into_byte1(even, t[2]);
     cvt_i32_into_byte1(odd, t[3]);

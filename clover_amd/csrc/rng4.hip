@@ -70,7 +70,7 @@ int clv_rng_tables(RngTables *t)
 // the 4 nibbles of half an output dword with their noise: words W.x..W.w of one draw, byte `sh` (see k_m4_quantize_strip_st)
 __device__ __forceinline__ uint32_t quant_pack4_st(const f32x4 v, float k, const u32x4 W, int sh)
 {
-#define ST_PRODUCT(x, w) __builtin_fmaf(x, k, __builtin_copysignf(noise_of(w, sh), x))       /* quant1_st before the conversion */
+#define ST_PRODUCT(x, w) __builtin_fmaf(x, k, sign_onto_nonneg(noise_of(w, sh), x))       /* quant1_st before the conversion */
     const uint32_t h = pack4_of_products(ST_PRODUCT(v.x, W.x), ST_PRODUCT(v.y, W.y), ST_PRODUCT(v.z, W.z), ST_PRODUCT(v.w, W.w));
 #undef ST_PRODUCT
     return k < __builtin_inff() ? h : 0u;
