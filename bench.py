@@ -170,6 +170,10 @@ def main() -> None:
     ap.add_argument("--workload", choices=("mvm", "gemm"), default="mvm",
                     help="mvm (default): the headline GEMV of BASELINE configs[2]; gemm: configs[3], one GPU, its own JSON line")
     ap.add_argument("--gemm-size", type=int, default=8192)
+    ap.add_argument("--mode", choices=("ranks", "one-process"), default="ranks",
+                    help="how N > 1 GPUs are driven.  ranks (default): one process per GPU under torch.distributed (backend nccl = RCCL); when "
+                         "no launcher set WORLD_SIZE, bench.py starts torch.distributed.run itself.  one-process: this process drives all N "
+                         "devices through the C ABI's clm4_sharded_* loop calls (RCCL all-gather on a second stream per device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
@@ -197,9 +201,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ              # torch.distributed.run (the driver's, or our own below) set the rank env
+    if not launched and (args.gpus > 1 or args.mode == "one-process"):
+        need = 1 if os.environ.get("CLOVER_BENCH_DEBUG_ONE_GPU") == "1" else args.gpus
+        have = torch.cuda.device_count()
+        if have < need:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this box shows {have} GPU(s) (torch.cuda.device_count()), {need} needed "
+                             f"-- a device-count problem, not a launcher problem: bench.py starts its own ranks")
+        if args.mode == "one-process":
+            return one_process_main(args, torch, CloverHip)
+        return self_launch(args)
+    if launched and args.mode == "one-process":
+        raise SystemExit("bench.py --mode one-process drives all GPUs from ONE process: run it without torch.distributed.run")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     # CLOVER_BENCH_DEBUG_ONE_GPU=1: rehearsal of the N>1 control flow on a box with ONE GPU -- every rank uses device 0 and the
     # exchange goes through gloo and the host.  Never a measurement: the output says so.
@@ -349,6 +363,7 @@ def main() -> None:
             **({"gathered_result_verified": gather_ok, "rccl_ranks": rccl_ranks, "backend": dist.get_backend(),
                 "per_rank_kernel_ms": per_rank_kernel_ms, "gather_us_blocking": gather_us,
                 "gather_bytes_per_rank": packed_bytes(rows)} if world > 1 else {}),
+            **({"mode": "ranks", "launcher": os.environ.get("CLOVER_BENCH_LAUNCHER", "external torch.distributed.run")} if world > 1 else {}),
             **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all ranks on one GPU, gloo through the host -- not a measurement"} if debug_one_gpu else {}),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_step": bytes_total,
@@ -384,6 +399,133 @@ def main() -> None:
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the ranks ourselves, exactly as the driver's launcher would
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>`),
+    pass rank 0's JSON line through on stdout and return the launcher's exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               CLOVER_BENCH_LAUNCHER="bench.py self-launch (torch.distributed.run re-exec)")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def one_process_main(args, torch, CloverHip) -> None:
+    """N GPUs driven by THIS process through the C ABI (clm4_sharded_create / _set_x / _loop_begin / _mvm_enqueue / _sync): the product's
+    own multi-GPU path, timed as it would run inside an application loop.  A step = every shard's kernel on its device's compute stream +
+    one grouped in-place ncclAllGather pair on its exchange stream (overlapping the next step's kernel); no host synchronisation inside
+    the timed region.  CLOVER_BENCH_DEBUG_ONE_GPU=1 lists device 0 N times (exchanges become copies): a rehearsal, not a measurement."""
+    import ctypes as C
+    debug = os.environ.get("CLOVER_BENCH_DEBUG_ONE_GPU") == "1"
+    n = args.gpus
+    hip = CloverHip(device=0)
+    lib = hip.lib
+    scaling = "weak"
+    if args.preset == "c5-weak":
+        args.rows_per_gpu = 131072
+    elif args.preset == "c5-strong":
+        assert (1 << 20) % (64 * n) == 0
+        args.rows_per_gpu, scaling = (1 << 20) // n, "strong"
+    rows, cols = args.rows_per_gpu, args.cols
+    rows_total = rows * n
+    devs = (C.c_int * n)(*([0] * n if debug else range(n)))
+    ctx = C.c_void_p()
+    hip.check(lib.clm4_sharded_create(C.byref(ctx), n, devs, rows_total, cols))
+    try:
+        hip.check(lib.clm4_sharded_fill_random(ctx, 0xC10FE4))
+        x = torch.empty(cols // 2, dtype=torch.uint8, device="cuda:0")
+        sx = torch.empty(cols // 64, dtype=torch.float32, device="cuda:0")
+        hip.check(lib.clv_fill_random_nibbles(x.data_ptr(), x.numel(), 0xC10FE4 + 2, 0, None))
+        hip.check(lib.clv_fill_random_scales(sx.data_ptr(), sx.numel(), 0xC10FE4 + 3, 0, None))
+        torch.cuda.synchronize()
+        hip.check(lib.clm4_sharded_set_x(ctx, x.data_ptr(), sx.data_ptr(), 0))
+        hip.check(lib.clm4_sharded_loop_begin(ctx, args.steps))
+        for w_ in range(args.warmup):
+            hip.check(lib.clm4_sharded_mvm_enqueue(ctx, w_, 0))
+        hip.check(lib.clm4_sharded_sync(ctx))
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            hip.check(lib.clm4_sharded_mvm_enqueue(ctx, i, 1))
+        hip.check(lib.clm4_sharded_sync(ctx))
+        elapsed = time.perf_counter() - t0
+        per_k, per_g = [], []
+        km, gm = C.c_float(), C.c_float()
+        for d in range(n):
+            ks, gs = 0.0, 0.0
+            for i in range(args.steps):
+                hip.check(lib.clm4_sharded_step_timing(ctx, d, i, C.byref(km), C.byref(gm)))
+                ks += km.value
+                gs += gm.value
+            per_k.append(ks / args.steps)
+            per_g.append(gs / args.steps)
+        # every device holds the full result, and it equals the unsharded call's (n * 72 KiB: compared on the host)
+        last = (args.steps - 1) & 1
+        import numpy as np
+        full = []
+        for d in range(n):
+            rp, sp = C.c_void_p(), C.c_void_p()
+            hip.check(lib.clm4_sharded_result_buf(ctx, d, last, C.byref(rp), C.byref(sp)))
+            rr = np.empty(rows_total // 2, np.uint8)
+            ss = np.empty(rows_total // 64, np.float32)
+            hip.check(lib.clv_set_device(0 if debug else d))
+            hip.check(lib.clv_memcpy_d2h(rr.ctypes.data, rp, rr.nbytes, None))
+            hip.check(lib.clv_memcpy_d2h(ss.ctypes.data, sp, ss.nbytes, None))
+            hip.check(lib.clv_device_sync())
+            full.append((rr, ss))
+        hip.check(lib.clv_set_device(0))
+        same = all(np.array_equal(full[0][0], f[0]) and np.array_equal(full[0][1].view(np.uint32), f[1].view(np.uint32)) for f in full[1:])
+        # shard 0's rows against a plain clm4_mvm of the same (regenerated) rows on device 0
+        A0 = torch.empty(rows * cols // 2, dtype=torch.uint8, device="cuda:0")
+        sA0 = torch.empty((rows // 64) * (cols // 64), dtype=torch.float32, device="cuda:0")
+        r0 = torch.empty(rows // 2, dtype=torch.uint8, device="cuda:0")
+        sr0 = torch.empty(rows // 64, dtype=torch.float32, device="cuda:0")
+        hip.check(lib.clv_fill_random_nibbles(A0.data_ptr(), A0.numel(), 0xC10FE4, 0, None))
+        hip.check(lib.clv_fill_random_scales(sA0.data_ptr(), sA0.numel(), 0xC10FE4 + 1, 0, None))
+        hip.check(lib.clm4_mvm(A0.data_ptr(), sA0.data_ptr(), rows, cols, x.data_ptr(), sx.data_ptr(), r0.data_ptr(), sr0.data_ptr(), None, None))
+        torch.cuda.synchronize()
+        ok0 = bool(np.array_equal(r0.cpu().numpy(), full[0][0][: rows // 2]) and
+                   np.array_equal(sr0.cpu().numpy().view(np.uint32), full[0][1][: rows // 64].view(np.uint32)))
+        ranks, equal = C.c_int(), C.c_int()
+        hip.check(lib.clm4_sharded_comm_info(ctx, C.byref(ranks), C.byref(equal)))
+    finally:
+        lib.clm4_sharded_destroy(ctx)
+    ms_per_step = elapsed / args.steps * 1e3
+    kern_avg_ms = max(per_k)
+    bytes_total, bytes_gpu = mvm_bytes(rows_total, cols), mvm_bytes(rows, cols)
+    achieved = bytes_gpu / (kern_avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "int4 GEMV (CloverMatrix4::mvm) effective GB/s, algorithmic operand bytes / time",
+        "value": round(bytes_total / (ms_per_step * 1e-3) / 1e9, 2), "unit": "GB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int4",
+        "data": "synthetic",
+        "config": {
+            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 ({rows}x{cols} per GPU; preset {args.preset}), x and result CloverVector4, "
+                        "STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
+            "rows_per_gpu": rows, "cols": cols, "mode": "one-process",
+            "parallelism": f"row-shard x{n}, one process drives all devices (clm4_sharded_mvm_enqueue): grouped in-place ncclAllGather pair per "
+                           "step on a second stream per device, overlapped with the next step's kernel",
+            "gathered_result_verified": bool(same and ok0), "rccl_ranks": ranks.value, "backend": "rccl (dlopen, ncclCommInitAll)" if ranks.value else "device copies",
+            "per_rank_kernel_ms": [round(v, 5) for v in per_k], "gather_ms_behind_kernel": [round(v, 5) for v in per_g],
+            "gather_bytes_per_rank": rows // 2 + rows // 16,
+            **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all shards on device 0, exchanges are copies -- not a measurement"} if debug else {}),
+            "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1), "algorithmic_bytes_per_step": bytes_total,
+        },
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "k_m4_mvm64", "kernel_avg_ms": round(kern_avg_ms, 5), "algorithmic_bytes_per_launch": bytes_gpu},
+    }
+    tr = pmc_traffic(rows, cols)
+    if tr:
+        out["roofline"]["traffic"] = tr[0]
+        out["roofline"]["traffic_source"] = f"profiles/{tr[1]}"
+    print(json.dumps(out))
 
 
 def gemm_main(args) -> None:

@@ -72,6 +72,10 @@ __device__ __forceinline__ int dot32(const u32x4 &a, const u32x4 &b)
 // v_div_fmas, v_div_fixup): q = x * c; r = fma(-7, q, x) (exact residual); q += r * c -- the classic division by a constant
 // known in advance (Brisebarre, Muller, Raina 2004).  Checked EXHAUSTIVELY against x / 7.0f for all 2^32 bit patterns
 // (tools/check_div7.c): identical for every finite x except x = -0 (gives +0), which the sign copy at the end repairs.
+// NOT identical for x = +/-inf: the residual fma(-7, inf, inf) is NaN, so div7(inf) = NaN where inf / 7.0f = inf.  Callers pass block
+// scales (absolute maxima of the data); a block with an infinite element is outside the reference's contract already (its quantiser
+// feeds 7/inf = 0 and inf * 0 = NaN to cvttps, CloverVector4.h:668-685) and DESIGN.md 4 lists non-finite inputs as out of contract,
+// so the callers do not guard (a guard would cost the streaming kernels one VALU instruction per block word).
 __device__ __forceinline__ float div7(float x)
 {
     const float c = 1.0f / 7.0f;

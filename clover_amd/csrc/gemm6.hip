@@ -479,9 +479,16 @@ extern "C" int clm4_gemm_release(clm4_gemm_operand *op)
 static int gemm_fp6_run(const clm4_gemm_operand *opA, const int8_t *A, const float *sA, uint64_t M, uint64_t K, const clm4_gemm_operand *opB,
                         const int8_t *B, const float *sB, uint64_t N, void *C, bool i32, uint64_t kb_begin, uint64_t kb_count, hipStream_t st)
 {
+    if (opA && opB && opA->tile != opB->tile) {
+        // clm4_gemm_prepare picks an image's staging layout (128- or 256-row tiles) from that operand's own row count, so a large and a
+        // small operand can disagree.  The smaller one is then re-coded for this call in the other's layout (it is the cheaper of the
+        // two) -- which needs its nibbles: callers that may mix sizes pass A / B besides the images (the C++ containers always do).
+        const bool drop_a = (M <= N && A) || !B;
+        CLV_REQUIRE(A || B, "clm4_gemm_prepared: the operands were prepared for different tile shapes (%u, %u rows) and neither operand's "
+                            "nibbles were passed to re-code one of them", opA->tile, opB->tile);
+        if (drop_a) opA = nullptr; else opB = nullptr;
+    }
     uint32_t tile = opA ? opA->tile : opB ? opB->tile : pick_tile(M, N);
-    CLV_REQUIRE(!(opA && opB) || opA->tile == opB->tile, "clm4_gemm_prepared: the operands were prepared for different tile shapes (%u, %u rows)",
-                opA ? opA->tile : 0, opB ? opB->tile : 0);
     const uint64_t a_bytes = opA ? 0 : image_bytes(M, K, tile), b_bytes = opB ? 0 : image_bytes(N, K, tile);
     uint8_t *A6 = opA ? opA->image : nullptr, *B6 = opB ? opB->image : nullptr;
     if (a_bytes + b_bytes) {

@@ -98,6 +98,15 @@ struct clm4_shard_ctx {
     std::vector<float *> sA, sx, sr;        // per device: shard tile scales, x scales, FULL result scales
     std::vector<hipStream_t> st;
     std::vector<ncclComm_t> comm;
+    // timed-loop form (clm4_sharded_loop_begin / _mvm_enqueue): a second result buffer and an exchange stream per device, so the
+    // gather of step i runs beside the kernel of step i+1; nothing in it synchronises with the host
+    int slots = 0;                          // steps whose events are kept (3 events per step and device)
+    std::vector<hipStream_t> cs;            // per device: the stream the exchanges of the loop run on
+    std::vector<int8_t *> r2;               // per device: FULL result nibbles, buffer 1 (buffer 0 is r)
+    std::vector<float *> sr2;
+    std::vector<hipEvent_t> kdone, gdone;   // [2*d + buf]: kernel of the step that last wrote buf finished / its gather finished
+    std::vector<char> gpending;             // [2*d + buf]: gdone was recorded
+    std::vector<hipEvent_t> slot_ev;        // [(3*step + e) * ndev + d]
     // GEMM (clm4_sharded_gemm): B replicated, one row shard of C per device
     uint64_t gemm_n = 0;
     std::vector<int8_t *> B;
@@ -122,7 +131,19 @@ extern "C" int clm4_sharded_destroy(clm4_shard_ctx *c)
     for (int d = 0; d < (int)c->dev.size(); d++) {
         (void)hipSetDevice(c->dev[d]);
         if (d < (int)c->comm.size() && c->comm[d]) rccl()->CommDestroy(c->comm[d]);
-        if (d < (int)c->st.size() && c->st[d]) (void)hipStreamDestroy(c->st[d]);
+        if (d < (int)c->st.size() && c->st[d]) {
+            clv_internal_workspace_forget(c->st[d]);         // the FP6 images clm4_gemm keeps per (device, stream)
+            (void)hipStreamDestroy(c->st[d]);
+        }
+        if (d < (int)c->cs.size() && c->cs[d]) (void)hipStreamDestroy(c->cs[d]);
+        for (int e = 0; e < 2; e++) {
+            if (2 * d + e < (int)c->kdone.size() && c->kdone[2 * d + e]) (void)hipEventDestroy(c->kdone[2 * d + e]);
+            if (2 * d + e < (int)c->gdone.size() && c->gdone[2 * d + e]) (void)hipEventDestroy(c->gdone[2 * d + e]);
+        }
+        for (size_t k = d; k < c->slot_ev.size(); k += c->dev.size())
+            if (c->slot_ev[k]) (void)hipEventDestroy(c->slot_ev[k]);
+        if (d < (int)c->r2.size() && c->r2[d]) (void)hipFree(c->r2[d]);
+        if (d < (int)c->sr2.size() && c->sr2[d]) (void)hipFree(c->sr2[d]);
         for (int e = 0; e < 3; e++)
             if (3 * d + e < (int)c->ev.size() && c->ev[3 * d + e]) (void)hipEventDestroy(c->ev[3 * d + e]);
         void *ptrs[] = {d < (int)c->A.size() ? c->A[d] : nullptr, d < (int)c->x.size() ? c->x[d] : nullptr, d < (int)c->r.size() ? c->r[d] : nullptr,
@@ -363,6 +384,160 @@ extern "C" int clm4_sharded_result(const clm4_shard_ctx *c, int part, const int8
 }
 
 
+// ---- timed-loop form: the same sharded mvm without any host synchronisation -----------------------------------------------------
+// clm4_sharded_mvm is the blocking convenience call (it ends with a stream synchronise per device).  A loop that multiplies many
+// times -- bench.py --mode one-process, an IHT iteration over a sharded matrix -- uses these instead:
+//     clm4_sharded_set_x        x to every device (stream-ordered);
+//     clm4_sharded_loop_begin   second result buffer, exchange stream and `slots` event triples per device;
+//     clm4_sharded_mvm_enqueue  step i: kernel into result buffer i & 1 on the device's compute stream, the all-gather of that buffer
+//                               on its exchange stream behind it -- so the gather of step i overlaps the kernel of step i + 1, and
+//                               the kernel of step i + 2 waits (on the device) until the gather of step i has left its buffer;
+//     clm4_sharded_sync         the one host wait, when the caller wants the results;
+//     clm4_sharded_step_timing  kernel and exchange time of a timed step, from events on the device's own streams.
+extern "C" int clm4_sharded_set_x(clm4_shard_ctx *c, const int8_t *x, const float *sx, int x_on_host)
+{
+    CLV_REQUIRE(c && x && sx, "clm4_sharded_set_x: null argument");
+    DeviceGuard guard;
+    CLV_HIP(hipSetDevice(c->dev[0]));
+    const hipMemcpyKind kind = x_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    CLV_HIP(hipMemcpyAsync(c->x[0], x, c->cols / 2, kind, c->st[0]));
+    CLV_HIP(hipMemcpyAsync(c->sx[0], sx, c->cols / 16, kind, c->st[0]));
+    int rc = replicate_from_0(c, (void *const *)c->x.data(), c->cols / 2);
+    if (rc == CLV_OK) rc = replicate_from_0(c, (void *const *)c->sx.data(), c->cols / 16);
+    return rc;
+}
+
+extern "C" int clm4_sharded_loop_begin(clm4_shard_ctx *c, int slots)
+{
+    CLV_REQUIRE(c && slots >= 0 && slots <= (1 << 20), "clm4_sharded_loop_begin: bad argument");
+    DeviceGuard guard;
+    const int n = c->ndev;
+    if (c->cs.empty()) {
+        c->cs.assign(n, nullptr); c->r2.assign(n, nullptr); c->sr2.assign(n, nullptr);
+        c->kdone.assign(2 * (size_t)n, nullptr); c->gdone.assign(2 * (size_t)n, nullptr);
+        c->gpending.assign(2 * (size_t)n, 0);
+        for (int d = 0; d < n; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            CLV_HIP(hipStreamCreateWithFlags(&c->cs[d], hipStreamNonBlocking));
+            CLV_HIP(hipMalloc((void **)&c->r2[d], c->rows / 2));
+            CLV_HIP(hipMalloc((void **)&c->sr2[d], c->rows / 16));
+            for (int e = 0; e < 2; e++) {
+                CLV_HIP(hipEventCreateWithFlags(&c->kdone[2 * d + e], hipEventDisableTiming));
+                CLV_HIP(hipEventCreateWithFlags(&c->gdone[2 * d + e], hipEventDisableTiming));
+            }
+        }
+    }
+    if (slots > c->slots) {
+        c->slot_ev.resize(3 * (size_t)slots * n, nullptr);
+        for (size_t k = 3 * (size_t)c->slots * n; k < c->slot_ev.size(); k++) {
+            CLV_HIP(hipSetDevice(c->dev[k % n]));
+            CLV_HIP(hipEventCreate(&c->slot_ev[k]));
+        }
+        c->slots = slots;
+    }
+    return CLV_OK;
+}
+
+extern "C" int clm4_sharded_mvm_enqueue(clm4_shard_ctx *c, int step, int timed)
+{
+    CLV_REQUIRE(c && step >= 0, "clm4_sharded_mvm_enqueue: bad argument");
+    CLV_REQUIRE(!c->cs.empty(), "clm4_sharded_mvm_enqueue: call clm4_sharded_loop_begin first");
+    CLV_REQUIRE(!timed || step < c->slots, "clm4_sharded_mvm_enqueue: step %d has no event slot (%d reserved)", step, c->slots);
+    DeviceGuard guard;
+    const int n = c->ndev, b = step & 1;
+    auto slot = [&](int e, int d) { return c->slot_ev[(3 * (size_t)step + e) * n + d]; };
+    auto rb = [&](int d) { return b ? c->r2[d] : c->r[d]; };
+    auto sb = [&](int d) { return b ? c->sr2[d] : c->sr[d]; };
+    for (int d = 0; d < n; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        if (c->gpending[2 * d + b]) CLV_HIP(hipStreamWaitEvent(c->st[d], c->gdone[2 * d + b], 0));   // the gather of step - 2 has left this buffer
+        if (timed) CLV_HIP(hipEventRecord(slot(0, d), c->st[d]));
+        int rc = clm4_mvm(c->A[d], c->sA[d], c->row_count[d], c->cols, c->x[d], c->sx[d], rb(d) + c->row_begin[d] / 2,
+                          sb(d) + c->row_begin[d] / 64, nullptr, c->st[d]);
+        if (rc != CLV_OK) return rc;
+        if (timed) CLV_HIP(hipEventRecord(slot(1, d), c->st[d]));
+        CLV_HIP(hipEventRecord(c->kdone[2 * d + b], c->st[d]));
+    }
+    if (n > 1 && c->loopback) {
+        for (int d = 0; d < n; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            for (int o = 0; o < n; o++) {
+                CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * o + b], 0));
+                if (o == d) continue;
+                CLV_HIP(hipMemcpyAsync(rb(d) + c->row_begin[o] / 2, rb(o) + c->row_begin[o] / 2, c->row_count[o] / 2, hipMemcpyDeviceToDevice, c->cs[d]));
+                CLV_HIP(hipMemcpyAsync(sb(d) + c->row_begin[o] / 64, sb(o) + c->row_begin[o] / 64, c->row_count[o] / 16, hipMemcpyDeviceToDevice, c->cs[d]));
+            }
+        }
+    } else if (c->use_rccl) {
+        for (int d = 0; d < n; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * d + b], 0));
+        }
+        RcclGroup g;
+        CLV_NCCL(g.start());
+        if (c->equal) {
+            const uint64_t rc_rows = c->row_count[0];
+            for (int d = 0; d < n; d++) {
+                CLV_NCCL(rccl()->AllGather(rb(d) + c->row_begin[d] / 2, rb(d), rc_rows / 2, ncclInt8, c->comm[d], c->cs[d]));
+                CLV_NCCL(rccl()->AllGather(sb(d) + c->row_begin[d] / 64, sb(d), rc_rows / 64, ncclFloat32, c->comm[d], c->cs[d]));
+            }
+        } else {
+            for (int root = 0; root < n; root++)
+                for (int d = 0; d < n; d++) {
+                    int8_t *pr = rb(d) + c->row_begin[root] / 2;
+                    float *ps = sb(d) + c->row_begin[root] / 64;
+                    CLV_NCCL(rccl()->Broadcast(pr, pr, c->row_count[root] / 2, ncclInt8, root, c->comm[d], c->cs[d]));
+                    CLV_NCCL(rccl()->Broadcast(ps, ps, c->row_count[root] / 64, ncclFloat32, root, c->comm[d], c->cs[d]));
+                }
+        }
+        CLV_NCCL(g.end());
+    } else {
+        for (int d = 0; d < n; d++) {                           // one shard: nothing to exchange, the exchange stream only follows
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * d + b], 0));
+        }
+    }
+    for (int d = 0; d < n; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        if (timed) CLV_HIP(hipEventRecord(slot(2, d), c->cs[d]));
+        CLV_HIP(hipEventRecord(c->gdone[2 * d + b], c->cs[d]));
+        c->gpending[2 * d + b] = 1;
+    }
+    return CLV_OK;
+}
+
+extern "C" int clm4_sharded_sync(clm4_shard_ctx *c)
+{
+    CLV_REQUIRE(c, "clm4_sharded_sync: null argument");
+    DeviceGuard guard;
+    for (int d = 0; d < c->ndev; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        CLV_HIP(hipStreamSynchronize(c->st[d]));
+        if (d < (int)c->cs.size() && c->cs[d]) CLV_HIP(hipStreamSynchronize(c->cs[d]));
+    }
+    return CLV_OK;
+}
+
+extern "C" int clm4_sharded_step_timing(const clm4_shard_ctx *c, int part, int step, float *mvm_ms, float *gather_ms)
+{
+    CLV_REQUIRE(c && part >= 0 && part < c->ndev && step >= 0 && step < c->slots, "clm4_sharded_step_timing: bad argument");
+    DeviceGuard guard;
+    CLV_HIP(hipSetDevice(c->dev[part]));
+    const size_t n = c->ndev;
+    if (mvm_ms) CLV_HIP(hipEventElapsedTime(mvm_ms, c->slot_ev[(3 * (size_t)step + 0) * n + part], c->slot_ev[(3 * (size_t)step + 1) * n + part]));
+    if (gather_ms) CLV_HIP(hipEventElapsedTime(gather_ms, c->slot_ev[(3 * (size_t)step + 1) * n + part], c->slot_ev[(3 * (size_t)step + 2) * n + part]));
+    return CLV_OK;
+}
+
+// device pointers of the full result in buffer `buf` (= step & 1 of the enqueue that wrote it) held by shard `part`
+extern "C" int clm4_sharded_result_buf(const clm4_shard_ctx *c, int part, int buf, const int8_t **r_dev, const float **sr_dev)
+{
+    CLV_REQUIRE(c && part >= 0 && part < c->ndev && (buf == 0 || (buf == 1 && !c->r2.empty())), "clm4_sharded_result_buf: bad argument");
+    if (r_dev) *r_dev = buf ? c->r2[part] : c->r[part];
+    if (sr_dev) *sr_dev = buf ? c->sr2[part] : c->sr[part];
+    return CLV_OK;
+}
+
 // C = A * B^T with A the sharded matrix (rows x cols) and B an N x cols CloverMatrix4 replicated on every device: device d ends
 // with rows [row_begin_d, +row_count_d) of C (fp32, row-major, N columns).  Every element of C is its own fma chain over the
 // K-blocks, so the shards equal the unsharded clm4_gemm bit for bit and nothing needs to be exchanged; C_host
@@ -402,7 +577,6 @@ extern "C" int clm4_sharded_gemm(clm4_shard_ctx *c, const int8_t *B, const float
         CLV_HIP(hipSetDevice(c->dev[d]));
         int rc = clm4_gemm(c->A[d], c->sA[d], c->row_count[d], K, c->B[d], c->sB[d], N, c->C[d], c->st[d]);
         if (rc != CLV_OK) return rc;
-        if (c->loopback) CLV_HIP(hipStreamSynchronize(c->st[d]));      // shards of one device share clm4_gemm's per-device workspace
     }
     for (int d = 0; d < c->ndev; d++) {
         CLV_HIP(hipSetDevice(c->dev[d]));

@@ -88,6 +88,12 @@ SIGNATURES = {
     "clm4_sharded_fill_random": (C.c_int, [_vp, _u64]),
     "clm4_sharded_mvm": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "clm4_sharded_result": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "clm4_sharded_set_x": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "clm4_sharded_loop_begin": (C.c_int, [_vp, C.c_int]),
+    "clm4_sharded_mvm_enqueue": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "clm4_sharded_sync": (C.c_int, [_vp]),
+    "clm4_sharded_step_timing": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "clm4_sharded_result_buf": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     "clm4_sharded_gemm": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _vp]),
     "clm4_sharded_gemm_result": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "clv_fill_random_nibbles": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),

@@ -352,7 +352,9 @@ public:
         const int8_t *qa = dev_values(), *qb = B.dev_values();            /* uploads pending host writes: versions are final after this */
         const clm4_gemm_operand *opA = gemm_operand(qa), *opB = B.gemm_operand(qb);
         if (opA || opB)
-            clover_hip::check(clm4_gemm_prepared(opA, opA ? nullptr : qa, dev_scales(), rows, cols, opB, opB ? nullptr : qb, B.dev_scales(), B.rows,
+            /* the nibbles go along with the images: two cached operands of very different size hold images in different staging
+             * layouts, and the call then re-codes the smaller one (clover_hip.h) */
+            clover_hip::check(clm4_gemm_prepared(opA, qa, dev_scales(), rows, cols, opB, qb, B.dev_scales(), B.rows,
                                                  C.device_wo(), nullptr), "CloverMatrix4::gemm");
         else
             clover_hip::check(clm4_gemm(qa, dev_scales(), rows, cols, qb, B.dev_scales(), B.rows, C.device_wo(), nullptr), "CloverMatrix4::gemm");

@@ -130,7 +130,10 @@ int  clm4_gemm(const int8_t *A, const float *sA, uint64_t M, uint64_t K,
 /* The matrix kernel behind clm4_gemm streams its operands as FP6 (E2M3) codes in staging order; clm4_gemm re-codes both of them on
  * every call.  An operand that is multiplied many times (weights) can be re-coded once: clm4_gemm_prepare allocates rows*K*3/4
  * bytes of HBM for the image (it keeps no reference to q: prepare again after q changes), clm4_gemm_prepared takes either operand
- * prepared (op != NULL) or raw (op == NULL, nibbles in A / B).  Results are those of clm4_gemm, bit for bit. */
+ * prepared (op != NULL) or raw (op == NULL, nibbles in A / B).  Results are those of clm4_gemm, bit for bit.  An image's staging layout
+ * (128- or 256-row tiles) is chosen from the operand's own row count; when two prepared operands disagree (one has >= 4096 rows on a
+ * 256-CU part, the other fewer) the smaller one is re-coded inside the call, for which its nibbles must be passed besides its image
+ * (A / B may always be given next to opA / opB; CLV_ERR_INVALID if they are needed and missing). */
 typedef struct clm4_gemm_operand clm4_gemm_operand;
 int  clm4_gemm_prepare(const int8_t *q, uint64_t rows, uint64_t K, clm4_gemm_operand **op, void *stream);
 int  clm4_gemm_release(clm4_gemm_operand *op);
@@ -239,6 +242,20 @@ int  clm4_sharded_timing(const clm4_shard_ctx *ctx, int part, float *mvm_ms, flo
 /* ranks in the RCCL communicator the context built (0: none needed), and whether the gather is the single ncclAllGather pair
  * (equal shards) or the per-owner broadcasts (ragged shards) */
 int  clm4_sharded_comm_info(const clm4_shard_ctx *ctx, int *rccl_ranks, int *equal_shards);
+/* The same sharded mvm for loops (no host synchronisation inside; clm4_sharded_mvm above is the blocking convenience form):
+ *   clm4_sharded_set_x        replicate x (host memory or device `part 0`) to every device, stream-ordered;
+ *   clm4_sharded_loop_begin   once: second result buffer + exchange stream per device, `slots` timed steps' worth of events;
+ *   clm4_sharded_mvm_enqueue  step `step`: every shard's kernel into result buffer step & 1 on its compute stream, the all-gather of
+ *                             that buffer on its exchange stream -- the gather of step i overlaps the kernel of step i + 1;
+ *                             timed != 0 (step < slots) keeps the step's events for clm4_sharded_step_timing;
+ *   clm4_sharded_sync         waits for everything enqueued on every device;
+ *   clm4_sharded_result_buf   device pointers of the full result in buffer `buf` held by shard `part`. */
+int  clm4_sharded_set_x(clm4_shard_ctx *ctx, const int8_t *x, const float *sx, int x_on_host);
+int  clm4_sharded_loop_begin(clm4_shard_ctx *ctx, int slots);
+int  clm4_sharded_mvm_enqueue(clm4_shard_ctx *ctx, int step, int timed);
+int  clm4_sharded_sync(clm4_shard_ctx *ctx);
+int  clm4_sharded_step_timing(const clm4_shard_ctx *ctx, int part, int step, float *mvm_ms, float *gather_ms);
+int  clm4_sharded_result_buf(const clm4_shard_ctx *ctx, int part, int buf, const int8_t **r_dev, const float **sr_dev);
 /* C = A * B^T with the sharded A and an N x cols CloverMatrix4 B (host memory or device `part 0`) replicated on every device:
  * device d ends with its rows of C (fp32, N columns), bit-identical to clm4_gemm on the whole matrix; nothing is exchanged
  * between the shards.  Every shard must be a multiple of 128 rows.  C_host (optional) receives the whole C. */

@@ -71,6 +71,23 @@ int main()
     if (A.gemmOperandCached()) { std::printf("image kept after cacheGemmOperand(false)\n"); return 1; }
     B.gemm(A, D1);
     if (!same(D0, D1)) { std::printf("result changed after cacheGemmOperand(false)\n"); return 1; }
+    // 4. a large and a small cached operand: their images are in different staging layouts (256- and 128-row tiles; the layout follows
+    //    an operand's own row count), and the call re-codes the smaller one -- same bits as the uncached product, either way round
+    {
+        const uint64_t ML = 4096, NS = 256, KL = 256;
+        CloverMatrix32 l32(ML, KL), s32(NS, KL);
+        fill(l32, 5); fill(s32, 6);
+        CloverMatrix4 L(ML, KL), S(NS, KL), Lref(ML, KL), Sref(NS, KL);
+        L.quantize(l32); S.quantize(s32); Lref.quantize(l32); Sref.quantize(s32);
+        CloverMatrix32 E0(ML, NS), E1(ML, NS), F0(NS, ML), F1(NS, ML);
+        Lref.gemm(Sref, E0); Sref.gemm(Lref, F0);
+        L.cacheGemmOperand(); S.cacheGemmOperand();
+        L.gemm(S, E1);
+        if (!same(E0, E1)) { std::printf("large x small cached gemm differs from the uncached one\n"); return 1; }
+        S.gemm(L, F1);
+        if (!same(F0, F1)) { std::printf("small x large cached gemm differs from the uncached one\n"); return 1; }
+        if (!L.gemmOperandCached() || !S.gemmOperandCached()) { std::printf("images of the mixed pair not kept\n"); return 1; }
+    }
     std::printf("gemm_cache ok\n");
     return 0;
 }
