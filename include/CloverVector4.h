@@ -173,9 +173,11 @@ public:
     }
 
     /* dot(): the reference's summation order, bit for bit (16 sequential fma chains: latency-bound by definition, 0.385 ms at
-     * n = 2^24).  dot_parallel() / dot_fast(): exact integer block sums, fp32 tree order -- memory-bound (6.8 TB/s), within
-     * 2e-6 * sum|terms| of dot(), as the reference's own dot_parallel differs from its dot.  -DCLOVER_DOT_FAST makes dot() the
-     * fast order for code that calls dot() in a loop and does not need the reference's last bits. */
+     * n = 2^24 -- NOT faster than one host core running the same order, 0.32 ms on the bench host; the floor is n/128 dependent
+     * fmas).  dot_parallel() / dot_fast(): exact integer block sums, fp32 tree order -- memory-bound (6.8 TB/s), within
+     * 2e-6 * sum|terms| of dot(), as the reference's own dot_parallel differs from its dot.
+     * RULE OF THUMB: n >= 2^20 -> call dot_parallel() (the reference's own name for "any order"), or build with -DCLOVER_DOT_FAST,
+     * which makes dot() the fast order for code that calls dot() in a loop and does not need the reference's last bits. */
 #ifdef CLOVER_DOT_FAST
     float dot(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
 #else

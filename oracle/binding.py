@@ -214,6 +214,7 @@ class FastOracle:
         _ensure_built()
         L = C.CDLL(str(_HERE / "liboracle_fast.so"))
         L.orcf_v4_dot.restype = C.c_float
+        L.orcf_v4_dot_parallel.restype = C.c_float
         L.orcf_max_threads.restype = C.c_int
         self.L = L
         if threads:
@@ -245,6 +246,20 @@ class FastOracle:
 
     def v4_dot(self, qu, su, qv, sv) -> np.float32:
         return np.float32(self.L.orcf_v4_dot(_p(qu, _u8p), _p(su, _fp), _p(qv, _u8p), _p(sv, _fp), _u64(qu.size * 2)))
+
+    def v4_dot_parallel(self, qu, su, qv, sv) -> np.float32:
+        """CloverVector4::dot_parallel's decomposition (block pairs over threads + reduction): tolerance-only, as in the reference"""
+        return np.float32(self.L.orcf_v4_dot_parallel(_p(qu, _u8p), _p(su, _fp), _p(qv, _u8p), _p(sv, _fp), _u64(qu.size * 2)))
+
+    def v4_quantize_into(self, x, q, s) -> None:
+        """quantize without allocating (timed loops)"""
+        self.L.orcf_v4_quantize(_p(x, _fp), _u64(x.size), _p(q, _u8p), _p(s, _fp))
+
+    def m4_gemm(self, qA, sA, M, K, qB, sB, N, out=None) -> np.ndarray:
+        """the build-defined GEMM (one fma chain over the K-blocks per element), AVX2 + OpenMP: whole-result checks at the timed sizes"""
+        c = np.empty(M * N, np.float32) if out is None else out
+        self.L.orcf_m4_gemm(_p(qA, _u8p), _p(sA, _fp), _u64(M), _u64(K), _p(qB, _u8p), _p(sB, _fp), _u64(N), _p(c, _fp))
+        return c.reshape(M, N)
 
     def m4_mvm(self, qA, sA, rows, cols, qx, sx, out=None):
         r = np.zeros(rows // 2, np.uint8) if out is None else out[0]

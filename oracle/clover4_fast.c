@@ -198,3 +198,69 @@ void orcf_m4_mvm(const uint8_t *A, const float *sA, uint64_t rows, uint64_t cols
         quant64(d, 7.0f / m, r + 32 * g);
     }
 }
+
+/* CloverVector4::dot_parallel (CloverVector4.h:1793-1907): block PAIRS split contiguously over the threads
+ * (iter_per_thread = ceil(pairs / nt), :1807-1810), every thread runs dot's two 8-lane fma chains over its own range and folds them with
+ * the same tree, and the per-thread partials meet in an OpenMP `reduction(+:sum)` whose order is unspecified -- so this result is
+ * tolerance-only, like the reference's (never a parity target; timed as "dot, all cores"). */
+float orcf_v4_dot_parallel(const uint8_t *qu, const float *su, const uint8_t *qv, const float *sv, uint64_t n_pad)
+{
+    const uint64_t pairs = n_pad / 128;
+    float sum = 0.0f;
+#pragma omp parallel reduction(+ : sum)
+    {
+#ifdef _OPENMP
+        const uint64_t nt = (uint64_t)omp_get_num_threads(), tid = (uint64_t)omp_get_thread_num();
+#else
+        const uint64_t nt = 1, tid = 0;
+#endif
+        const uint64_t per = (pairs + nt - 1) / nt;
+        const uint64_t start = per * tid, end = start + per < pairs ? start + per : pairs;
+        if (start < end) sum = dot_row(qu + 64 * start, su + 2 * start, qv + 64 * start, sv + 2 * start, 2 * (end - start));
+    }
+    return sum;
+}
+
+/* ---- GEMM (build-defined, clover4_oracle.c orc_m4_gemm): C = A * B^T, A is M x K, B is N x K, one fma chain over the K-blocks per element:
+ *     S_b = sum of the block's 64 nibble products (exact),  c_b = f32(f32(sA * 1/49) * sB),  C = fmaf(c_b, (float)S_b, C)  for b = 0, 1, ...
+ * AVX2: eight columns j at a time -- their eight per-word sum vectors (the maddubs pipeline above) are folded to one vector of eight block
+ * sums with a vphaddd tree, and the eight chains advance with one vfmadd.  Rows of C are split over the threads.  Same bits as the scalar
+ * orc_m4_gemm (tests/test_oracle_properties.py); exists so that WHOLE results of the timed GEMM sizes can be compared. */
+static inline __m256i hsum8x8(const __m256i v[8])
+{
+    /* vphaddd works inside 128-bit halves: after three levels lane k of each half holds the half-sum of v[k]'s (k < 4: from the first level's
+     * ordering), then the halves are added crosswise */
+    const __m256i a01 = _mm256_hadd_epi32(v[0], v[1]), a23 = _mm256_hadd_epi32(v[2], v[3]);
+    const __m256i a45 = _mm256_hadd_epi32(v[4], v[5]), a67 = _mm256_hadd_epi32(v[6], v[7]);
+    const __m256i b0123 = _mm256_hadd_epi32(a01, a23), b4567 = _mm256_hadd_epi32(a45, a67);
+    /* b0123 = [s0 s1 s2 s3 | s0' s1' s2' s3'] (low / high half partial sums), b4567 likewise for 4..7 */
+    const __m256i lo = _mm256_permute2x128_si256(b0123, b4567, 0x20);      /* low halves:  [s0..s3 | s4..s7]   */
+    const __m256i hi = _mm256_permute2x128_si256(b0123, b4567, 0x31);      /* high halves: [s0'..s3' | s4'..s7'] */
+    return _mm256_add_epi32(lo, hi);
+}
+
+void orcf_m4_gemm(const uint8_t *A, const float *sA, uint64_t M, uint64_t K, const uint8_t *B, const float *sB, uint64_t N, float *C)
+{
+    const uint64_t kb = K / 64;
+    const int64_t rows = (int64_t)M;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < rows; i++) {
+        const uint8_t *a = A + (uint64_t)i * (K / 2);
+        const float *sa = sA + ((uint64_t)i >> 6) * kb;
+        for (uint64_t j = 0; j < N; j += 8) {
+            const float *sb = sB + (j >> 6) * kb;
+            __m256 acc = _mm256_setzero_ps();
+            for (uint64_t b = 0; b < kb; b++) {
+                const __m256i u = _mm256_loadu_si256((const __m256i *)(a + 32 * b));
+                __m256i w[8];
+                for (int t = 0; t < 8; t++) {
+                    const __m256i v = _mm256_loadu_si256((const __m256i *)(B + (j + (uint64_t)t) * (K / 2) + 32 * b));
+                    w[t] = g_kernel ? block_word_isums_maddubs(u, v) : block_word_isums(u, v);
+                }
+                const float c = (sa[b] * RCP49) * sb[b];
+                acc = _mm256_fmadd_ps(_mm256_set1_ps(c), _mm256_cvtepi32_ps(hsum8x8(w)), acc);
+            }
+            _mm256_storeu_ps(C + (uint64_t)i * N + j, acc);
+        }
+    }
+}

@@ -172,3 +172,39 @@ def test_fast_oracle_mvm_equals_scalar(oracle, fast_oracle):
         qx = oracle.v4_quantize(rng.normal(size=N).astype(np.float32))
         r0, r1 = oracle.m4_mvm(qA, sA, M, N, *qx), fast_oracle.m4_mvm(qA, sA, M, N, *qx)
         assert np.array_equal(r0[0], r1[0]) and np.array_equal(bits(r0[1]), bits(r1[1]))
+
+
+@pytest.mark.parametrize("kernel", ["maddubs", "planes"])
+def test_fast_oracle_gemm_equals_scalar(oracle, fast_oracle, kernel):
+    """orcf_m4_gemm (AVX2 + OpenMP, 8 columns per fma) is the checker of the WHOLE GEMM results at 4096^3 / 8192^3: it must itself be
+    the scalar definition bit for bit, incl. all-+-7 operands (block sums +-3136) and scales 30 decades apart"""
+    fast_oracle.set_kernel(kernel)
+    rng = np.random.default_rng(8)
+    for (M, N, K) in ((128, 128, 128), (256, 384, 640), (128, 256, 1024)):
+        A = (rng.normal(size=(M, K)) * 10.0 ** rng.integers(-15, 15, size=(M, 1))).astype(np.float32)
+        B = rng.normal(size=(N, K)).astype(np.float32)
+        qA, sA = oracle.m4_quantize(A)
+        qB, sB = oracle.m4_quantize(B)
+        assert np.array_equal(bits(oracle.m4_gemm(qA, sA, M, K, qB, sB, N)), bits(fast_oracle.m4_gemm(qA, sA, M, K, qB, sB, N)))
+    q7, q9 = np.full(128 * 128 // 2, 0x77, np.uint8), np.full(128 * 128 // 2, 0x99, np.uint8)
+    s = np.full(4, 3.0, np.float32)
+    for a, b in ((q7, q7), (q7, q9), (q9, q9)):
+        assert np.array_equal(bits(oracle.m4_gemm(a, s, 128, 128, b, s, 128)), bits(fast_oracle.m4_gemm(a, s, 128, 128, b, s, 128)))
+    fast_oracle.set_kernel("maddubs")
+
+
+def test_fast_oracle_dot_parallel_is_tolerance_only(oracle, fast_oracle):
+    """dot_parallel's decomposition (CloverVector4.h:1793-1907): thread partials summed in unspecified order -- the reference's own
+    check allows 0.02 absolute on small vectors (test/validate/02_vector.cpp); here relative 1e-5 of the sum of magnitudes"""
+    rng = np.random.default_rng(9)
+    n = 1 << 16
+    a, b = oracle.v4_quantize(ints(rng, n, 10)), oracle.v4_quantize(ints(rng, n, 10))
+    d, dp = float(fast_oracle.v4_dot(*a, *b)), float(fast_oracle.v4_dot_parallel(*a, *b))
+    mag = float(np.abs(oracle.v4_restore(*a) * oracle.v4_restore(*b)).sum())
+    assert abs(d - dp) <= 1e-5 * mag
+    before = fast_oracle.max_threads()
+    fast_oracle.set_threads(1)
+    try:
+        assert bits(fast_oracle.v4_dot_parallel(*a, *b)) == bits(fast_oracle.v4_dot(*a, *b))   # one thread: dot's own order
+    finally:
+        fast_oracle.set_threads(before)
