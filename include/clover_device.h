@@ -18,11 +18,25 @@
  * A SIGSEGV handler (installed once, chained in front of whatever was there) resolves faults that hit a tracked block, so
  * a pointer kept across a device operation reads the kernel's results and a write through it reaches the next kernel --
  * at the price of one fault (a few microseconds) per state change, none while an object stays on one side.  Accessor
- * methods (get(), set(), getBits() ...) switch state directly and never fault.  Limits, all loud rather than silent: a
- * system call given a pointer into a DEVICE_DIRTY block returns EFAULT instead of faulting (use the accessors or touch the
- * memory first); debuggers stop on the resolved SIGSEGVs (gdb: `handle SIGSEGV nostop noprint`).  Building with
- * -DCLOVER_HIP_NO_PAGE_TRACKING disables all of it: getData() then conservatively invalidates the device copy, and a pointer
- * kept across a device operation is stale (the round-1 behaviour).
+ * methods (get(), set(), getBits() ...) switch state directly and never fault.
+ *
+ * Threads (round 3).  The reference's raw pointers may be read by any number of host threads at once; so may these:
+ *   - every state change of a block -- from a method or from a fault -- runs under that block's own lock and re-checks the state
+ *     after taking it, so two threads faulting on one block resolve it once (the second finds it done and just retries its access),
+ *     and a fault racing an upload / a kernel hand-over on another thread is ordered with it;
+ *   - the handler finds the block by binary search in an address-sorted table under the tracker lock and PINS it before dropping that
+ *     lock; a destructor unlinks the block first and then waits for the pins to drain, so the handler never touches a dead object;
+ *   - the handler itself only does atomics, mprotect and futex calls.  The device -> host copy a DEVICE_DIRTY fault needs is done by a
+ *     helper thread (started with the first tracked block) in ordinary context -- no HIP runtime call, allocation or stdio happens in
+ *     signal context.  (-DCLOVER_HIP_FAULT_INLINE, or a process that forked, copies from the handler as rounds 1-2 did.)
+ *   What stays the caller's job, as in the reference: two threads CALLING METHODS that write one object need their own ordering
+ *   (objects are not thread-safe, CloverVector4.h:59-66: mutable RNG state, shared scratch).
+ * Limits, all loud rather than silent: a system call given a pointer into a DEVICE_DIRTY block returns EFAULT instead of faulting, and
+ * a HIP runtime call given such a pointer faults inside the runtime, where the helper's copy may need a lock the faulting thread
+ * holds (use the accessors or touch the memory first -- the containers do that for their own copies, detail::touch_for_*);
+ * debuggers stop on the resolved SIGSEGVs (gdb: `handle SIGSEGV nostop noprint`).  Building with -DCLOVER_HIP_NO_PAGE_TRACKING
+ * disables all of it: getData() then conservatively invalidates the device copy, and a pointer kept across a device operation is
+ * stale (the round-1 behaviour).
  *
  * Non-owning views (CloverVector4(n, values, scales), CloverVector4.h:114-119) alias caller memory that cannot be
  * protected (not page-granular): they are written through -- every device result is copied back into the caller's memory
@@ -43,9 +57,18 @@
 #include <iostream>
 #include <random>
 
+#include <errno.h>
+#include <pthread.h>
 #include <signal.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
 #include <unistd.h>
+#if defined(__linux__)
+#include <linux/futex.h>
+#endif
+#if defined(__x86_64__)
+#include <ucontext.h>
+#endif
 
 #include "clover_hip.h"
 
@@ -65,16 +88,56 @@ class Mirror;
 
 namespace detail {
 
-/* process-wide list of tracked blocks + the chained SIGSEGV handler.  Lives in an inline function so that every
- * translation unit including this header shares one instance (C++11). */
+/* test-and-test-and-set lock on a lock-free atomic: usable from the signal handler */
+struct SpinLock {
+    std::atomic<int> v;
+    SpinLock() : v(0) {}
+    void lock()
+    {
+        while (v.exchange(1, std::memory_order_acquire))
+            while (v.load(std::memory_order_relaxed)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+    }
+    void unlock() { v.store(0, std::memory_order_release); }
+};
+struct Guard {
+    SpinLock &l;
+    explicit Guard(SpinLock &lk) : l(lk) { l.lock(); }
+    ~Guard() { l.unlock(); }
+    Guard(const Guard &) = delete;
+    Guard &operator=(const Guard &) = delete;
+};
+
+inline long futex(std::atomic<int> *word, int op, int val)
+{
+#if defined(__linux__)
+    return syscall(SYS_futex, reinterpret_cast<int *>(word), op, val, nullptr, nullptr, 0);      /* a plain system call: async-signal-safe */
+#else
+    (void)word; (void)op; (void)val;
+    return 0;
+#endif
+}
+
+/* process-wide table of tracked blocks (sorted by host address), the chained SIGSEGV handler and the helper thread that performs
+ * device -> host copies on behalf of faulting threads.  Lives in an inline function so that every translation unit including
+ * this header shares one instance (C++11). */
 struct Tracker {
-    std::atomic_flag lock;
-    Mirror *head;
+    SpinLock lock;                     /* guards table / count / cap */
+    Mirror **table;
+    size_t count, cap;
     struct sigaction previous;
     bool installed;
-    Tracker() : head(nullptr), installed(false) { lock.clear(); }
-    void acquire() { while (lock.test_and_set(std::memory_order_acquire)) {} }
-    void release() { lock.clear(std::memory_order_release); }
+    /* helper thread mailbox: one request at a time (req_lock), word: 0 idle, 1 posted, 2 done */
+    SpinLock req_lock;
+    std::atomic<int> req_word;
+    Mirror *req_mirror;
+    int req_after;
+    std::atomic<int> helper_pid;       /* pid of the process the helper thread lives in (0: none): a forked child has no helper */
+    pthread_t helper;
+    Tracker() : table(nullptr), count(0), cap(0), installed(false), req_word(0), req_mirror(nullptr), req_after(0), helper_pid(0), helper() {}
 };
 inline Tracker &tracker()
 {
@@ -82,6 +145,7 @@ inline Tracker &tracker()
     return t;
 }
 inline void fault_handler(int sig, siginfo_t *info, void *uctx);
+inline void *helper_main(void *);
 inline bool install_handler_once()
 {
     Tracker &t = tracker();
@@ -92,6 +156,16 @@ inline bool install_handler_once()
     sigemptyset(&sa.sa_mask);
     sigaction(SIGSEGV, &sa, &t.previous);
     t.installed = true;
+#if !defined(CLOVER_HIP_FAULT_INLINE) && defined(__linux__)
+    sigset_t all, old;                          /* the helper never handles signals itself */
+    sigfillset(&all);
+    pthread_sigmask(SIG_SETMASK, &all, &old);
+    if (pthread_create(&t.helper, nullptr, helper_main, nullptr) == 0) {
+        pthread_detach(t.helper);
+        t.helper_pid.store((int)getpid(), std::memory_order_release);
+    }
+    pthread_sigmask(SIG_SETMASK, &old, nullptr);
+#endif
     return true;
 }
 inline void install_handler()
@@ -125,7 +199,7 @@ class Mirror {
 public:
     enum State { HOST_DIRTY, SHARED, DEVICE_DIRTY };
 
-    Mirror() : host_(nullptr), dev_(nullptr), bytes_(0), span_(0), state_(HOST_DIRTY), owns_host_(true), pending_(false), version_(0), next_(nullptr), prev_(nullptr) {}
+    Mirror() : host_(nullptr), alias_(nullptr), dev_(nullptr), bytes_(0), span_(0), state_(HOST_DIRTY), owns_host_(true), mapped_(false), pending_(false), version_(0), pins_(0), spurious_(0) {}
     ~Mirror() { release(); }
     Mirror(const Mirror &) = delete;
     Mirror &operator=(const Mirror &) = delete;
@@ -136,14 +210,9 @@ public:
         bytes_ = bytes;
         const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE);
         span_ = round_up(bytes ? bytes : 1, page);                 /* whole pages: protection must not touch a neighbour */
-        void *p = nullptr;
-        if (posix_memalign(&p, (size_t)page, span_) != 0) {
-            std::cout << "Could not allocate host memory. Exiting ..." << std::endl;
-            exit(1);
-        }
-        host_ = static_cast<uint8_t *>(p);
+        map_block((size_t)page);
         owns_host_ = true;
-        state_ = HOST_DIRTY;
+        state_.store(HOST_DIRTY, std::memory_order_release);
 #ifndef CLOVER_HIP_NO_PAGE_TRACKING
         detail::install_handler();
         link();
@@ -154,15 +223,15 @@ public:
     void adopt(void *host, uint64_t bytes)
     {
         release();
-        host_ = static_cast<uint8_t *>(host);
+        host_ = alias_ = static_cast<uint8_t *>(host);
         bytes_ = bytes;
         span_ = 0;
         owns_host_ = false;
-        state_ = HOST_DIRTY;
+        state_.store(HOST_DIRTY, std::memory_order_release);
     }
 
     uint64_t bytes() const { return bytes_; }
-    State state() const { return state_; }
+    State state() const { return (State)state_.load(std::memory_order_acquire); }
     /* counts every event after which the DEVICE copy may hold other bytes than before (an upload, a kernel that was handed a
      * writable pointer): what is derived from the device copy -- CloverMatrix4's cached GEMM operand image -- is valid for one
      * value of it.  Read it AFTER dev_ro(): a pending upload is counted there. */
@@ -183,38 +252,31 @@ public:
     /* host pointer that the CALLER IS ABOUT TO WRITE THROUGH (accessor methods: set(), clear(), ...) */
     uint8_t *host_rw()
     {
-        if (!owns_host_) { commit(); return host_; }
-        if (state_ == DEVICE_DIRTY) pull(HOST_DIRTY);
-        else if (state_ == SHARED) set_state(HOST_DIRTY);
+        detail::Guard g(lock_);
+        if (!owns_host_) { commit_locked(); return host_; }
+        const State s = state();
+        if (s == DEVICE_DIRTY) pull(HOST_DIRTY);
+        else if (s == SHARED) set_state(HOST_DIRTY);
         return host_;
     }
     /* host pointer for reading only */
     const uint8_t *host_ro()
     {
-        if (!owns_host_) { commit(); return host_; }
-        if (state_ == DEVICE_DIRTY) pull(SHARED);
+        detail::Guard g(lock_);
+        if (!owns_host_) { commit_locked(); return host_; }
+        if (state() == DEVICE_DIRTY) pull(SHARED);
         return host_;
     }
     /* device pointer for reading: uploads if the host side is newer */
     const uint8_t *dev_ro()
     {
-        ensure_dev();
-        if (!owns_host_) {                         /* view: the caller may have written its memory at any time */
-            detail::touch_for_read(host_, bytes_);
-            check(clv_memcpy_h2d(dev_, host_, bytes_, nullptr), "host->device copy");
-            check(clv_stream_sync(nullptr), "stream sync");
-            ++version_;
-        } else if (state_ == HOST_DIRTY) {
-            check(clv_memcpy_h2d(dev_, host_, bytes_, nullptr), "host->device copy");
-            check(clv_stream_sync(nullptr), "stream sync");
-            set_state(SHARED);
-            ++version_;
-        }
-        return dev_;
+        detail::Guard g(lock_);
+        return dev_ro_locked();
     }
     /* device pointer that a kernel is about to overwrite completely; follow the launch with commit() */
     uint8_t *dev_wo()
     {
+        detail::Guard g(lock_);
         ensure_dev();
         ++version_;
         if (owns_host_) set_state(DEVICE_DIRTY);
@@ -224,7 +286,8 @@ public:
     /* device pointer that a kernel updates in place; follow the launch with commit() */
     uint8_t *dev_rw()
     {
-        dev_ro();
+        detail::Guard g(lock_);
+        dev_ro_locked();
         ++version_;
         if (owns_host_) set_state(DEVICE_DIRTY);
         else pending_ = true;
@@ -233,29 +296,72 @@ public:
     /* after the launches that wrote through dev_wo()/dev_rw(): views copy the result back into the caller's memory now */
     void commit()
     {
-        if (owns_host_ || !pending_) return;
-        pending_ = false;
-        detail::touch_for_write(host_, bytes_);
-        check(clv_memcpy_d2h(host_, dev_, bytes_, nullptr), "device->host copy");
+        detail::Guard g(lock_);
+        commit_locked();
     }
-    bool device_is_current() const { return state_ != HOST_DIRTY; }
+    bool device_is_current() const { return state() != HOST_DIRTY; }
 
-    /* called by the SIGSEGV handler: true if `addr` lies in this block and the fault was resolved */
+    /* ---- used by the tracker / the SIGSEGV handler ---- */
+    const uint8_t *block_begin() const { return host_; }
     bool contains(const void *addr) const
     {
         const uint8_t *a = static_cast<const uint8_t *>(addr);
         return owns_host_ && host_ && a >= host_ && a < host_ + span_;
     }
-    bool resolve_fault(const void *addr)
+    void pin() { pins_.fetch_add(1, std::memory_order_acq_rel); }
+    void unpin() { pins_.fetch_sub(1, std::memory_order_acq_rel); }
+    /* Signal context, block pinned by the caller.  access: 0 read, 1 write, -1 unknown (no error code on this platform: a fault in a
+     * SHARED block is then taken for a write, as in rounds 1-2).  True = resolved (or already resolved by another thread): the
+     * faulting instruction is simply restarted. */
+    bool resolve_fault(const void *addr, int access)
     {
-        if (!contains(addr)) return false;
-        if (state_ == DEVICE_DIRTY) { pull(SHARED); return true; }       /* a write faults once more and lands below */
-        if (state_ == SHARED) { set_state(HOST_DIRTY); return true; }
-        return false;                                                   /* HOST_DIRTY is unprotected: not ours */
+        detail::Guard g(lock_);
+        if (!contains(addr)) return false;                               /* released and re-used between lookup and lock */
+        const State s = state();
+        if (s == DEVICE_DIRTY) {
+            pull_from_handler(access == 1 ? HOST_DIRTY : SHARED);         /* an access of unknown kind that was a write faults once more */
+            spurious_ = 0;
+            return true;
+        }
+        if (s == SHARED) {
+            if (access != 0) { set_state(HOST_DIRTY); spurious_ = 0; return true; }
+            return ++spurious_ < 1000;                                   /* a read of a readable block: another thread pulled it while we waited */
+        }
+        /* HOST_DIRTY pages are unprotected: either another thread resolved this very fault while we waited for the lock (retry), or
+         * the fault is not a protection fault of ours (the bound turns a loop into the crash it should be) */
+        return ++spurious_ < 1000;
     }
-    Mirror *next_tracked() const { return next_; }
+    /* helper thread: the copy a faulting thread asked for (that thread holds lock_ and waits) */
+    void pull_for_request(int after) { pull((State)after); }
 
 private:
+    const uint8_t *dev_ro_locked()
+    {
+        ensure_dev();
+        if (!owns_host_) {                         /* view: the caller may have written its memory at any time */
+            detail::touch_for_read(host_, bytes_);
+            check(clv_memcpy_h2d(dev_, host_, bytes_, nullptr), "host->device copy");
+            check(clv_stream_sync(nullptr), "stream sync");
+            ++version_;
+        } else if (state() == HOST_DIRTY) {
+            /* read-only FIRST, then the copy (from the alias), then SHARED: a write through a kept pointer on another thread either
+             * lands before the protection (and is uploaded) or faults, waits for lock_ and finds SHARED -> HOST_DIRTY: never lost */
+            protect(PROT_READ);
+            check(clv_memcpy_h2d(dev_, alias_, bytes_, nullptr), "host->device copy");
+            check(clv_stream_sync(nullptr), "stream sync");
+            state_.store(SHARED, std::memory_order_release);
+            spurious_ = 0;
+            ++version_;
+        }
+        return dev_;
+    }
+    void commit_locked()
+    {
+        if (owns_host_ || !pending_) return;
+        pending_ = false;
+        detail::touch_for_write(host_, bytes_);
+        check(clv_memcpy_d2h(host_, dev_, bytes_, nullptr), "device->host copy");
+    }
     void ensure_dev()
     {
         if (!dev_) {
@@ -268,87 +374,212 @@ private:
     {
 #ifndef CLOVER_HIP_NO_PAGE_TRACKING
         if (owns_host_ && host_ && mprotect(host_, span_, prot) != 0) {
-            std::cout << "mprotect failed. Exiting ..." << std::endl;
-            exit(1);
+            static const char msg[] = "mprotect failed. Exiting ...\n";      /* may run in signal context: write(2), _exit(2) */
+            ssize_t w = write(1, msg, sizeof(msg) - 1);
+            (void)w;
+            _exit(1);
         }
 #else
         (void)prot;
 #endif
     }
-    void set_state(State s)
+    void set_state(State s)                                  /* lock_ held */
     {
-        if (s == state_) return;
-        state_ = s;
+        if (s == state()) return;
+        state_.store(s, std::memory_order_release);
         protect(s == HOST_DIRTY ? (PROT_READ | PROT_WRITE) : s == SHARED ? PROT_READ : PROT_NONE);
+        spurious_ = 0;
     }
-    /* device -> host, ending in `after` (SHARED or HOST_DIRTY) */
+    /* device -> host, ending in `after` (SHARED or HOST_DIRTY); lock_ held; ordinary context */
     void pull(State after)
     {
-        protect(PROT_READ | PROT_WRITE);
-        check(clv_memcpy_d2h(host_, dev_, bytes_, nullptr), "device->host copy");
-        state_ = HOST_DIRTY;
+        /* the copy lands through the alias mapping while the user-visible one is still PROT_NONE: a second thread reading through a
+         * kept pointer faults and waits for lock_ instead of seeing half a copy.  (Without the alias -- memfd_create unavailable --
+         * the pages have to be opened first, and such a reader may see bytes of either version until the copy ends.) */
+        if (alias_ == host_) protect(PROT_READ | PROT_WRITE);
+        check(clv_memcpy_d2h(alias_, dev_, bytes_, nullptr), "device->host copy");
+        if (alias_ == host_) state_.store(HOST_DIRTY, std::memory_order_release);
         set_state(after);
     }
-    void link()
+    /* the same from the SIGSEGV handler: hand the copy to the helper thread and wait for it on a futex */
+    void pull_from_handler(State after)
     {
         detail::Tracker &t = detail::tracker();
-        t.acquire();
-        next_ = t.head;
-        prev_ = nullptr;
-        if (t.head) t.head->prev_ = this;
-        t.head = this;
-        t.release();
+#if !defined(CLOVER_HIP_FAULT_INLINE) && defined(__linux__)
+        const int hp = t.helper_pid.load(std::memory_order_acquire);
+        if (hp != 0 && hp == (int)getpid() && !pthread_equal(pthread_self(), t.helper)) {
+            t.req_lock.lock();
+            t.req_mirror = this;
+            t.req_after = (int)after;
+            t.req_word.store(1, std::memory_order_release);
+            detail::futex(&t.req_word, FUTEX_WAKE, 1);
+            while (t.req_word.load(std::memory_order_acquire) != 2) detail::futex(&t.req_word, FUTEX_WAIT, 1);
+            t.req_word.store(0, std::memory_order_release);
+            t.req_lock.unlock();
+            return;
+        }
+#endif
+        (void)t;
+        pull(after);                                /* no helper (inline build, forked child): as rounds 1-2 */
     }
-    void unlink()
-    {
-        detail::Tracker &t = detail::tracker();
-        t.acquire();
-        if (prev_) prev_->next_ = next_;
-        else if (t.head == this) t.head = next_;
-        if (next_) next_->prev_ = prev_;
-        next_ = prev_ = nullptr;
-        t.release();
-    }
+    void link();
+    void unlink();
     void release()
     {
-        if (dev_) clv_free(dev_);
         if (host_ && owns_host_) {
 #ifndef CLOVER_HIP_NO_PAGE_TRACKING
-            unlink();
-            mprotect(host_, span_, PROT_READ | PROT_WRITE);            /* hand the pages back to the allocator usable */
+            unlink();                                                   /* no new fault can find this block ... */
+            while (pins_.load(std::memory_order_acquire) != 0) {}       /* ... and the ones that did have finished with it */
+            lock_.lock();
+            if (!mapped_) mprotect(host_, span_, PROT_READ | PROT_WRITE);   /* hand the pages back to the allocator usable */
+            lock_.unlock();
 #endif
-            free(host_);
+            if (mapped_) {
+                munmap(host_, span_);
+                munmap(alias_, span_);
+            } else {
+                free(host_);
+            }
         }
+        if (dev_) clv_free(dev_);
         host_ = nullptr;
+        alias_ = nullptr;
+        mapped_ = false;
         dev_ = nullptr;
         bytes_ = 0;
         span_ = 0;
-        state_ = HOST_DIRTY;
+        state_.store(HOST_DIRTY, std::memory_order_release);
         pending_ = false;
     }
+    /* the host block: two mappings of one anonymous memory file where the platform has memfd_create (tracked builds), else one
+     * page-aligned allocation as in the reference (CloverVector4.h:70-79) */
+    void map_block(size_t page)
+    {
+#if !defined(CLOVER_HIP_NO_PAGE_TRACKING) && defined(__linux__) && defined(SYS_memfd_create)
+        const int fd = (int)syscall(SYS_memfd_create, "clover_block", 1u /* MFD_CLOEXEC */);
+        if (fd >= 0) {
+            void *a = MAP_FAILED, *b = MAP_FAILED;
+            if (ftruncate(fd, (off_t)span_) == 0) {
+                a = mmap(nullptr, span_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                if (a != MAP_FAILED) b = mmap(nullptr, span_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            }
+            close(fd);
+            if (a != MAP_FAILED && b != MAP_FAILED) {
+                host_ = static_cast<uint8_t *>(a);
+                alias_ = static_cast<uint8_t *>(b);
+                mapped_ = true;
+                return;
+            }
+            if (a != MAP_FAILED) munmap(a, span_);
+        }
+#endif
+        void *p = nullptr;
+        if (posix_memalign(&p, page, span_) != 0) {
+            std::cout << "Could not allocate host memory. Exiting ..." << std::endl;
+            exit(1);
+        }
+        host_ = alias_ = static_cast<uint8_t *>(p);
+        mapped_ = false;
+    }
 
-    uint8_t *host_;
+    uint8_t *host_;                    /* the address the user sees: this mapping carries the protection */
+    uint8_t *alias_;                   /* the same pages, always read/write, never handed out: where device -> host copies land */
     uint8_t *dev_;
     uint64_t bytes_, span_;
-    volatile State state_;             /* also written by the fault handler: always re-read */
+    std::atomic<int> state_;           /* a State; written under lock_, read anywhere */
     bool owns_host_;
-    volatile bool pending_;
+    bool mapped_;                      /* host_/alias_ are two mmaps of one memfd (else: posix_memalign, alias_ == host_) */
+    bool pending_;
     uint64_t version_;                 /* see device_version() */
-    Mirror *next_, *prev_;             /* intrusive list of tracked blocks (detail::Tracker) */
+    detail::SpinLock lock_;            /* every state change of this block, from methods and from the fault handler */
+    std::atomic<int> pins_;            /* fault handlers between table lookup and resolution: the destructor waits for 0 */
+    int spurious_;                     /* faults that found nothing to do since the last state change (under lock_) */
 };
 
+inline void Mirror::link()
+{
+    detail::Tracker &t = detail::tracker();
+    detail::Guard g(t.lock);
+    if (t.count == t.cap) {
+        const size_t ncap = t.cap ? 2 * t.cap : 64;
+        Mirror **nt = static_cast<Mirror **>(realloc(t.table, ncap * sizeof(Mirror *)));
+        if (!nt) {
+            std::cout << "Could not allocate host memory. Exiting ..." << std::endl;
+            exit(1);
+        }
+        t.table = nt;
+        t.cap = ncap;
+    }
+    size_t lo = 0, hi = t.count;                       /* first entry whose block begins above ours */
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (t.table[mid]->block_begin() < host_) lo = mid + 1;
+        else hi = mid;
+    }
+    memmove(t.table + lo + 1, t.table + lo, (t.count - lo) * sizeof(Mirror *));
+    t.table[lo] = this;
+    t.count++;
+}
+inline void Mirror::unlink()
+{
+    detail::Tracker &t = detail::tracker();
+    detail::Guard g(t.lock);
+    for (size_t i = 0; i < t.count; i++)
+        if (t.table[i] == this) {
+            memmove(t.table + i, t.table + i + 1, (t.count - i - 1) * sizeof(Mirror *));
+            t.count--;
+            break;
+        }
+}
+
 namespace detail {
+/* the tracked block that contains addr, pinned; or NULL.  Signal context: a spin lock and a binary search. */
+inline Mirror *find_and_pin(const void *addr)
+{
+    Tracker &t = tracker();
+    Guard g(t.lock);
+    size_t lo = 0, hi = t.count;                       /* last entry whose block begins at or below addr */
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (static_cast<const void *>(t.table[mid]->block_begin()) <= addr) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo == 0) return nullptr;
+    Mirror *m = t.table[lo - 1];
+    if (!m->contains(addr)) return nullptr;
+    m->pin();
+    return m;
+}
+inline void *helper_main(void *)
+{
+    Tracker &t = tracker();
+    for (;;) {
+        int w;
+        while ((w = t.req_word.load(std::memory_order_acquire)) != 1) futex(&t.req_word, FUTEX_WAIT, w);
+        t.req_mirror->pull_for_request(t.req_after);
+        t.req_word.store(2, std::memory_order_release);
+        futex(&t.req_word, FUTEX_WAKE, 64);
+    }
+    return nullptr;
+}
 inline void fault_handler(int sig, siginfo_t *info, void *uctx)
 {
     Tracker &t = tracker();
+    const int saved_errno = errno;
     const void *addr = info ? info->si_addr : nullptr;
-    Mirror *hit = nullptr;
-    if (addr) {
-        t.acquire();
-        for (Mirror *m = t.head; m && !hit; m = m->next_tracked())
-            if (m->contains(addr)) hit = m;
-        t.release();
-        if (hit && hit->resolve_fault(addr)) return;       /* resolved: the faulting instruction is restarted */
+    int access = -1;
+#if defined(__x86_64__) && defined(REG_ERR)
+    if (uctx) {
+        const unsigned long err = (unsigned long)static_cast<ucontext_t *>(uctx)->uc_mcontext.gregs[REG_ERR];
+        access = (err & 16) ? 2 : (err & 2) ? 1 : 0;                /* page-fault error code: bit 1 write, bit 4 instruction fetch */
+    }
+#endif
+    if (addr && access != 2) {
+        if (Mirror *hit = find_and_pin(addr)) {
+            const bool ok = hit->resolve_fault(addr, access);
+            hit->unpin();
+            if (ok) { errno = saved_errno; return; }                 /* resolved: the faulting instruction is restarted */
+        }
     }
     /* not ours: behave as if this handler had never been installed */
     if (t.previous.sa_flags & SA_SIGINFO) {

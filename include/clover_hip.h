@@ -25,6 +25,14 @@
  *  - results: bit-identical to the reference's AVX2 path when stochastic rounding is disabled
  *    (rng == NULL); with an rng state the same XORShift stream as the reference's sequential methods is
  *    consumed (bit-identical nibbles for identical keys).  Exceptions are spelled out per function.
+ *  - STOCHASTIC CALLS (any function given a non-NULL rng_state_dev: clv4_quantize, clm4_quantize, clm4_mvm, clv4_scale_and_add,
+ *    clm4_mvm_scale_and_add, clv8_quantize, clv8_scale_and_add, clm4_mvm_v8, clm4_mvm_v8_scale_and_add, clm4_iht, clm4_iht_v8):
+ *      (1) calls that share a state buffer must be STREAM-ORDERED -- the same stream, or an event / sync between them: they consume one
+ *          sequential XORShift stream, as the reference's methods do on one object, and each launch reads the state its predecessor left;
+ *      (2) such a call must NOT be captured into a hipGraph: every launch carries a fresh host-side sequence number as a kernel argument
+ *          (how a kernel tells the state slot written by its predecessor from the one it writes itself); a replayed graph would
+ *          replay the number.  Deterministic calls (rng_state_dev == NULL) capture fine;
+ *      (3) a state belongs to the process that initialised it (re-key with clv_rng_set after sharing the buffer across processes).
  *  - asynchrony: every call only enqueues work on `stream`; results are valid after clv_stream_sync / an event.
  *    clv4_dot, the threshold functions (when `workspace` is NULL) and clm4_gemm use grow-only scratch owned by the library, one
  *    buffer per (device, stream): calls on different streams never share scratch and may overlap.
@@ -91,7 +99,8 @@ int  clv_rng_get(const uint64_t *state_dev, uint64_t key1[4], uint64_t key2[4], 
 /* ---- CloverVector4 ---------------------------------------------------------------------------- */
 /* CloverVector4::quantize (CloverVector4.h:605-807).  x: n_pad floats; q: n_pad/2 bytes; s: n_pad/64
  * floats.  rng_state_dev == NULL <=> CLOVER_STOCHASTIC_ROUNDING_DISABLED; otherwise two draws per block
- * are consumed in block order and the state is advanced in place, as the sequential method does. */
+ * are consumed in block order and the state is advanced in place, as the sequential method does (with an rng: order the calls
+ * that share the state on one stream, and do not capture them in a hipGraph -- "STOCHASTIC CALLS" above). */
 int  clv4_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream);
 /* CloverVector4::restore (CloverVector4.h:1027-1093). */
 int  clv4_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, void *stream);
@@ -107,14 +116,15 @@ int  clv4_word_isums(const int8_t *qu, const int8_t *qv, uint64_t n_pad, int32_t
 /* ---- CloverMatrix4 ---------------------------------------------------------------------------- */
 /* CloverMatrix4::quantize (CloverMatrix4.h:512-766).  A: rows*cols floats row-major; q: rows*cols/2
  * bytes; s: (rows/64)*(cols/64) floats.  With an rng the tiles consume the stream in the reference's
- * order (column-block outer, row-block inner, two draws per tile row). */
+ * order (column-block outer, row-block inner, two draws per tile row).  With an rng: stream-ordered per state, no graph capture. */
 int  clm4_quantize(const float *A, uint64_t rows, uint64_t cols, int8_t *q, float *s,
                    uint64_t *rng_state_dev, void *stream);
 /* CloverMatrix4::restore_scalar (CloverMatrix4.h:266-301): A[i][j] = f32(s_tile/7) * q, rows*cols floats row-major */
 int  clm4_restore(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, float *A, void *stream);
 /* CloverMatrix4::mvm(const CloverVector4&, CloverVector4&) (CloverMatrix4.h:777-1083) and mvm_parallel
  * (:1681-2006; same results).  x: cols/2 bytes + cols/64 scales; r: rows/2 bytes + rows/64 scales
- * (the re-quantised result).  Bit-identical to the reference when rng_state_dev == NULL. */
+ * (the re-quantised result).  Bit-identical to the reference when rng_state_dev == NULL; with an rng the re-quantisation draws two
+ * values per output block from the state (lane map 8j+g, CloverMatrix4.h:925-932): stream-ordered per state, no graph capture. */
 int  clm4_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols,
               const int8_t *x, const float *sx, int8_t *r, float *sr,
               uint64_t *rng_state_dev, void *stream);
@@ -154,7 +164,7 @@ int  clm4_gemm_i32_prepared(const clm4_gemm_operand *opA, const int8_t *A, uint6
 /* ---- callers either side of the hot path: the other steps of the quantized IHT/GD loops ---- */
 /* CloverVector4::scaleAndAdd (CloverVector4.h:1196-1478; _parallel :1489-1791): r = quantize(u + a*v) per
  * 64-block; r/sr may alias qu/su (the in-place overload).  Bit-identical; with an rng the sequential
- * method's XORShift stream and its lane map (element 8j+(g^1)) are reproduced. */
+ * method's XORShift stream and its lane map (element 8j+(g^1)) are reproduced (stream-ordered per state, no graph capture). */
 int  clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
                         int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
 /* mvm immediately followed by scaleAndAdd on its result -- the pairs "t2 = y - Phi x" and "x += mu Phi' t2" of the

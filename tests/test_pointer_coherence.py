@@ -27,9 +27,48 @@ def _build_coherence(tmp_path, extra=()):
 def test_mirror_state_machine_with_fake_device(tmp_path, opt):
     obj, exe = tmp_path / "fake_clv.o", tmp_path / "mirror_states"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-c", f"-I{ROOT / 'include'}", str(CPP / "fake_clv.c"), "-o", str(obj)], check=True)
-    subprocess.run(["g++", "-std=c++11", opt, "-Wall", "-Wextra", f"-I{ROOT / 'include'}", str(CPP / "mirror_states.cpp"), str(obj), "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-std=c++11", opt, "-Wall", "-Wextra", f"-I{ROOT / 'include'}", str(CPP / "mirror_states.cpp"), str(obj), "-o", str(exe), "-lpthread"],
+                   check=True)
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert p.returncode == 0 and "mirror ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+def _build_mirror_threads(tmp_path, *flags):
+    obj, exe = tmp_path / "fake_clv.o", tmp_path / "mirror_threads"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-c", f"-I{ROOT / 'include'}", str(CPP / "fake_clv.c"), "-o", str(obj)], check=True)
+    subprocess.run(["g++", "-std=c++11", *flags, "-Wall", "-Wextra", f"-I{ROOT / 'include'}", str(CPP / "mirror_threads.cpp"), str(obj), "-o", str(exe),
+                    "-lpthread"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("flags", [("-O2",), ("-O0",), ("-O2", "-DCLOVER_HIP_FAULT_INLINE"), ("-O1", "-g", "-fsanitize=thread")],
+                         ids=["O2", "O0", "inline-handler", "tsan"])
+def test_mirror_under_threads_with_fake_device(tmp_path, flags):
+    """four threads faulting on one block, writers racing uploads, the block table changing under lookups, a destructor waiting for
+    a fault in flight (tests/cpp/mirror_threads.cpp); also with the copy made inside the handler, and under ThreadSanitizer"""
+    exe = _build_mirror_threads(tmp_path, *flags)
+    for _ in range(2):
+        p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "mirror threads ok" in p.stdout and "WARNING: ThreadSanitizer" not in p.stderr, (p.returncode, p.stdout, p.stderr[-3000:])
+
+
+def _build_pointer_threads(tmp_path):
+    exe = tmp_path / "pointer_threads"
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}",
+                    str(CPP / "pointer_threads.cpp"), "-o", str(exe), *_link_flags(), "-lpthread"], check=True)
+    return exe
+
+
+def test_pointer_threads_client_builds(tmp_path):
+    p = subprocess.run([str(_build_pointer_threads(tmp_path))], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and ("no_device" in p.stdout or "pointer threads ok" in p.stdout), (p.returncode, p.stdout, p.stderr)
+
+
+@pytest.mark.gpu
+def test_kept_pointers_under_host_threads_on_the_gpu(tmp_path):
+    """mvm / quantize / restore from several threads on shared operands while other threads read and write through kept pointers"""
+    p = subprocess.run([str(_build_pointer_threads(tmp_path))], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "pointer threads ok" in p.stdout, (p.returncode, p.stdout, p.stderr[-2000:])
 
 
 def test_coherence_client_builds_and_a_wild_access_still_crashes(tmp_path):
