@@ -215,9 +215,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--gemm-probe-child", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.warmup is None:
         args.warmup = 80 if args.workload == "gemm" else 20
+    if args.gemm_probe_child:
+        return gemm_probe_child(args.gemm_probe_child, args.gemm_size)
     if args.workload == "gemm":
         return gemm_main(args)
 
@@ -654,6 +657,89 @@ FP6_PEAK_TOPS = 10000.0     # dense FP6/FP4 block-scaled MFMA (MI355X_MICROARCH.
 INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA: the pipe BASELINE's wording names
 
 
+def gemm_probe_child(spec: str, G: int) -> None:
+    """One timing of the 8192^3 GEMM in a process of its own (the kernel switches CLV_GEMM_KERNEL / CLV_GEMM_LOOP are read once per process).
+    spec = "<library>:<call>", library = product | probe (clover_amd/lib/libclover_hip_probe.so: the loop's timing-only variants), call =
+    gemm | prepared | i32_prepared.  No torch: ctypes + the library only.  Prints {"ms": mean of 100 calls after 80 untimed ones}."""
+    import ctypes as C
+
+    from clover_amd.build import probe_library_path
+    from clover_amd.lib_binding import CloverHip
+    which, call = spec.split(":")
+    hip = CloverHip(path=probe_library_path() if which == "probe" else None, device=0)
+    lib = hip.lib
+    A, B = hip.alloc(G * G // 2), hip.alloc(G * G // 2)
+    sA, sB = hip.alloc((G // 64) ** 2 * 4), hip.alloc((G // 64) ** 2 * 4)
+    Cc = hip.alloc(G * G * 4)
+    for t, sd in ((A, 21), (B, 22)):
+        hip.check(lib.clv_fill_random_nibbles(t.ptr, t.nbytes, sd, 0, None))
+    for t, sd in ((sA, 23), (sB, 24)):
+        hip.check(lib.clv_fill_random_scales(t.ptr, t.nbytes // 4, sd, 0, None))
+    opA, opB = C.c_void_p(), C.c_void_p()
+    if call != "gemm":
+        hip.check(lib.clm4_gemm_prepare(A.ptr, G, G, C.byref(opA), None))
+        hip.check(lib.clm4_gemm_prepare(B.ptr, G, G, C.byref(opB), None))
+    fn = {"gemm": lambda: lib.clm4_gemm(A.ptr, sA.ptr, G, G, B.ptr, sB.ptr, G, Cc.ptr, None),
+          "prepared": lambda: lib.clm4_gemm_prepared(opA, None, sA.ptr, G, G, opB, None, sB.ptr, G, Cc.ptr, None),
+          "i32_prepared": lambda: lib.clm4_gemm_i32_prepared(opA, None, G, G, opB, None, G, 0, G // 64, Cc.ptr, None)}[call]
+    for _ in range(80):
+        hip.check(fn())
+    hip.sync()
+    a, b = C.c_void_p(), C.c_void_p()
+    hip.check(lib.clv_event_create(C.byref(a)))
+    hip.check(lib.clv_event_create(C.byref(b)))
+    hip.check(lib.clv_event_record(a, None))
+    for _ in range(100):
+        hip.check(fn())
+    hip.check(lib.clv_event_record(b, None))
+    hip.check(lib.clv_event_sync(b))
+    ms = C.c_float()
+    hip.check(lib.clv_event_elapsed_ms(a, b, C.byref(ms)))
+    print(json.dumps({"ms": ms.value / 100}))
+
+
+def gemm_probe(spec: str, G: int, env_extra: dict) -> float | None:
+    env = dict(os.environ, **env_extra)
+    for k in ("CLV_GEMM_LOOP", "CLV_GEMM_KERNEL", "CLV_GEMM_TILE"):
+        if k not in env_extra:
+            env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, __file__, "--gemm-probe-child", spec, "--gemm-size", str(G)], env=env, check=True, capture_output=True,
+                             text=True, timeout=300).stdout
+        return float(json.loads(out.strip().splitlines()[-1])["ms"])
+    except Exception:
+        return None
+
+
+def gemm_pmc(G: int):
+    """matrix-pipe busy share and memory traffic of the GEMM kernel from the latest committed rocprofv3 --pmc passes (profiles/rNN_gemm_pmc.json,
+    written by tools/gemm_pmc_json.py on the GPU box: counters cannot be collected inside a timed run)"""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_gemm_pmc.json")):
+        try:
+            d = json.loads(f.read_text())
+            if d["G"] == G:
+                best = (d, f.name)
+        except (OSError, KeyError, ValueError):
+            continue
+    return best
+
+
+def smi_power_clock():
+    """socket power (W) and shader clock (MHz) right now, from rocm-smi; None where the tool or a field is missing"""
+    try:
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        power = next((float(v) for k, v in card.items() if "power" in k.lower() and "socket" in k.lower()), None)
+        if power is None:
+            power = next((float(v) for k, v in card.items() if "power" in k.lower() and str(v).replace(".", "", 1).isdigit()), None)
+        sclk = next((v for k, v in card.items() if k.lower().startswith("sclk")), None)
+        mhz = float("".join(ch for ch in str(sclk).split("Mhz")[0].split("(")[-1] if ch.isdigit() or ch == ".")) if sclk else None
+        return {"socket_power_W": power, "sclk_MHz": mhz}
+    except Exception:
+        return None
+
+
 def gemm_object(hip, torch, dev, stream, G: int = 8192) -> dict:
     """BASELINE configs[3]: CloverMatrix4::gemm 8192^3.  One clm4_gemm call = the FP6 re-coding pass over both operands + the matrix
     kernel; timed with HIP events on the launch stream.  Normalised to the FP6 dense peak (the pipe in use); the int8 figure beside."""
@@ -675,16 +761,54 @@ def gemm_object(hip, torch, dev, stream, G: int = 8192) -> dict:
     hip.check(lib.clm4_gemm_prepare(gB.data_ptr(), G, G, C.byref(opB), stream))
     p_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_prepared(opA, None, gsA.data_ptr(), G, G, opB, None, gsB.data_ptr(), G, gC.data_ptr(), stream)), 100, warm=40)
     ip_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_i32_prepared(opA, None, G, G, opB, None, G, 0, G // 64, gC.data_ptr(), stream)), 100, warm=40)
+    # power and clock while the prepared GEMM runs back to back: 4000 calls are enqueued (about 1.5 s of work), sampled 0.5 s in
+    power = None
+    try:
+        for _ in range(4000):
+            hip.check(lib.clm4_gemm_prepared(opA, None, gsA.data_ptr(), G, G, opB, None, gsB.data_ptr(), G, gC.data_ptr(), stream))
+        time.sleep(0.5)
+        power = smi_power_clock()
+        torch.cuda.synchronize()
+    except Exception:
+        torch.cuda.synchronize()
     hip.check(lib.clm4_gemm_release(opA))
     hip.check(lib.clm4_gemm_release(opB))
     i_ms = _timeit(torch, lambda: hip.check(lib.clm4_gemm_i32(gA.data_ptr(), G, G, gB.data_ptr(), G, 0, G // 64, gC.data_ptr(), stream)), 100, warm=40)
     tops = ops / g_ms / 1e9
+    # the ceiling, measured on THIS box: the same main loop with parts left out (bench-only probe library, separate processes), and the
+    # int8-MFMA kernel (the pipe BASELINE's wording names) for comparison
+    full_p = gemm_probe("probe:prepared", G, {})
+    arith = gemm_probe("probe:prepared", G, {"CLV_GEMM_LOOP": "v9"})
+    nofold = gemm_probe("probe:prepared", G, {"CLV_GEMM_LOOP": "v5"})
+    mfma_only = gemm_probe("probe:i32_prepared", G, {"CLV_GEMM_LOOP": "v9"})
+    i8_ms = gemm_probe("product:gemm", G, {"CLV_GEMM_KERNEL": "i8"})
+    ceiling = {
+        "full_loop_ms": full_p, "mfma_plus_fold_only_ms": arith, "no_fold_ms": nofold, "mfma_only_ms": mfma_only,
+        "frac_if_only_arithmetic": round(ops / arith / 1e9 / FP6_PEAK_TOPS, 4) if arith else None,
+        "power_and_clock_during_prepared_gemm": power,
+        "what": "k_m4_gemm_fp6_t256 on prepared operands through clover_amd/lib/libclover_hip_probe.so (bench-only build of the same kernel with "
+                "CLV_GEMM_LOOP=vN variants: v9 = nothing but the wave's MFMAs and the per-K-block fp32 fold -- no staging, fragment reads, "
+                "barrier, store or pointer arithmetic; v5 = the whole loop without the fold; int32 v9 = the MFMAs alone).  The definition's "
+                "one fp32 fma per element and K-block runs on the VALU, which on a CDNA4 SIMD issues BESIDE an MFMA for only 2-5 instructions "
+                "per 32-cycle MFMA (tools/mfma_fold_probe.hip, profiles/r02_mfma_fold_probe.txt: MFMA 14.5 ns + 8 packed fmas 15.8 ns = 30.9 ns "
+                "together): mfma_plus_fold_only_ms is the floor of ANY schedule of this definition on this box, frac_if_only_arithmetic the "
+                "roofline fraction it would give",
+    }
+    pmc = gemm_pmc(G)
     return {
+        "ceiling": ceiling,
+        "int8_mfma_kernel": {"ms": i8_ms, "TOP/s": round(ops / i8_ms / 1e9, 1) if i8_ms else None,
+                             "frac_of_int8_peak": round(ops / i8_ms / 1e9 / INT8_PEAK_TOPS, 4) if i8_ms else None,
+                             "note": "k_m4_gemm_mfma (v_mfma_i32_16x16x64_i8, CLV_GEMM_KERNEL=i8), one clm4_gemm call, own process"},
         "workload": f"CloverMatrix4::gemm {G}x{G}x{G} int4 x int4 -> fp32 (BASELINE configs[3]), both operands re-coded inside the call, "
                     "bit-exact against the build-defined semantics (one fma chain over the 64-element K-blocks per element)",
         "ms": round(g_ms, 4), "value": round(tops, 1), "unit": "TOP/s",
         "roofline": {"bound": "mfma", "achieved": round(tops, 1), "peak": FP6_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / FP6_PEAK_TOPS, 4),
-                     "traffic": None, "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_t256 (one clm4_gemm call)", "kernel_avg_ms": round(g_ms, 4),
+                     "traffic": pmc[0].get("traffic_bytes_per_call") if pmc else None,
+                     **({"traffic_source": f"profiles/{pmc[1]}: " + pmc[0].get("traffic_how", ""),
+                         "mfma_busy_pct": pmc[0].get("mfma_busy_pct"), "mfma_busy_how": pmc[0].get("mfma_busy_how"),
+                         "l2_hit_pct": pmc[0].get("l2_hit_pct"), "algorithmic_bytes_per_call": pmc[0].get("algorithmic_bytes_per_call")} if pmc else {}),
+                     "kernel": "k_m4_to_fp6 + k_m4_gemm_fp6_t256 (one clm4_gemm call)", "kernel_avg_ms": round(g_ms, 4),
                      "frac_of_int8_peak": round(tops / INT8_PEAK_TOPS, 4),
                      "peak_note": "10 POP/s = dense FP6 block-scaled MFMA, the pipe the kernel runs on (nibbles are exact E2M3 values); "
                                   "5 POP/s = dense int8 MFMA, the pipe BASELINE names"},

@@ -47,7 +47,7 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> Path:
     root = repo_root()
     src_dir = root / "clover_amd" / "csrc"
     srcs = [src_dir / s for s in HIP_SOURCES if (src_dir / s).exists()]
-    deps = srcs + list(src_dir.glob("*.h")) + [root / "include" / "clover_hip.h"]
+    deps = srcs + list(src_dir.glob("*.h")) + list(src_dir.glob("*.inc")) + [root / "include" / "clover_hip.h"]
     out = hip_library_path()
     out.parent.mkdir(parents=True, exist_ok=True)
     if force or _stale(out, deps):
@@ -72,6 +72,33 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> Path:
     return out
 
 
+def probe_library_path() -> Path:
+    return repo_root() / "clover_amd" / "lib" / "libclover_hip_probe.so"
+
+
+def build_probe_library(force: bool = False) -> Path:
+    """libclover_hip_probe.so = the product's objects with gemm6.hip compiled a second time under -DCLV_GEMM_EXPERIMENTS: the GEMM main
+    loop's timing-only variants with parts left out (tools/gen_gemm6_loop256.py ... experiments; results wrong by construction), selected
+    by CLV_GEMM_LOOP=vN.  BENCH INFRASTRUCTURE: bench.py's `gemm.ceiling` and tools/gemm_bench.py load it explicitly to measure what the
+    arithmetic alone costs on the box the bench runs on; nothing else ever loads it and the product library has no such switch."""
+    import sys
+    root = repo_root()
+    src_dir = root / "clover_amd" / "csrc"
+    out = probe_library_path()
+    build_hip_library(force=force)
+    obj_dir = hip_library_path().parent / "obj"
+    gen = root / "tools" / "gen_gemm6_loop256.py"
+    deps = [src_dir / "gemm6.hip", gen, hip_library_path()] + list(src_dir.glob("*.h")) + list(src_dir.glob("*.inc"))
+    if force or _stale(out, deps):
+        subprocess.run([sys.executable, str(gen), str(obj_dir / "gemm6_loop256_exp.inc"), "experiments"], check=True, stdout=subprocess.DEVNULL)
+        obj = obj_dir / "gemm6_probe.o"
+        subprocess.run([_hipcc(), *HIP_FLAGS, "-DCLV_GEMM_EXPERIMENTS", f"-I{root / 'include'}", f"-I{src_dir}", f"-I{obj_dir}", "-c", "-o", str(obj),
+                        str(src_dir / "gemm6.hip")], check=True)
+        objs = [str(obj_dir / (Path(s).stem + ".o")) for s in HIP_SOURCES if s != "gemm6.hip"] + [str(obj)]
+        subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *objs, "-ldl"], check=True)
+    return out
+
+
 def build_oracle(force: bool = False) -> Path:
     """Builds oracle/liboracle.so (+ liboracle_fast.so): test infrastructure, never loaded by the product."""
     odir = repo_root() / "oracle"
@@ -86,6 +113,7 @@ def build_oracle(force: bool = False) -> Path:
 
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip_library(force=force, verbose=verbose)
+    build_probe_library(force=force)
     build_oracle(force=force)
 
 

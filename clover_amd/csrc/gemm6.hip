@@ -329,7 +329,11 @@ __global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6_asm(const uint8_t *__res
 // Half the LDS-DMA requests and L2 bytes per MFMA of the 128 x 128 tile (see tools/gen_gemm6_loop256.py for the schedule).
 // A workgroup walks tiles id = blockIdx.x, + gridDim.x, ...; the asm statement is one tile: prologue, main loop, asynchronous
 // store of C.  Operand images are those of k_m4_to_fp6 with tile_rows = 256, padded with zero rows to whole tiles.
+#ifdef CLV_GEMM_EXPERIMENTS          // the bench-only probe library (clover_amd/build.py): the product's loops + timing-only variants
+#include "gemm6_loop256_exp.inc"
+#else
 #include "gemm6_loop256.inc"
+#endif
 #define G6T_TILE 256
 #define G6T_LDS_BYTES (3 * 4 * G6T_TILE * 48)       // three stage buffers of 48 KiB
 

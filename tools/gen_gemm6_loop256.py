@@ -44,6 +44,7 @@ NS = int(os.environ.get("G6T_NS", "8"))     # scalar fmas per fold, the rest pac
 MODE = "scaled"
 # timing-only experiment switches (results are wrong by construction): parts of the loop LEFT OUT
 OFF = set()               # subset of {"dma", "lds", "barrier", "store", "fold"}
+FOLD = os.environ.get("G6T_FOLD", "mixed")   # mixed: NS scalar v_fma + packed; fmac: 16 VOP2 v_fmac_f32; pk: 8 v_pk_fma_f32
 
 FRAG = {"A0": 96, "A1": 102, "B0": 108, "B1": 114}
 VS, VT, VC1 = 120, 121, 122
@@ -92,9 +93,14 @@ def fold(e, m, tile, creg):
     if MODE == "i32" or "fold" in OFF:
         return
     a, r = 16 * tile, 64 + 16 * (m & 1)
-    for i in range(NS):
+    if FOLD == "fmac":                         # VOP2: 4-byte encodings, acc = s * r + acc
+        for i in range(16):
+            e(f"v_fmac_f32 v{a+i}, s{creg}, v{r+i}")
+        return
+    ns = 0 if FOLD == "pk" else NS
+    for i in range(ns):
         e(f"v_fma_f32 v{a+i}, s{creg}, v{r+i}, v{a+i}")
-    for i in range(NS, 16, 2):
+    for i in range(ns, 16, 2):
         e(f"v_pk_fma_f32 v[{a+i}:{a+i+1}], s[{creg}:{creg+1}], v[{r+i}:{r+i+1}], v[{a+i}:{a+i+1}] op_sel_hi:[0,1,1]")
 
 
@@ -309,19 +315,23 @@ EXPERIMENTS = {1: {"dma"}, 2: {"lds"}, 3: {"dma", "lds"}, 4: {"barrier"}, 5: {"f
                8: {"dma", "store"}, 9: {"dma", "lds", "barrier", "store", "salu"}, 10: {"dma", "lds", "store", "salu"}}
 
 
-def main():
-    global MODE, OFF
-    out = sys.argv[1] if len(sys.argv) > 1 else "clover_amd/csrc/gemm6_loop256.inc"
-    experiments = len(sys.argv) > 2 and sys.argv[2] == "experiments"
+CANDIDATES = {1: {"FOLD": "fmac"}, 2: {"FOLD": "pk"}, 3: {"FOLD": "mixed"}}      # `candidates`: CORRECT alternative schedules in slots v1..
+
+
+def write(out, variants, define_experiments):
+    global MODE, OFF, FOLD
+    base_fold = FOLD
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_gemm6_loop256.py -- do not edit; see that file for the schedule and the register map.\n")
         todo = [("G6T_LOOP_ASM", "scaled", set()), ("G6T_LOOP_ASM_I32", "i32", set())]
-        if experiments:
+        if define_experiments:
             f.write("#define G6T_LOOP_EXPERIMENTS 1\n")
-            for v, off in EXPERIMENTS.items():
-                todo += [(f"G6T_LOOP_ASM_V{v}", "scaled", off), (f"G6T_LOOP_ASM_I32_V{v}", "i32", off)]
-        for name, mode, off in todo:
-            MODE, OFF = mode, off
+        for v, spec in variants.items():
+            todo += [(f"G6T_LOOP_ASM_V{v}", "scaled", spec), (f"G6T_LOOP_ASM_I32_V{v}", "i32", spec)]
+        for name, mode, spec in todo:
+            MODE, OFF, FOLD = mode, spec, base_fold
+            if isinstance(spec, dict):                      # a candidate: a CORRECT alternative schedule
+                OFF, FOLD = set(), spec.get("FOLD", base_fold)
             lines = generate()
             f.write(f"#define {name} \\\n")
             for ln in lines:
@@ -331,6 +341,23 @@ def main():
         vregs = list(range(0, 123))
         sregs = list(range(40, 48)) + list(range(52, 78))
         f.write("#define G6T_LOOP_CLOBBERS " + ", ".join(f'"v{i}"' for i in vregs) + ", " + ", ".join(f'"s{i}"' for i in sregs) + ', "scc", "memory"\n')
+
+
+def main():
+    """no argument: clover_amd/csrc/gemm6_loop256.inc, the product's loops (libclover_hip.so; committed).
+       <out> experiments: the same + the timing-only variants v1..v10 with parts LEFT OUT (wrong results by construction).  The build
+            (clover_amd/build.py) generates this into clover_amd/lib/obj/gemm6_loop256_exp.inc and compiles it ONLY into the bench-only probe
+            library clover_amd/lib/libclover_hip_probe.so (-DCLV_GEMM_EXPERIMENTS), where CLV_GEMM_LOOP=vN selects a variant --
+            bench.py's `gemm.ceiling` and tools/gemm_bench.py load that library explicitly; the product library has no such switch.
+       <out> candidates: v1.. = CORRECT alternative schedules (CANDIDATES) for A/B runs through the same switch."""
+    if len(sys.argv) > 2 and sys.argv[2] == "candidates":
+        write(sys.argv[1], {v: CANDIDATES.get(v, {}) for v in range(1, 11)}, True)
+        return
+    if len(sys.argv) > 2 and sys.argv[2] == "experiments":
+        write(sys.argv[1], EXPERIMENTS, True)
+        return
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "clover_amd", "csrc")
+    write(sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "gemm6_loop256.inc"), {}, False)
 
 
 if __name__ == "__main__":
