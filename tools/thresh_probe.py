@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""clv4_threshold on large vectors, a few calls per size, for rocprofv3 --kernel-trace --stats (per-kernel time of the multi-launch path)."""
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clover_amd.lib_binding import CloverHip  # noqa: E402
+
+hip = CloverHip()
+lib = hip.lib
+for logn in [int(v) for v in os.environ.get("TP_LOGN", "24,28").split(",")]:
+    n = 1 << logn
+    q, s = hip.alloc(n // 2), hip.alloc(n // 16)
+    for _ in range(int(os.environ.get("TP_CALLS", "10"))):
+        hip.check(lib.clv_fill_random_nibbles(q.ptr, q.nbytes, 7, 0, None))
+        hip.check(lib.clv_fill_random_scales(s.ptr, n // 64, 8, 0, None))
+        hip.check(lib.clv4_threshold(q.ptr, s.ptr, n, n, n // 4, None, None))
+    hip.sync()
+print("threshold probe done")

@@ -65,6 +65,40 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters)
             REP16(asm volatile("v_max3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_max3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
                                "v_max3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_max3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (MODE == 12) {   // 4-bit signed -> float/16 through the interpolation-offset conversion
+            REP16(asm volatile("v_cvt_off_f32_i4 %0, %8\n v_cvt_off_f32_i4 %1, %9\n v_cvt_off_f32_i4 %2, %10\n v_cvt_off_f32_i4 %3, %11\n"
+                               "v_cvt_off_f32_i4 %4, %12\n v_cvt_off_f32_i4 %5, %13\n v_cvt_off_f32_i4 %6, %14\n v_cvt_off_f32_i4 %7, %15\n"
+                               : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7)
+                               : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "v"(i5), "v"(i6), "v"(i7));)
+        } else if (MODE == 13) {
+            REP16(asm volatile("v_cvt_off_f32_i4_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0\n v_cvt_off_f32_i4_sdwa %1, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n"
+                               "v_cvt_off_f32_i4_sdwa %2, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n v_cvt_off_f32_i4_sdwa %3, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n"
+                               "v_cvt_off_f32_i4_sdwa %4, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0\n v_cvt_off_f32_i4_sdwa %5, %13 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n"
+                               "v_cvt_off_f32_i4_sdwa %6, %14 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n v_cvt_off_f32_i4_sdwa %7, %15 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n"
+                               : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7)
+                               : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "v"(i5), "v"(i6), "v"(i7));)
+        } else if (MODE == 14) {
+            REP16(asm volatile("v_cvt_f32_ubyte0 %0, %8\n v_cvt_f32_ubyte1 %1, %9\n v_cvt_f32_ubyte2 %2, %10\n v_cvt_f32_ubyte3 %3, %11\n"
+                               "v_cvt_f32_ubyte0 %4, %12\n v_cvt_f32_ubyte1 %5, %13\n v_cvt_f32_ubyte2 %6, %14\n v_cvt_f32_ubyte3 %7, %15\n"
+                               : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7)
+                               : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "v"(i5), "v"(i6), "v"(i7));)
+        } else if (MODE == 15) {
+            REP16(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                               "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        } else if (MODE == 16) {   // VOP2 fmac
+            REP16(asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                               "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (MODE == 17) {   // v_pk_mul_f32
+            REP16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                               "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));)
+        } else if (MODE == 18) {   // v_and_b32 with a literal
+            REP16(asm volatile("v_and_b32 %0, 0xf0f0f0f0, %8\n v_and_b32 %1, 0xf0f0f0f0, %9\n v_and_b32 %2, 0xf0f0f0f0, %10\n v_and_b32 %3, 0xf0f0f0f0, %11\n"
+                               "v_and_b32 %4, 0xf0f0f0f0, %12\n v_and_b32 %5, 0xf0f0f0f0, %13\n v_and_b32 %6, 0xf0f0f0f0, %14\n v_and_b32 %7, 0xf0f0f0f0, %15\n"
+                               : "=v"(i0), "=v"(i1), "=v"(i2), "=v"(i3), "=v"(i4), "=v"(i5), "=v"(i6), "=v"(i7)
+                               : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "v"(i5), "v"(i6), "v"(i7));)
         } else {   // 4 independent v_pk_fma_f32 (2 fmas each) x 2 = 8 instrs
             REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
                                "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
@@ -101,7 +135,7 @@ static void run(const char *name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {4}) {
+    for (int w : {2, 4}) {
         run<0>("v_fma_f32", w);
         run<1>("v_cvt_f32_i32", w);
         run<2>("v_pk_fma_f32", w);
@@ -114,6 +148,13 @@ int main()
         run<9>("v_cvt_i32_f32_sdwa(dst)", w);
         run<10>("v_bfi_b32", w);
         run<11>("v_max3_f32", w);
+        run<12>("v_cvt_off_f32_i4", w);
+        run<13>("v_cvt_off_f32_i4_sdwa", w);
+        run<14>("v_cvt_f32_ubyteN", w);
+        run<15>("v_mul_f32", w);
+        run<16>("v_fmac_f32 (VOP2)", w);
+        run<17>("v_pk_mul_f32", w);
+        run<18>("v_and_b32 literal", w);
     }
     return 0;
 }
