@@ -21,6 +21,9 @@
 #define CLOVER_MATRIX4_H
 
 #include <cmath>
+#include <iomanip>
+#include <sstream>
+#include <string>
 
 #include "CloverMatrix32.h"
 #include "CloverVector4.h"
@@ -69,6 +72,24 @@ public:
         const uint64_t pos = i * cols + j;
         const int8_t b = (int8_t)h[pos >> 1];
         return scale * (float)(int8_t)((int8_t)(b << ((pos % 2) * 4)) >> 4);
+    }
+
+    /* CloverMatrix4.h:141-163: the restored elements row by row, then the grid of tile scales */
+    std::string toString() const
+    {
+        const uint8_t *h = mem.host_ro();
+        const float *s = reinterpret_cast<const float *>(h + value_bytes);
+        const uint64_t v_blocks = rows >> 6, h_blocks = cols >> 6;
+        std::stringstream sout;
+        for (uint64_t i = 0; i < rows; i++) {
+            for (uint64_t j = 0; j < cols; j++) sout << std::setw(7) << std::fixed << std::setprecision(2) << get(i, j) << " ";
+            sout << ";" << std::endl;
+        }
+        for (uint64_t i = 0; i < v_blocks; i++) {
+            for (uint64_t j = 0; j < h_blocks; j++) sout << std::setw(7) << std::fixed << std::setprecision(2) << s[i * h_blocks + j] << " ";
+            sout << ";" << std::endl;
+        }
+        return sout.str();
     }
 
     void setRandomKeys(const uint64_t key1[4], const uint64_t key2[4]) { random.set(key1, key2); }

@@ -3,6 +3,8 @@
 // tests/test_gpu_cpp_dropin.py compares with the oracle / the reference's known answers.
 #include <CloverIHT.h>
 #include <CloverMatrix32.h>
+#include <string>
+
 #include <CloverMatrix4.h>
 #include <CloverVector32.h>
 #include <CloverVector4.h>
@@ -78,6 +80,10 @@ int main()
         hexdump("kat3_r_parallel", r2.getData(), 64);
         printf("kat3_scales=0x%08x,0x%08x\n", bits(r.getScales()[0]), bits(r.getScales()[1]));
         printf("kat3_get=%.5f,%.5f,%.5f,%.5f\n", qA.get(0, 0), qA.get(0, 1), qA.get(0, 2), qA.get(0, 3));
+        {   // CloverMatrix4::toString (CloverMatrix4.h:141-163): the first row as the reference prints it (setw(7), 2 decimals)
+            const std::string t = qA.toString();
+            printf("kat3_tostring_head=%s\n", t.substr(0, 31).c_str());
+        }
         // GEMM (new): C = qA * qA^T, spot values
         CloverMatrix32 C(M, M);
         qA.gemm(qA, C);

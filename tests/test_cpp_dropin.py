@@ -51,6 +51,8 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
     assert kv["kat3_r"] == KAT["KAT3"]["r_bytes_0_63"] and kv["kat3_r_parallel"] == KAT["KAT3"]["r_bytes_0_63"]
     assert kv["kat3_scales"].split(",") == KAT["KAT3"]["r_scale_bits"]
     np.testing.assert_allclose([float(v) for v in kv["kat3_get"].split(",")], KAT["KAT3"]["qA_get_0_0_3"], atol=1e-5)
+    head = [ln for ln in out.splitlines() if ln.startswith("kat3_tostring_head=")][0].split("=", 1)[1]
+    assert head.rstrip() == " -11.00    4.71    0.00   -4.71"                    # -11, 4.71429, 0, -4.71429 with setw(7), precision 2
     # mixed precision: CloverVector8 + CloverMatrix4::mvm(CloverVector8, CloverVector8) against the oracle
     A3, _ = kat3_inputs()
     x3 = np.array([np.float32(float(((13 * c) % 19) - 9)) * np.float32(0.37) for c in range(256)], np.float32)
