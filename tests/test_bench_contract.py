@@ -44,6 +44,18 @@ def test_mvm_line():
     g = d["gemm"]
     assert g["roofline"]["bound"] == "mfma" and g["roofline"]["peak"] == 10000.0 and abs(g["roofline"]["frac"] - g["value"] / 10000.0) < 1e-3
     assert g["prepared_operands"]["ms"] > 0 and g["int32_unscaled"]["ms"] > 0
+    # round 3: the ceiling of the definition measured on this box (probe library, child processes), the int8-MFMA kernel, counters
+    c = g["ceiling"]
+    assert 0 < c["mfma_only_ms"] < c["mfma_plus_fold_only_ms"] < c["full_loop_ms"] and 0 < c["frac_if_only_arithmetic"] < 1
+    assert g["int8_mfma_kernel"]["ms"] > g["ms"] * 0.5
+    assert g["roofline"]["traffic"] > g["roofline"]["algorithmic_bytes_per_call"] and 0 < g["roofline"]["mfma_busy_pct"] < 100
+    # BASELINE configs[1] on the host: quantize and dot, one core and all cores, cache-sized and DRAM-sized
+    v = cb["vector_ops"]
+    for size in ("n2^24", "n2^30"):
+        for op in ("quantize_sequential", "quantize_all_cores", "dot_sequential", "dot_all_cores"):
+            assert v[size][op]["value"] > 0 and v[size][op]["threads"] >= 1, (size, op)
+    assert d["extras"]["footnote_cache_resident_n2^24"]["dot_exact"]["host_one_core_ms_same_order"] > 0
+    assert "kernel_avg_of" in rf
     # HBM-resident vector workloads, each with its own achieved / peak / frac
     h = d["extras"]["hbm_resident_n2^30"]
     for k in ("quantize", "quantize_stochastic", "dot_fast", "scale_and_add", "restore"):
