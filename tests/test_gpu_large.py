@@ -264,3 +264,46 @@ def test_sharded_c_api_single_process(hip, oracle):
         assert cd.value
     finally:
         hip.check(lib.clm4_sharded_destroy(ctx))
+
+
+@pytest.mark.parametrize("parts,rows", [(3, 896), (4, 1024), (1, 256)])
+def test_sharded_loop_calls_equal_the_unsharded_mvm(hip, parts, rows):
+    """the loop form of the one-process API (clm4_sharded_set_x / _loop_begin / _mvm_enqueue / _sync / _step_timing / _result_buf): ragged
+    (7 blocks over 3 shards) and equal shards on device 0 (exchanges are copies on the exchange stream), both result buffers, x replaced
+    between steps -- every shard's full result == clm4_mvm of the whole matrix"""
+    vp = C.c_void_p
+    lib = hip.lib
+    cols = 2048
+    devs = (C.c_int * parts)(*([0] * parts))
+    ctx = vp()
+    hip.check(lib.clm4_sharded_create(C.byref(ctx), parts, devs, rows, cols))
+    try:
+        hip.check(lib.clm4_sharded_fill_random(ctx, 91))
+        A, sA = hip.alloc(rows * cols // 2), hip.alloc((rows // 64) * (cols // 64) * 4)
+        hip.check(lib.clv_fill_random_nibbles(A.ptr, A.nbytes, 91, 0, None))
+        hip.check(lib.clv_fill_random_scales(sA.ptr, sA.nbytes // 4, 92, 0, None))
+        qA, sAh = A.download(np.uint8), sA.download(np.float32)
+        hip.check(lib.clm4_sharded_loop_begin(ctx, 4))
+        rng = np.random.default_rng(3)
+        want = []
+        for step in range(4):
+            qx = (rng.integers(0, 256, size=cols // 2, dtype=np.uint8) & 0x77).astype(np.uint8)
+            sx = rng.uniform(0.5, 2, size=cols // 64).astype(np.float32)
+            hip.check(lib.clm4_sharded_set_x(ctx, qx.ctypes.data, sx.ctypes.data, 1))
+            hip.check(lib.clm4_sharded_mvm_enqueue(ctx, step, 1))
+            want.append(hip.m4_mvm(qA, sAh, rows, cols, qx, sx))
+            if step >= 2:                                   # buffers alternate: after steps 2 and 3 both hold the latest two results
+                hip.check(lib.clm4_sharded_sync(ctx))
+                for part in range(parts):
+                    for buf, ref in ((step & 1, want[step]), ((step - 1) & 1, want[step - 1])):
+                        rp, sp = vp(), vp()
+                        hip.check(lib.clm4_sharded_result_buf(ctx, part, buf, C.byref(rp), C.byref(sp)))
+                        assert same(_download(hip, rp.value, rows // 2, np.uint8), ref[0]), (step, part, buf)
+                        assert same(_download(hip, sp.value, rows // 16, np.float32), ref[1]), (step, part, buf)
+        km, gm = C.c_float(), C.c_float()
+        hip.check(lib.clm4_sharded_step_timing(ctx, parts - 1, 3, C.byref(km), C.byref(gm)))
+        assert km.value > 0 and gm.value >= 0
+        assert lib.clm4_sharded_mvm_enqueue(ctx, 4, 1) != 0              # no event slot reserved for step 4
+        assert lib.clm4_sharded_step_timing(ctx, 0, 9, C.byref(km), C.byref(gm)) != 0
+    finally:
+        hip.check(lib.clm4_sharded_destroy(ctx))
