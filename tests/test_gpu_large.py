@@ -285,10 +285,11 @@ def test_sharded_loop_calls_equal_the_unsharded_mvm(hip, parts, rows):
         qA, sAh = A.download(np.uint8), sA.download(np.float32)
         hip.check(lib.clm4_sharded_loop_begin(ctx, 4))
         rng = np.random.default_rng(3)
-        want = []
+        want, keep = [], []
         for step in range(4):
             qx = (rng.integers(0, 256, size=cols // 2, dtype=np.uint8) & 0x77).astype(np.uint8)
             sx = rng.uniform(0.5, 2, size=cols // 64).astype(np.float32)
+            keep.append((qx, sx))                           # the copy out of host memory is only enqueued
             hip.check(lib.clm4_sharded_set_x(ctx, qx.ctypes.data, sx.ctypes.data, 1))
             hip.check(lib.clm4_sharded_mvm_enqueue(ctx, step, 1))
             want.append(hip.m4_mvm(qA, sAh, rows, cols, qx, sx))
