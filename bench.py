@@ -266,15 +266,36 @@ def main() -> None:
     # CLOVER_BENCH_DEBUG_ONE_GPU=1: rehearsal of the N>1 control flow on a box with ONE GPU -- every rank uses device 0 and the
     # exchange goes through gloo and the host.  Never a measurement: the output says so.
     debug_one_gpu = world > 1 and os.environ.get("CLOVER_BENCH_DEBUG_ONE_GPU") == "1"
+    # CLOVER_BENCH_FORCE_DIST=1 (under a launcher, any world size incl. 1): take the N > 1 code path -- process groups, RCCL sub-group,
+    # per-step all-gather -- even with one rank, so that the very calls an 8-GPU run makes execute on a one-GPU box (tests)
+    dist_on = world > 1 or (launched and os.environ.get("CLOVER_BENCH_FORCE_DIST") == "1")
     dev_index = 0 if debug_one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    red_dev = torch.device("cpu") if debug_one_gpu else dev          # where the tiny timing all-reduces live
-    if world > 1:
-        if debug_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    red_dev = torch.device("cpu")                    # control plane (timing maxima, flags, barriers): always gloo on the host
+    data_group, data_backend, nccl_error = None, "gloo", None
+    if dist_on:
+        dist.init_process_group("gloo")
+        if not debug_one_gpu:
+            # data plane: an RCCL (backend "nccl") group for the per-step all-gather.  If it cannot be built or its first collective
+            # fails on ANY rank, every rank falls back to gloo through the host for the 72 KiB exchange -- slower, reported as such, but
+            # a scaling run still produces its line (the ranks agree on the outcome over the gloo group)
+            ok = 1
+            try:
+                data_group = dist.new_group(backend="nccl")
+                probe = torch.ones(1, dtype=torch.float32, device=dev)
+                dist.all_reduce(probe, group=data_group)
+                torch.cuda.synchronize()
+                ok = int(float(probe.item()) == float(world))
+            except Exception as e:                       # noqa: BLE001 -- whatever RCCL raises, the answer is the fallback
+                ok, nccl_error = 0, f"{type(e).__name__}: {e}"[:300]
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                data_backend = "nccl"
+            else:
+                data_group = None
+    host_exchange = dist_on and data_backend == "gloo"       # the packed result travels through host memory
 
     hip = CloverHip(device=dev_index)                # raises if libclover_hip.so is missing: no fallback
     lib = hip.lib
@@ -323,8 +344,8 @@ def main() -> None:
                                buf.data_ptr() + rows // 2, None, stream))
         if timed:
             ev[i][1].record()
-        if world > 1:                             # RCCL all-gather of [nibbles | scales] from every rank, overlapping the next step
-            pending[n & 1] = gather_packed_async(buf.cpu() if debug_one_gpu else buf, rows_total)
+        if dist_on:                               # RCCL all-gather of [nibbles | scales] from every rank, overlapping the next step
+            pending[n & 1] = gather_packed_async(buf.cpu() if host_exchange else buf, rows_total, group=data_group)
 
     def drain() -> None:                          # every gather has landed (the stream waits; synchronize() follows)
         for j in (0, 1):
@@ -335,41 +356,41 @@ def main() -> None:
     for w_ in range(args.warmup):
         step(None, w_)
     drain()
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, i)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     kern_ms = [a.elapsed_time(b) for i, (a, b) in enumerate(ev) if i % args.event_every == 0]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     kt = torch.tensor([kern_avg_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kern_avg_ms = float(kt.item())
     per_rank_kernel_ms, gather_us, rccl_ranks = None, None, None
-    if world > 1:
+    if dist_on:
         pr = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
         dist.all_gather(pr, torch.tensor([sum(kern_ms) / len(kern_ms)], dtype=torch.float64, device=red_dev))
         per_rank_kernel_ms = [round(float(v.item()), 5) for v in pr]
-        rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+        rccl_ranks = dist.get_world_size(data_group) if data_backend == "nccl" else 0
         # the exchange alone, outside the timed region: K blocking all-gathers of the packed result
         reps = 50
         dist.barrier()
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         for _ in range(reps):
-            gather_packed(res.cpu() if debug_one_gpu else res, rows_total)
+            gather_packed(res.cpu() if host_exchange else res, rows_total, group=data_group)
         torch.cuda.synchronize()
         gt = torch.tensor([(time.perf_counter() - g0) / reps * 1e6], dtype=torch.float64, device=red_dev)
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
@@ -377,11 +398,11 @@ def main() -> None:
 
     # outside the timed region: every rank finds its own shard, bit for bit, at its place in the gathered vector
     gather_ok = None
-    if world > 1:
+    if dist_on:
         from clover_amd.sharding import unpack_gathered
-        g = gather_packed(res.cpu() if debug_one_gpu else res, rows_total)
+        g = gather_packed(res.cpu() if host_exchange else res, rows_total, group=data_group)
         nib, sc = unpack_gathered(g, rows_total, world)
-        mine = res.cpu() if debug_one_gpu else res
+        mine = res.cpu() if host_exchange else res
         ok = bool(torch.equal(nib[rank * rows // 2: (rank + 1) * rows // 2], mine[: rows // 2])) and \
             bool(torch.equal(sc[rank * rows // 64: (rank + 1) * rows // 64], mine[rows // 2:].view(torch.float32)))
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
@@ -389,8 +410,7 @@ def main() -> None:
         gather_ok = bool(okt.item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -408,11 +428,12 @@ def main() -> None:
             "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 ({rows}x{cols} per GPU; preset {args.preset}: BASELINE "
                         f"{'configs[2] per GPU' if args.preset == 'c3' else 'configs[4]' + (' at N=8' if args.preset == 'c5-weak' else '')}), "
                         f"x and result CloverVector4, STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
-            "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of every step's packed result, overlapped with the next step" if world > 1 else ""),
-            **({"gathered_result_verified": gather_ok, "rccl_ranks": rccl_ranks, "backend": dist.get_backend(),
+            "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + all-gather of every step's packed result, overlapped with the next step" if dist_on else ""),
+            **({"gathered_result_verified": gather_ok, "rccl_ranks": rccl_ranks, "backend": data_backend,
+                **({"nccl_fallback_reason": nccl_error or "the RCCL group failed on another rank"} if host_exchange and not debug_one_gpu else {}),
                 "per_rank_kernel_ms": per_rank_kernel_ms, "gather_us_blocking": gather_us,
-                "gather_bytes_per_rank": packed_bytes(rows)} if world > 1 else {}),
-            **({"mode": "ranks", "launcher": os.environ.get("CLOVER_BENCH_LAUNCHER", "external torch.distributed.run")} if world > 1 else {}),
+                "gather_bytes_per_rank": packed_bytes(rows)} if dist_on else {}),
+            **({"mode": "ranks", "launcher": os.environ.get("CLOVER_BENCH_LAUNCHER", "external torch.distributed.run")} if dist_on else {}),
             **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all ranks on one GPU, gloo through the host -- not a measurement"} if debug_one_gpu else {}),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_step": bytes_total,
@@ -458,7 +479,7 @@ def main() -> None:
     except (KeyError, TypeError):
         pass
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -104,6 +104,20 @@ def test_two_rank_rehearsal_under_the_drivers_launcher():
 
 
 @pytest.mark.gpu
+def test_ranks_path_through_rccl_with_one_rank():
+    """CLOVER_BENCH_FORCE_DIST=1 under the launcher with ONE rank: the N > 1 code path as an 8-GPU run takes it -- gloo control group,
+    RCCL data group (torch backend "nccl"), per-step all_gather_into_tensor of the packed result on the device, overlap, verification --
+    executes on the one-GPU box"""
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29733"]
+    out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLOVER_BENCH_FORCE_DIST": "1"}, launcher=launcher))
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and cfg["backend"] == "nccl" and cfg["rccl_ranks"] == 1 and cfg["gathered_result_verified"] is True
+    assert cfg["mode"] == "ranks" and "nccl_fallback_reason" not in cfg and "DEBUG" not in cfg
+    assert cfg["gather_us_blocking"] > 0 and len(cfg["per_rank_kernel_ms"]) == 1
+
+
+@pytest.mark.gpu
 def test_one_process_rehearsal_two_shards_on_one_gpu():
     out = json_line(run_bench(["--gpus", "2", "--mode", "one-process", *SMALL], REHEARSAL))
     check_two_way(out, "one-process")
