@@ -1287,15 +1287,29 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
                     }
                 }
             };
+            const uint32_t last = ngroups - 1;
+            auto ld = [&](uint32_t gg) {                                   // clamped: a step past the end re-reads the last group
+                const uint32_t gc = gg < last ? gg : last;
+                return NT ? __builtin_nontemporal_load(&Ap[4 * gc + a]) : Ap[4 * gc + a];
+            };
             uint32_t g = 0;
+            u32x4 cur[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u] = ld(u);
             for (; g + U <= ngroups; g += U) {
-                u32x4 av[U];
+                u32x4 nxt[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) av[u] = NT ? __builtin_nontemporal_load(&Ap[4 * (g + u) + a]) : Ap[4 * (g + u) + a];
+                for (int u = 0; u < U; u++) nxt[u] = ld(g + U + u);
+                asm volatile("" ::: "memory");                              // the next step's loads are issued HERE, before this step's arithmetic
 #pragma unroll
-                for (int u = 0; u < U; u++) group(av[u], g + u);
+                for (int u = 0; u < U; u++) group(cur[u], g + u);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < U; u++) cur[u] = nxt[u];
             }
-            for (; g < ngroups; g++) group(NT ? __builtin_nontemporal_load(&Ap[4 * g + a]) : Ap[4 * g + a], g);
+#pragma unroll
+            for (int u = 0; u < U - 1; u++)
+                if (g + u < ngroups) group(cur[u], g + u);
         };
         if (fast) chunk(std::true_type{});
         else chunk(std::false_type{});
