@@ -217,6 +217,10 @@ def main() -> None:
                          "auto: steps // 8 clamped to [1, 8].  An event pair puts two barrier packets into the queue, which keeps a launch from "
                          "overlapping its predecessor's drain: with a pair around EVERY step the timed loop ran 0.336 ms per step, with none "
                          "0.3285 ms -- less than the 0.3307 ms the events themselves report for the kernel (rocprofv3: 0.3278)")
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="untimed launches of the same step for this many milliseconds BEFORE the W warm-up steps: after an idle period the chip "
+                         "needs ~20-30 ms of work to reach its steady clocks (the driver's --warmup 5 is 1.6 ms: the 20 timed steps behind it ran "
+                         "0.349 ms per step against 0.330 in steady state).  Reported in the JSON; 0 switches it off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
@@ -353,6 +357,17 @@ def main() -> None:
                 pending[j].wait()
                 pending[j] = None
 
+    # clock settle (untimed, reported): the same step, back to back, until --settle-ms of wall time have passed
+    settle_launches = 0
+    if args.settle_ms > 0:
+        torch.cuda.synchronize()
+        t_settle = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_settle:
+            for _ in range(8):
+                step(None, settle_launches)
+                settle_launches += 1
+            drain()
+            torch.cuda.synchronize()
     for w_ in range(args.warmup):
         step(None, w_)
     drain()
@@ -437,6 +452,8 @@ def main() -> None:
             **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all ranks on one GPU, gloo through the host -- not a measurement"} if debug_one_gpu else {}),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_step": bytes_total,
+            "clock_settle": f"{settle_launches} untimed launches of the same step ({args.settle_ms:g} ms) before the {args.warmup} warm-up steps "
+                            "(steady clocks need 20-30 ms of work after idle); the K timed steps and their barriers are unchanged",
             "arithmetic": "int4 x int4 products summed exactly per 32-bit word (v_dot8_i32_i4), fp32 per-block scale + fma chains in reference order",
         },
         "roofline": {
@@ -530,6 +547,13 @@ def one_process_main(args, torch, CloverHip) -> None:
         torch.cuda.synchronize()
         hip.check(lib.clm4_sharded_set_x(ctx, x.data_ptr(), sx.data_ptr(), 0))
         hip.check(lib.clm4_sharded_loop_begin(ctx, args.steps))
+        if args.settle_ms > 0:                        # clock settle, as in ranks mode (untimed)
+            t_settle, k_ = time.perf_counter() + args.settle_ms * 1e-3, 0
+            while time.perf_counter() < t_settle:
+                for _ in range(8):
+                    hip.check(lib.clm4_sharded_mvm_enqueue(ctx, k_, 0))
+                    k_ += 1
+                hip.check(lib.clm4_sharded_sync(ctx))
         for w_ in range(args.warmup):
             hip.check(lib.clm4_sharded_mvm_enqueue(ctx, w_, 0))
         hip.check(lib.clm4_sharded_sync(ctx))
