@@ -217,7 +217,7 @@ def main() -> None:
                          "auto: steps // 8 clamped to [1, 8].  An event pair puts two barrier packets into the queue, which keeps a launch from "
                          "overlapping its predecessor's drain: with a pair around EVERY step the timed loop ran 0.336 ms per step, with none "
                          "0.3285 ms -- less than the 0.3307 ms the events themselves report for the kernel (rocprofv3: 0.3278)")
-    ap.add_argument("--settle-ms", type=float, default=40.0,
+    ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed launches of the same step for this many milliseconds BEFORE the W warm-up steps: after an idle period the chip "
                          "needs ~20-30 ms of work to reach its steady clocks (the driver's --warmup 5 is 1.6 ms: the 20 timed steps behind it ran "
                          "0.349 ms per step against 0.330 in steady state).  Reported in the JSON; 0 switches it off")
@@ -358,11 +358,14 @@ def main() -> None:
                 pending[j] = None
 
     # clock settle (untimed, reported): the same step, back to back, until --settle-ms of wall time have passed
+    # (a launch COUNT derived from the shape, not a wall-clock loop: with N > 1 every step carries a collective, so all ranks must issue
+    #  the same number of them)
     settle_launches = 0
     if args.settle_ms > 0:
+        est_ms = mvm_bytes(rows, cols) / 6.0e12 * 1e3                      # one launch at ~6 TB/s
+        settle_target = min(256, max(8, int(args.settle_ms / est_ms + 7) // 8 * 8))        # small test shapes: capped
         torch.cuda.synchronize()
-        t_settle = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < t_settle:
+        while settle_launches < settle_target:
             for _ in range(8):
                 step(None, settle_launches)
                 settle_launches += 1
@@ -548,8 +551,8 @@ def one_process_main(args, torch, CloverHip) -> None:
         hip.check(lib.clm4_sharded_set_x(ctx, x.data_ptr(), sx.data_ptr(), 0))
         hip.check(lib.clm4_sharded_loop_begin(ctx, args.steps))
         if args.settle_ms > 0:                        # clock settle, as in ranks mode (untimed)
-            t_settle, k_ = time.perf_counter() + args.settle_ms * 1e-3, 0
-            while time.perf_counter() < t_settle:
+            k_, settle_target = 0, min(256, max(8, int(args.settle_ms / (mvm_bytes(rows, cols) / 6.0e12 * 1e3) + 7) // 8 * 8))
+            while k_ < settle_target:
                 for _ in range(8):
                     hip.check(lib.clm4_sharded_mvm_enqueue(ctx, k_, 0))
                     k_ += 1
