@@ -395,7 +395,7 @@ static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t 
     if (rng) {
         int rc = clv_rng_tables(&T);
         if (rc) return rc;
-        seq = clv_rng_next_seq();
+        seq = clv_rng_seq_for(rng, st);
     }
     const MvmFuse no_fuse = {nullptr, nullptr, 0.0f, nullptr, nullptr};
 #define MVM_LAUNCH_F(NT, ST, FUSE)                                                                                               \

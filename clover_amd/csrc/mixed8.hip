@@ -474,7 +474,7 @@ extern "C" int clv8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s
     int rc = clv_rng_tables(&T);
     if (rc) return rc;
     const uint64_t nb = n_pad / 64;
-    const uint64_t seq = clv_rng_next_seq();
+    const uint64_t seq = clv_rng_seq_for(rng_state_dev, st);
 #define Q8_LAUNCH(S)                                                                                                           \
     hipLaunchKernelGGL(k_v8_quantize_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const f32x4 *)x, \
                        (u32x2 *)q, s, nb, rng_state_dev, seq, T)
@@ -529,7 +529,7 @@ extern "C" int clv8_scale_and_add(const int8_t *qu, const float *su, const int8_
     RngTables T;
     int rc = clv_rng_tables(&T);
     if (rc) return rc;
-    const uint64_t seq = clv_rng_next_seq();
+    const uint64_t seq = clv_rng_seq_for(rng_state_dev, st);
 #define SAA8_LAUNCH(S)                                                                                                               \
     hipLaunchKernelGGL(k_v8_scale_and_add_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const u32x4 *)qu, su, \
                        (const u32x4 *)qv, sv, a, (u32x4 *)r, sr, nb, rng_state_dev, seq, T)
@@ -554,7 +554,7 @@ static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t
     if (rng) {
         int rc = clv_rng_tables(&T);
         if (rc) return rc;
-        seq = clv_rng_next_seq();
+        seq = clv_rng_seq_for(rng, st);
     }
     const bool streaming = rows * (cols / 2) > (256ull << 20);
     const Mvm8Fuse no_fuse = {nullptr, nullptr, 0.0f, nullptr, nullptr};

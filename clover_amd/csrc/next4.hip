@@ -216,7 +216,7 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
     RngTables T;
     int rc = clv_rng_tables(&T);
     if (rc) return rc;
-    const uint64_t seq = clv_rng_next_seq();
+    const uint64_t seq = clv_rng_seq_for(rng_state_dev, st);
 #define SAA_LAUNCH(S)                                                                                                                  \
     hipLaunchKernelGGL(k_v4_scale_and_add_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const uint32_t *)qu, \
                        su, (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, rng_state_dev, seq, T)

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void k_m4_quantize_strip_st(const float *__res
 
     SegRows<8 * NV> segs;
     segs.load(T.seg_rows, 0);
+    seq = rng_effective_seq(state, seq);
     const int slot = rng_read_slot(state, seq);
     uint64_t a0[4], b[4];
 #pragma unroll
@@ -343,7 +344,7 @@ int clv4_quantize_stochastic(const float *x, uint64_t n_pad, int8_t *q, float *s
     int rc = clv_rng_tables(&T);
     if (rc) return rc;
     const uint64_t nb = n_pad / 64;
-    const uint64_t seq = clv_rng_next_seq();
+    const uint64_t seq = clv_rng_seq_for(rng, st);
 #define QST_LAUNCH(S)                                                                                                          \
     hipLaunchKernelGGL(k_v4_quantize_st<S>, dim3((unsigned)((nb + 32 * S - 1) / (32 * S))), dim3(256), 0, st, (const f32x4 *)x, \
                        (uint32_t *)q, s, nb, rng, seq, T)
@@ -370,15 +371,15 @@ int clm4_quantize_stochastic(const float *A, uint64_t rows, uint64_t cols, int8_
         static const bool one_tile = getenv("CLV_M4Q_NV1") != nullptr;       // A/B switch: one tile row per workgroup
         if (one_tile || rows / 64 < 2)
             hipLaunchKernelGGL(k_m4_quantize_strip_st<1>, dim3((unsigned)((rows / 64) * strips_x)), dim3(256), 0, st, A, cols, (uint32_t *)q, s,
-                               strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_next_seq(), T);
+                               strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_seq_for(rng, st), T);
         else
             hipLaunchKernelGGL(k_m4_quantize_strip_st<2>, dim3((unsigned)(((rows / 64 + 1) / 2) * strips_x)), dim3(256), 0, st, A, cols, (uint32_t *)q,
-                               s, strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_next_seq(), T);
+                               s, strips_x, (uint32_t)(cols / 64), rows / 64, rng, clv_rng_seq_for(rng, st), T);
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
     hipLaunchKernelGGL(k_m4_quantize_st, dim3((unsigned)tiles), dim3(256), 0, st, A, cols, (uint32_t *)q, s, (uint32_t)(cols / 64),
-                       rows / 64, rng, clv_rng_next_seq(), T);
+                       rows / 64, rng, clv_rng_seq_for(rng, st), T);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

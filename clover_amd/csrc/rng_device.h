@@ -22,6 +22,7 @@
                                  // (and, in a second table, T^(64*e): 32-block segments of the large-vector shape)
 #define RNG_SLOT_WORDS 16        // u64 stride between the two state slots
 #define RNG_STAMP_WORD 8         // u64 index of the slot's sequence stamp
+#define RNG_TICK_WORD 9          // u64 index (slot 0 only) of the DEVICE-side launch counter: graph mode (clv_rng_graph_mode)
 
 // device tables, one allocation, all in ROW form (bit i of row j = bit j of the image of bit i), which is what the
 // whole-wave product below wants: pow_rows[56][64] = T^(2^k), seg_rows[64][64] = T^(16 e)
@@ -32,6 +33,10 @@ struct RngTables {
 };
 int clv_rng_tables(RngTables *t);      // rng4.hip; builds the tables on first use per device
 uint64_t clv_rng_next_seq();           // runtime.hip; process-wide launch sequence number (>= 1)
+// The sequence number a stochastic launch on `state` carries.  Ordinary states: the next host number.  States in graph mode
+// (clv_rng_graph_mode): 0 -- after enqueueing a one-thread kernel that increments the state's own counter (RNG_TICK_WORD) on `stream`;
+// the kernels read that counter when they are handed 0 (rng_effective_seq), so a captured graph replays with fresh numbers.
+uint64_t clv_rng_seq_for(uint64_t *state, hipStream_t stream);      // runtime.hip
 
 __host__ __device__ __forceinline__ uint64_t xs_T(uint64_t a)
 {
@@ -100,6 +105,13 @@ __device__ __forceinline__ uint64_t wave_pow_apply(const uint64_t *__restrict__ 
         for (int i = 0; i < 8; i++) R[i] = ((e >> i) & 1ull) ? row[64 * i] : 0ull;
     }
     return v;
+}
+
+// seq == 0: the launch belongs to a state in graph mode; its number is the device counter its tick kernel has just advanced (stable for
+// the whole launch: the next tick is stream-ordered behind it)
+__device__ __forceinline__ uint64_t rng_effective_seq(const uint64_t *state, uint64_t seq)
+{
+    return seq ? seq : state[RNG_TICK_WORD];
 }
 
 // the slot a launch with sequence number `seq` reads: largest stamp below seq
@@ -179,6 +191,7 @@ __device__ __forceinline__ uint64_t rng_workgroup_begin(uint64_t *state, uint64_
                                                         uint64_t index, int shift, uint64_t total, uint64_t *lds_base)
 {
     const int k = threadIdx.x >> 6;
+    seq = rng_effective_seq(state, seq);
     const int slot = rng_read_slot(state, seq);
     const uint64_t a0 = state[slot * RNG_SLOT_WORDS + 4 + k];
     const uint64_t b = wave_pow_apply(pow_rows, a0, index, shift);

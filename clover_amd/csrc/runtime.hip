@@ -1,5 +1,9 @@
 // runtime.hip -- device/stream/memory plumbing, XORShift key handling and synthetic-data fills.
 #include "common.h"
+#include "rng_device.h"
+
+#include <mutex>
+#include <unordered_set>
 
 #include <atomic>
 
@@ -223,10 +227,58 @@ static void canon_jump(uint64_t in0, uint64_t in1, uint64_t &out0, uint64_t &out
     out1 = b;
 }
 
-uint64_t clv_rng_next_seq()
+static std::atomic<uint64_t> g_rng_seq{1};
+uint64_t clv_rng_next_seq() { return g_rng_seq.fetch_add(1, std::memory_order_relaxed); }
+// host numbers must stay above every stamp a state carries: a state that leaves graph mode brings device-made stamps along
+static void rng_seq_raise_above(uint64_t stamp)
 {
-    static std::atomic<uint64_t> seq{1};
-    return seq.fetch_add(1, std::memory_order_relaxed);
+    uint64_t cur = g_rng_seq.load(std::memory_order_relaxed);
+    while (cur <= stamp && !g_rng_seq.compare_exchange_weak(cur, stamp + 1, std::memory_order_relaxed)) {}
+}
+
+// ---- graph mode: the launch sequence of a state kept on the device -----------------------------------------------------------------
+// A stochastic kernel tells the state slot its predecessor wrote from the one it writes itself by a per-launch number.  Ordinarily the
+// host hands that number over as a kernel argument -- which a captured hipGraph would replay.  For a state in graph mode the number
+// lives in the state buffer (RNG_TICK_WORD): every stochastic call first enqueues k_rng_tick (one thread: counter += 1) and passes 0,
+// the kernels read the counter (rng_effective_seq).  Price: one extra ~2 us launch per stochastic call -- hence opt-in.
+static std::mutex g_graph_mutex;
+static std::unordered_set<const uint64_t *> g_graph_states;
+
+__global__ void k_rng_tick(uint64_t *state) { state[RNG_TICK_WORD] += 1; }
+// the counter starts behind every stamp present, so the first tick is newer than both slots
+__global__ void k_rng_tick_init(uint64_t *state)
+{
+    const uint64_t s0 = state[RNG_STAMP_WORD], s1 = state[RNG_SLOT_WORDS + RNG_STAMP_WORD];
+    state[RNG_TICK_WORD] = s0 > s1 ? s0 : s1;
+}
+
+uint64_t clv_rng_seq_for(uint64_t *state, hipStream_t stream)
+{
+    bool graph;
+    {
+        std::lock_guard<std::mutex> g(g_graph_mutex);
+        graph = !g_graph_states.empty() && g_graph_states.count(state) != 0;
+    }
+    if (!graph) return clv_rng_next_seq();
+    hipLaunchKernelGGL(k_rng_tick, dim3(1), dim3(1), 0, stream, state);
+    return 0;
+}
+
+extern "C" int clv_rng_graph_mode(uint64_t *state_dev, int on, void *stream)
+{
+    CLV_REQUIRE(state_dev, "clv_rng_graph_mode: null argument");
+    std::lock_guard<std::mutex> g(g_graph_mutex);
+    if (on) {
+        hipLaunchKernelGGL(k_rng_tick_init, dim3(1), dim3(1), 0, as_stream(stream), state_dev);
+        CLV_LAUNCH_CHECK();
+        g_graph_states.insert(state_dev);
+    } else if (g_graph_states.erase(state_dev)) {
+        uint64_t tick = 0;                           // the stamps this state carries were made on the device: host numbers continue above them
+        CLV_HIP(hipMemcpyAsync(&tick, state_dev + RNG_TICK_WORD, sizeof tick, hipMemcpyDeviceToHost, as_stream(stream)));
+        CLV_HIP(hipStreamSynchronize(as_stream(stream)));
+        rng_seq_raise_above(tick);
+    }
+    return CLV_OK;
 }
 
 extern "C" int clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const uint64_t key2[4], void *stream)
@@ -236,6 +288,7 @@ extern "C" int clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const ui
     memcpy(st, key1, 32);
     memcpy(st + 4, key2, 32);
     st[8] = clv_rng_next_seq();
+    st[RNG_TICK_WORD] = st[8];                       // graph mode: the device counter continues from this stamp
     CLV_HIP(hipMemcpyAsync(state_dev, st, sizeof st, hipMemcpyHostToDevice, as_stream(stream)));
     CLV_HIP(hipStreamSynchronize(as_stream(stream)));   // st is a stack buffer
     return CLV_OK;

@@ -45,6 +45,7 @@ SIGNATURES = {
     "clv_rng_seed": (C.c_int, [_vp, _u64, _u64, _vp]),
     "clv_rng_set": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), _vp]),
     "clv_rng_get": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), _vp]),
+    "clv_rng_graph_mode": (C.c_int, [_vp, C.c_int, _vp]),
     "clv4_quantize": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
     "clv4_restore": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "clv4_dot_workspace_bytes": (_u64, [_u64]),

@@ -668,6 +668,8 @@ public:
     {
         check(clv_rng_get(device(), key1, key2, nullptr), "rng get");
     }
+    /* stochastic methods of the owning object become capturable into a hipGraph (clv_rng_graph_mode, clover_hip.h) */
+    void graph_mode(bool on) { check(clv_rng_graph_mode(device(), on ? 1 : 0, nullptr), "rng graph mode"); }
 
 private:
     void alloc()

@@ -29,9 +29,10 @@
  *    clm4_mvm_scale_and_add, clv8_quantize, clv8_scale_and_add, clm4_mvm_v8, clm4_mvm_v8_scale_and_add, clm4_iht, clm4_iht_v8):
  *      (1) calls that share a state buffer must be STREAM-ORDERED -- the same stream, or an event / sync between them: they consume one
  *          sequential XORShift stream, as the reference's methods do on one object, and each launch reads the state its predecessor left;
- *      (2) such a call must NOT be captured into a hipGraph: every launch carries a fresh host-side sequence number as a kernel argument
- *          (how a kernel tells the state slot written by its predecessor from the one it writes itself); a replayed graph would
- *          replay the number.  Deterministic calls (rng_state_dev == NULL) capture fine;
+ *      (2) such a call must NOT be captured into a hipGraph unless its state is in graph mode (clv_rng_graph_mode): ordinarily every launch
+ *          carries a fresh host-side sequence number as a kernel argument (how a kernel tells the state slot written by its predecessor
+ *          from the one it writes itself), and a replayed graph would replay the number.  Deterministic calls (rng_state_dev == NULL)
+ *          capture fine;
  *      (3) a state belongs to the process that initialised it (re-key with clv_rng_set after sharing the buffer across processes).
  *  - asynchrony: every call only enqueues work on `stream`; results are valid after clv_stream_sync / an event.
  *    clv4_dot, the threshold functions (when `workspace` is NULL) and clm4_gemm use grow-only scratch owned by the library, one
@@ -89,12 +90,19 @@ int  clv_event_elapsed_ms(void *start, void *stop, float *ms);
  * Initialise it with clv_rng_seed() (reproduces avx_xorshift128plus_init(key1, key2) on the host and uploads
  * it) or clv_rng_set() (explicit keys, CloverRandom::setRandomKeys); never write the buffer directly.
  * Calls that share a state must be ordered (same stream, or synchronised) -- they consume one sequential
- * stream -- and must not be captured into a hipGraph (each call carries a fresh launch stamp).  A state belongs to the
+ * stream -- and must not be captured into a hipGraph unless the state is in graph mode (clv_rng_graph_mode below: each call otherwise
+ * carries a fresh host-side launch stamp).  A state belongs to the
  * process that initialised it (the stamps come from a per-process counter): re-key with clv_rng_set after sharing a buffer. */
 #define CLV_RNG_STATE_BYTES 256
 int  clv_rng_seed(uint64_t *state_dev, uint64_t key1, uint64_t key2, void *stream);
 int  clv_rng_set(uint64_t *state_dev, const uint64_t key1[4], const uint64_t key2[4], void *stream);
 int  clv_rng_get(const uint64_t *state_dev, uint64_t key1[4], uint64_t key2[4], void *stream); /* syncs */
+/* Graph mode (opt-in, per state): on != 0 moves the launch stamps of this state from the host's counter into the state buffer itself --
+ * every stochastic call on it then enqueues a one-thread "tick" kernel in front of its own kernel (about 2 us of stream time) and carries
+ * no per-launch argument any more, so the calls CAN be captured into a hipGraph and the graph replayed: each replay consumes the next
+ * part of the XORShift stream, exactly as the same calls issued one after another would.  Enable it before capturing (outside the
+ * capture), on the stream the calls will use; on == 0 returns the state to host stamps.  clv_rng_set / clv_rng_seed keep the mode. */
+int  clv_rng_graph_mode(uint64_t *state_dev, int on, void *stream);
 
 /* ---- CloverVector4 ---------------------------------------------------------------------------- */
 /* CloverVector4::quantize (CloverVector4.h:605-807).  x: n_pad floats; q: n_pad/2 bytes; s: n_pad/64

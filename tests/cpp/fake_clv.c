@@ -43,3 +43,4 @@ int clv_host_free(void *ptr) { free(ptr); return CLV_OK; }
 int clv_rng_seed(uint64_t *s, uint64_t a, uint64_t b, void *st) { (void)s; (void)a; (void)b; (void)st; return CLV_OK; }
 int clv_rng_set(uint64_t *s, const uint64_t a[4], const uint64_t b[4], void *st) { (void)s; (void)a; (void)b; (void)st; return CLV_OK; }
 int clv_rng_get(const uint64_t *s, uint64_t a[4], uint64_t b[4], void *st) { (void)s; (void)a; (void)b; (void)st; return CLV_OK; }
+int clv_rng_graph_mode(uint64_t *s, int on, void *st) { (void)s; (void)on; (void)st; return CLV_OK; }
