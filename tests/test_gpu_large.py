@@ -266,18 +266,25 @@ def test_sharded_c_api_single_process(hip, oracle):
         hip.check(lib.clm4_sharded_destroy(ctx))
 
 
-@pytest.mark.parametrize("parts,rows", [(3, 896), (4, 1024), (1, 256)])
-def test_sharded_loop_calls_equal_the_unsharded_mvm(hip, parts, rows):
+@pytest.mark.parametrize("parts,rows,selftest", [(3, 896, None), (4, 1024, None), (1, 256, None), (1, 256, "1"), (1, 384, "ragged")])
+def test_sharded_loop_calls_equal_the_unsharded_mvm(hip, parts, rows, selftest, monkeypatch):
     """the loop form of the one-process API (clm4_sharded_set_x / _loop_begin / _mvm_enqueue / _sync / _step_timing / _result_buf): ragged
     (7 blocks over 3 shards) and equal shards on device 0 (exchanges are copies on the exchange stream), both result buffers, x replaced
     between steps -- every shard's full result == clm4_mvm of the whole matrix"""
     vp = C.c_void_p
     lib = hip.lib
     cols = 2048
+    if selftest:         # one shard through RCCL with a communicator of one rank: the grouped in-place all-gather pair / the per-owner broadcasts
+        monkeypatch.setenv("CLV_SHARDED_RCCL_SELFTEST", selftest)
+    else:
+        monkeypatch.delenv("CLV_SHARDED_RCCL_SELFTEST", raising=False)
     devs = (C.c_int * parts)(*([0] * parts))
     ctx = vp()
     hip.check(lib.clm4_sharded_create(C.byref(ctx), parts, devs, rows, cols))
     try:
+        ranks, equal = C.c_int(), C.c_int()
+        hip.check(lib.clm4_sharded_comm_info(ctx, C.byref(ranks), C.byref(equal)))
+        assert ranks.value == (1 if selftest else 0) and (selftest != "ragged" or equal.value == 0)
         hip.check(lib.clm4_sharded_fill_random(ctx, 91))
         A, sA = hip.alloc(rows * cols // 2), hip.alloc((rows // 64) * (cols // 64) * 4)
         hip.check(lib.clv_fill_random_nibbles(A.ptr, A.nbytes, 91, 0, None))
