@@ -279,6 +279,10 @@ def main() -> None:
     red_dev = torch.device("cpu")                    # control plane (timing maxima, flags, barriers): always gloo on the host
     data_group, data_backend, nccl_error = None, "gloo", None
     if dist_on:
+        # one node, rendezvous on 127.0.0.1: keep gloo on the loopback interface (a container hostname that does not resolve would
+        # otherwise stop it before the first collective)
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo")
         if not debug_one_gpu:
             # data plane: an RCCL (backend "nccl") group for the per-step all-gather.  If it cannot be built or its first collective
