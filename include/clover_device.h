@@ -300,6 +300,8 @@ public:
         commit_locked();
     }
     bool device_is_current() const { return state() != HOST_DIRTY; }
+    /* true when the host block is two mappings of one memory file (copies land behind the protection); false: plain allocation */
+    bool double_mapped() const { return mapped_; }
 
     /* ---- used by the tracker / the SIGSEGV handler ---- */
     const uint8_t *block_begin() const { return host_; }
