@@ -721,14 +721,14 @@ INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA: the pipe BASELINE's wording names
 
 def gemm_probe_child(spec: str, G: int) -> None:
     """One timing of the 8192^3 GEMM in a process of its own (the kernel switches CLV_GEMM_KERNEL / CLV_GEMM_LOOP are read once per process).
-    spec = "<library>:<call>", library = product | probe (clover_amd/lib/libclover_hip_probe.so: the loop's timing-only variants), call =
+    spec = "<library>:<call>", library = product | probe (tools/_build/libclover_hip_probe.so: the loop's timing-only variants), call =
     gemm | prepared | i32_prepared.  No torch: ctypes + the library only.  Prints {"ms": mean of 100 calls after 80 untimed ones}."""
     import ctypes as C
 
     from clover_amd.build import probe_library_path
     from clover_amd.lib_binding import CloverHip
     which, call = spec.split(":")
-    hip = CloverHip(path=probe_library_path() if which == "probe" else None, device=0)
+    hip = CloverHip(path=probe_library_path() if which == "probe" else None, device=0, allow_probe=which == "probe")
     lib = hip.lib
     A, B = hip.alloc(G * G // 2), hip.alloc(G * G // 2)
     sA, sB = hip.alloc((G // 64) ** 2 * 4), hip.alloc((G // 64) ** 2 * 4)
@@ -848,7 +848,7 @@ def gemm_object(hip, torch, dev, stream, G: int = 8192) -> dict:
         "full_loop_ms": full_p, "mfma_plus_fold_only_ms": arith, "no_fold_ms": nofold, "mfma_only_ms": mfma_only,
         "frac_if_only_arithmetic": round(ops / arith / 1e9 / FP6_PEAK_TOPS, 4) if arith else None,
         "power_and_clock_during_prepared_gemm": power,
-        "what": "k_m4_gemm_fp6_t256 on prepared operands through clover_amd/lib/libclover_hip_probe.so (bench-only build of the same kernel with "
+        "what": "k_m4_gemm_fp6_t256 on prepared operands through tools/_build/libclover_hip_probe.so (bench-only build of the same kernel with "
                 "CLV_GEMM_LOOP=vN variants: v9 = nothing but the wave's MFMAs and the per-K-block fp32 fold -- no staging, fragment reads, "
                 "barrier, store or pointer arithmetic; v5 = the whole loop without the fold; int32 v9 = the MFMAs alone).  The definition's "
                 "one fp32 fma per element and K-block runs on the VALU, which on a CDNA4 SIMD issues BESIDE an MFMA for only 2-5 instructions "

@@ -73,18 +73,24 @@ def build_hip_library(force: bool = False, verbose: bool = False) -> Path:
 
 
 def probe_library_path() -> Path:
-    return repo_root() / "clover_amd" / "lib" / "libclover_hip_probe.so"
+    # NOT beside the product library: a mis-set -L / CLV_LIB must never pick up a build whose GEMM variants are wrong by construction
+    return repo_root() / "tools" / "_build" / "libclover_hip_probe.so"
 
 
 def build_probe_library(force: bool = False) -> Path:
     """libclover_hip_probe.so = the product's objects with gemm6.hip compiled a second time under -DCLV_GEMM_EXPERIMENTS: the GEMM main
     loop's timing-only variants with parts left out (tools/gen_gemm6_loop256.py ... experiments; results wrong by construction), selected
-    by CLV_GEMM_LOOP=vN.  BENCH INFRASTRUCTURE: bench.py's `gemm.ceiling` and tools/gemm_bench.py load it explicitly to measure what the
+    by CLV_GEMM_LOOP=vN.  It lives under tools/_build/, and clv_version() of it reads "clover_hip_probe ..." (load_library refuses that unless
+    allow_probe=True).  BENCH INFRASTRUCTURE: bench.py's `gemm.ceiling` and tools/gemm_bench.py load it explicitly to measure what the
     arithmetic alone costs on the box the bench runs on; nothing else ever loads it and the product library has no such switch."""
     import sys
     root = repo_root()
     src_dir = root / "clover_amd" / "csrc"
     out = probe_library_path()
+    out.parent.mkdir(parents=True, exist_ok=True)
+    stale_old = repo_root() / "clover_amd" / "lib" / "libclover_hip_probe.so"      # where rounds 2-3 put it
+    if stale_old.exists():
+        stale_old.unlink()
     build_hip_library(force=force)
     obj_dir = hip_library_path().parent / "obj"
     gen = root / "tools" / "gen_gemm6_loop256.py"

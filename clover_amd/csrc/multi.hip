@@ -100,6 +100,7 @@ struct clm4_shard_ctx {
     std::vector<ncclComm_t> comm;
     // timed-loop form (clm4_sharded_loop_begin / _mvm_enqueue): a second result buffer and an exchange stream per device, so the
     // gather of step i runs beside the kernel of step i+1; nothing in it synchronises with the host
+    bool loop_ready = false;                // clm4_sharded_loop_begin built cs / r2 / sr2 / kdone / gdone completely
     int slots = 0;                          // steps whose events are kept (3 events per step and device)
     std::vector<hipStream_t> cs;            // per device: the stream the exchanges of the loop run on
     std::vector<int8_t *> r2;               // per device: FULL result nibbles, buffer 1 (buffer 0 is r)
@@ -412,28 +413,54 @@ extern "C" int clm4_sharded_loop_begin(clm4_shard_ctx *c, int slots)
     CLV_REQUIRE(c && slots >= 0 && slots <= (1 << 20), "clm4_sharded_loop_begin: bad argument");
     DeviceGuard guard;
     const int n = c->ndev;
-    if (c->cs.empty()) {
-        c->cs.assign(n, nullptr); c->r2.assign(n, nullptr); c->sr2.assign(n, nullptr);
-        c->kdone.assign(2 * (size_t)n, nullptr); c->gdone.assign(2 * (size_t)n, nullptr);
-        c->gpending.assign(2 * (size_t)n, 0);
-        for (int d = 0; d < n; d++) {
-            CLV_HIP(hipSetDevice(c->dev[d]));
-            CLV_HIP(hipStreamCreateWithFlags(&c->cs[d], hipStreamNonBlocking));
-            CLV_HIP(hipMalloc((void **)&c->r2[d], c->rows / 2));
-            CLV_HIP(hipMalloc((void **)&c->sr2[d], c->rows / 16));
-            for (int e = 0; e < 2; e++) {
-                CLV_HIP(hipEventCreateWithFlags(&c->kdone[2 * d + e], hipEventDisableTiming));
-                CLV_HIP(hipEventCreateWithFlags(&c->gdone[2 * d + e], hipEventDisableTiming));
+    if (!c->loop_ready) {
+        // built into locals and committed only when every device succeeded: a failure half way leaves the context as it was (no
+        // half-initialised streams / buffers for a later enqueue to trip over), and what was created is released here
+        std::vector<hipStream_t> cs(n, nullptr);
+        std::vector<int8_t *> r2(n, nullptr);
+        std::vector<float *> sr2(n, nullptr);
+        std::vector<hipEvent_t> kdone(2 * (size_t)n, nullptr), gdone(2 * (size_t)n, nullptr);
+        hipError_t err = hipSuccess;
+        for (int d = 0; d < n && err == hipSuccess; d++) {
+            if ((err = hipSetDevice(c->dev[d])) != hipSuccess) break;
+            if ((err = hipStreamCreateWithFlags(&cs[d], hipStreamNonBlocking)) != hipSuccess) break;
+            if ((err = hipMalloc((void **)&r2[d], c->rows / 2)) != hipSuccess) break;
+            if ((err = hipMalloc((void **)&sr2[d], c->rows / 16)) != hipSuccess) break;
+            for (int e = 0; e < 2 && err == hipSuccess; e++) {
+                err = hipEventCreateWithFlags(&kdone[2 * d + e], hipEventDisableTiming);
+                if (err == hipSuccess) err = hipEventCreateWithFlags(&gdone[2 * d + e], hipEventDisableTiming);
             }
         }
+        if (err != hipSuccess) {
+            for (int d = 0; d < n; d++) {
+                (void)hipSetDevice(c->dev[d]);
+                if (cs[d]) (void)hipStreamDestroy(cs[d]);
+                if (r2[d]) (void)hipFree(r2[d]);
+                if (sr2[d]) (void)hipFree(sr2[d]);
+                for (int e = 0; e < 2; e++) {
+                    if (kdone[2 * d + e]) (void)hipEventDestroy(kdone[2 * d + e]);
+                    if (gdone[2 * d + e]) (void)hipEventDestroy(gdone[2 * d + e]);
+                }
+            }
+            clv_set_error("clm4_sharded_loop_begin: %s", hipGetErrorString(err));
+            return CLV_ERR_HIP;
+        }
+        c->cs.swap(cs); c->r2.swap(r2); c->sr2.swap(sr2); c->kdone.swap(kdone); c->gdone.swap(gdone);
+        c->gpending.assign(2 * (size_t)n, 0);
+        c->loop_ready = true;
     }
     if (slots > c->slots) {
-        c->slot_ev.resize(3 * (size_t)slots * n, nullptr);
-        for (size_t k = 3 * (size_t)c->slots * n; k < c->slot_ev.size(); k++) {
-            CLV_HIP(hipSetDevice(c->dev[k % n]));
-            CLV_HIP(hipEventCreate(&c->slot_ev[k]));
+        // events are appended one at a time and c->slots only moves over complete steps: a failure keeps what exists (destroyed with the
+        // context) and a retry continues behind it instead of re-creating over live events
+        const size_t want = 3 * (size_t)slots * n;
+        c->slot_ev.reserve(want);
+        while (c->slot_ev.size() < want) {
+            hipEvent_t e = nullptr;
+            CLV_HIP(hipSetDevice(c->dev[c->slot_ev.size() % n]));
+            CLV_HIP(hipEventCreate(&e));
+            c->slot_ev.push_back(e);
+            c->slots = (int)(c->slot_ev.size() / (3 * (size_t)n));
         }
-        c->slots = slots;
     }
     return CLV_OK;
 }
@@ -441,7 +468,7 @@ extern "C" int clm4_sharded_loop_begin(clm4_shard_ctx *c, int slots)
 extern "C" int clm4_sharded_mvm_enqueue(clm4_shard_ctx *c, int step, int timed)
 {
     CLV_REQUIRE(c && step >= 0, "clm4_sharded_mvm_enqueue: bad argument");
-    CLV_REQUIRE(!c->cs.empty(), "clm4_sharded_mvm_enqueue: call clm4_sharded_loop_begin first");
+    CLV_REQUIRE(c->loop_ready, "clm4_sharded_mvm_enqueue: call clm4_sharded_loop_begin first");
     CLV_REQUIRE(!timed || step < c->slots, "clm4_sharded_mvm_enqueue: step %d has no event slot (%d reserved)", step, c->slots);
     DeviceGuard guard;
     const int n = c->ndev, b = step & 1;
@@ -450,7 +477,15 @@ extern "C" int clm4_sharded_mvm_enqueue(clm4_shard_ctx *c, int step, int timed)
     auto sb = [&](int d) { return b ? c->sr2[d] : c->sr[d]; };
     for (int d = 0; d < n; d++) {
         CLV_HIP(hipSetDevice(c->dev[d]));
-        if (c->gpending[2 * d + b]) CLV_HIP(hipStreamWaitEvent(c->st[d], c->gdone[2 * d + b], 0));   // the gather of step - 2 has left this buffer
+        // the gather of step - 2 has left this buffer.  RCCL: the collective on cs[d] is the only reader AND writer of device d's buffer,
+        // so its own gdone is enough.  Same-device test layout: the exchange is pull-based -- every OTHER shard's exchange stream copies
+        // this shard's slice out of THIS buffer -- so the kernel waits for every shard's gather of step - 2, not only its own
+        if (c->loopback && n > 1) {
+            for (int o = 0; o < n; o++)
+                if (c->gpending[2 * o + b]) CLV_HIP(hipStreamWaitEvent(c->st[d], c->gdone[2 * o + b], 0));
+        } else if (c->gpending[2 * d + b]) {
+            CLV_HIP(hipStreamWaitEvent(c->st[d], c->gdone[2 * d + b], 0));
+        }
         if (timed) CLV_HIP(hipEventRecord(slot(0, d), c->st[d]));
         int rc = clm4_mvm(c->A[d], c->sA[d], c->row_count[d], c->cols, c->x[d], c->sx[d], rb(d) + c->row_begin[d] / 2,
                           sb(d) + c->row_begin[d] / 64, nullptr, c->st[d]);

@@ -25,7 +25,10 @@ void clv_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *clv_last_error(void) { return g_err; }
-extern "C" const char *clv_version(void) { return "clover_hip 0.1 (gfx950)"; }
+// the bench-only probe build (clover_amd/build.py build_probe_library) defines this symbol; the product library does not, the weak
+// reference is then null.  A probe build announces itself, and clover_amd.lib_binding.load_library refuses it unless asked for.
+extern "C" __attribute__((weak)) const char *clvx_probe_tag(void);
+extern "C" const char *clv_version(void) { return clvx_probe_tag ? clvx_probe_tag() : "clover_hip 0.1 (gfx950)"; }
 
 // ---- devices ----------------------------------------------------------------------------------
 extern "C" int clv_device_count(int *count)
@@ -133,7 +136,8 @@ extern "C" int clv_malloc(void **ptr, uint64_t bytes)
     CLV_HIP(hipMalloc(ptr, bytes ? bytes : 1));
     return CLV_OK;
 }
-extern "C" int clv_free(void *ptr) { if (ptr) CLV_HIP(hipFree(ptr)); return CLV_OK; }
+static void rng_graph_forget(const void *ptr);      // below: a freed buffer must not leave its address in graph mode
+extern "C" int clv_free(void *ptr) { if (ptr) { rng_graph_forget(ptr); CLV_HIP(hipFree(ptr)); } return CLV_OK; }
 extern "C" int clv_memset(void *ptr, int value, uint64_t bytes, void *stream)
 {
     CLV_HIP(hipMemsetAsync(ptr, value, bytes, as_stream(stream)));
@@ -243,6 +247,15 @@ static void rng_seq_raise_above(uint64_t stamp)
 // the kernels read the counter (rng_effective_seq).  Price: one extra ~2 us launch per stochastic call -- hence opt-in.
 static std::mutex g_graph_mutex;
 static std::unordered_set<const uint64_t *> g_graph_states;
+static std::atomic<int> g_graph_count{0};       // size of the set, readable without the mutex: the ordinary (non-graph) launch path takes no lock
+
+// hipMalloc hands addresses out again: clv_free drops the address, so a later, unrelated state does not inherit graph mode
+static void rng_graph_forget(const void *ptr)
+{
+    if (g_graph_count.load(std::memory_order_acquire) == 0) return;
+    std::lock_guard<std::mutex> g(g_graph_mutex);
+    if (g_graph_states.erase((const uint64_t *)ptr)) g_graph_count.fetch_sub(1, std::memory_order_release);
+}
 
 __global__ void k_rng_tick(uint64_t *state) { state[RNG_TICK_WORD] += 1; }
 // the counter starts behind every stamp present, so the first tick is newer than both slots
@@ -254,13 +267,16 @@ __global__ void k_rng_tick_init(uint64_t *state)
 
 uint64_t clv_rng_seq_for(uint64_t *state, hipStream_t stream)
 {
+    if (g_graph_count.load(std::memory_order_acquire) == 0) return clv_rng_next_seq();
     bool graph;
     {
         std::lock_guard<std::mutex> g(g_graph_mutex);
-        graph = !g_graph_states.empty() && g_graph_states.count(state) != 0;
+        graph = g_graph_states.count(state) != 0;
     }
     if (!graph) return clv_rng_next_seq();
     hipLaunchKernelGGL(k_rng_tick, dim3(1), dim3(1), 0, stream, state);
+    // a failed tick launch is left in hipGetLastError for the CLV_LAUNCH_CHECK that follows the stochastic kernel of this very call
+    // (every caller launches and checks right behind this): the call then fails instead of drawing from a stale sequence number
     return 0;
 }
 
@@ -271,8 +287,9 @@ extern "C" int clv_rng_graph_mode(uint64_t *state_dev, int on, void *stream)
     if (on) {
         hipLaunchKernelGGL(k_rng_tick_init, dim3(1), dim3(1), 0, as_stream(stream), state_dev);
         CLV_LAUNCH_CHECK();
-        g_graph_states.insert(state_dev);
+        if (g_graph_states.insert(state_dev).second) g_graph_count.fetch_add(1, std::memory_order_release);
     } else if (g_graph_states.erase(state_dev)) {
+        g_graph_count.fetch_sub(1, std::memory_order_release);
         uint64_t tick = 0;                           // the stamps this state carries were made on the device: host numbers continue above them
         CLV_HIP(hipMemcpyAsync(&tick, state_dev + RNG_TICK_WORD, sizeof tick, hipMemcpyDeviceToHost, as_stream(stream)));
         CLV_HIP(hipStreamSynchronize(as_stream(stream)));

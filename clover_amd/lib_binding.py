@@ -107,8 +107,9 @@ class CloverHipError(RuntimeError):
     pass
 
 
-def load_library(path: str | Path | None = None) -> C.CDLL:
-    """dlopen the HIP library and attach prototypes; raises if it is not built."""
+def load_library(path: str | Path | None = None, allow_probe: bool = False) -> C.CDLL:
+    """dlopen the HIP library and attach prototypes; raises if it is not built.  The bench-only probe build (tools/_build/, GEMM loop variants
+    that are wrong by construction) announces itself through clv_version() and is refused unless allow_probe is set."""
     p = Path(path) if path else hip_library_path()
     if not p.exists():
         raise CloverHipError(
@@ -119,6 +120,8 @@ def load_library(path: str | Path | None = None) -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.clv_version().decode().startswith("clover_hip_probe") and not allow_probe:
+        raise CloverHipError(f"{p} is the bench-only probe build ({lib.clv_version().decode()}): not a product library")
     return lib
 
 
@@ -161,8 +164,8 @@ class DevBuf:
 class CloverHip:
     """Thin object wrapper: error checking + numpy convenience around the C ABI."""
 
-    def __init__(self, path: str | Path | None = None, device: int | None = None):
-        self.lib = load_library(path)
+    def __init__(self, path: str | Path | None = None, device: int | None = None, allow_probe: bool = False):
+        self.lib = load_library(path, allow_probe=allow_probe)
         n = C.c_int(0)
         self.check(self.lib.clv_device_count(C.byref(n)))
         self.device_count = n.value

@@ -34,6 +34,21 @@ def test_binding_table_matches_header():
     assert lib.clv_version().decode().startswith("clover_hip")
 
 
+def test_probe_build_is_not_beside_the_product_and_is_refused():
+    """the bench-only probe build (GEMM loop variants that are wrong by construction) lives under tools/_build/, says so in clv_version(),
+    and the loader refuses it unless asked"""
+    import pytest
+    from clover_amd.build import build_probe_library, hip_library_path
+    from clover_amd.lib_binding import CloverHipError
+    probe = build_probe_library()
+    assert probe.parent != hip_library_path().parent
+    assert [f.name for f in hip_library_path().parent.glob("*.so")] == ["libclover_hip.so"]
+    with pytest.raises(CloverHipError, match="probe build"):
+        load_library(probe)
+    assert load_library(probe, allow_probe=True).clv_version().decode().startswith("clover_hip_probe")
+    assert load_library().clv_version().decode().startswith("clover_hip 0.")
+
+
 def test_error_codes_without_compute():
     lib = load_library()
     # argument validation happens before any device work: callable on a CPU-only box

@@ -13,7 +13,7 @@ from clover_amd.lib_binding import CloverHip  # noqa: E402
 # GB_LIB=probe: the bench-only build with the loop's timing-only variants (CLV_GEMM_LOOP=vN; clover_amd/build.py build_probe_library)
 from clover_amd.build import probe_library_path  # noqa: E402
 
-hip = CloverHip(path=probe_library_path() if os.environ.get("GB_LIB") == "probe" else None)
+hip = CloverHip(path=probe_library_path() if os.environ.get("GB_LIB") == "probe" else None, allow_probe=os.environ.get("GB_LIB") == "probe")
 lib = hip.lib
 for G in [int(g) for g in os.environ.get("GB_SIZES", "4096,8192").split(",")]:
     A, B = hip.alloc(G * G // 2), hip.alloc(G * G // 2)

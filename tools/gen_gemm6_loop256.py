@@ -347,7 +347,7 @@ def main():
     """no argument: clover_amd/csrc/gemm6_loop256.inc, the product's loops (libclover_hip.so; committed).
        <out> experiments: the same + the timing-only variants v1..v10 with parts LEFT OUT (wrong results by construction).  The build
             (clover_amd/build.py) generates this into clover_amd/lib/obj/gemm6_loop256_exp.inc and compiles it ONLY into the bench-only probe
-            library clover_amd/lib/libclover_hip_probe.so (-DCLV_GEMM_EXPERIMENTS), where CLV_GEMM_LOOP=vN selects a variant --
+            library tools/_build/libclover_hip_probe.so (-DCLV_GEMM_EXPERIMENTS), where CLV_GEMM_LOOP=vN selects a variant --
             bench.py's `gemm.ceiling` and tools/gemm_bench.py load that library explicitly; the product library has no such switch.
        <out> candidates: v1.. = CORRECT alternative schedules (CANDIDATES) for A/B runs through the same switch."""
     if len(sys.argv) > 2 and sys.argv[2] == "candidates":
