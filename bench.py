@@ -99,12 +99,13 @@ def cpu_baseline_child(path: str) -> None:
     except MemoryError as e:
         vec["failed"] = f"MemoryError: {e}"
 
-    best, tried, match = None, {}, None
+    best, tried, match, by_threads = None, {}, None, {}
     for threads in counts:
         F.set_threads(threads)
         qA = F.first_touch_copy(d["qA"], rows)          # NUMA placement for this thread count (threads are bound: OMP_PROC_BIND)
         med, mn, mx, runs = med_time(lambda: F.m4_mvm(qA, d["sA"], rows, cols, d["qx"], d["sx"], out=out), 15, 4.0)
         tried[threads] = round(med * 1e3, 3)
+        by_threads[threads] = {"s": med, "ms": round(med * 1e3, 3), "ms_min": round(mn * 1e3, 3), "ms_max": round(mx * 1e3, 3), "runs": runs}
         if best is None or med < best[0]:
             best = (med, threads, mn, mx, runs)
         if match is None:
@@ -131,7 +132,7 @@ def cpu_baseline_child(path: str) -> None:
     dot = None
     if "dot_sequential" in vec.get("n2^24", {}):
         dot = {"n": 1 << 24, "seconds": vec["n2^24"]["dot_sequential"]["ms"] / 1e3}
-    print(json.dumps({"seconds": best[0], "threads": best[1], "min_s": best[2], "max_s": best[3], "runs": best[4], "median_ms_by_threads": tried,
+    print(json.dumps({"seconds": best[0], "threads": best[1], "min_s": best[2], "max_s": best[3], "runs": best[4], "median_ms_by_threads": tried, "by_threads": by_threads,
                       "runnable_cpus": runnable, "gpu_result_matches_cpu": match, "dot": dot, "vector_ops": vec}))
 
 
@@ -169,9 +170,26 @@ def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sampl
                 break
     except OSError:
         pass
+    # the cgroup quota is what the process may use ON AVERAGE; a team wider than it runs in bursts and gets throttled (ms_max).  Both are
+    # reported: the best thread count overall (`value`) and the widest team that stays inside the quota (`within_quota`)
+    quota_cpus = None
+    try:
+        mxq, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota_cpus = None if mxq == "max" else int(mxq) / int(period)
+    except (OSError, ValueError):
+        pass
+    bt = {int(k): v for k, v in (res.get("by_threads") or {}).items()}
+    for v in bt.values():
+        v["GB/s"] = round(nbytes / v.pop("s") / 1e9, 3)
+    inside = [t for t in bt if quota_cpus is None or t <= quota_cpus]
+    within = None
+    if inside:
+        tq = min(inside, key=lambda t: bt[t]["ms"])
+        within = {"threads": tq, **bt[tq], "note": "best team no wider than the cgroup cpu quota" if quota_cpus else "no quota: same as value"}
     return {
         "value": round(nbytes / res["seconds"] / 1e9, 3), "unit": "GB/s", "cores": res["threads"], "kind": "port",
-        "sample": f"mvm of the first {sample_rows} rows x {cols} cols of the same matrix ({nbytes} B), median of <=15 runs, "
+        "within_quota": within, "quota_cpus": quota_cpus, "by_threads": {str(k): v for k, v in sorted(bt.items())},
+        "sample": f"mvm of {'ALL' if sample_rows == rows_total else 'the first'} {sample_rows} rows x {cols} cols of the same matrix ({nbytes} B), median of <=15 runs, "
                   f"AVX2+OpenMP restatement with the reference's vpmaddubsw instruction mix (oracle/clover4_fast.c, bound threads, NUMA "
                   f"first-touch placement, best of 1/16/64/half/all threads) on {cpu_model}, {os.cpu_count()} cpus, "
                   f"{res.get('runnable_cpus')} runnable by this process, {quota}",
@@ -198,13 +216,16 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before the timed ones (default 20; 80 for --workload gemm: the matrix "
                                                                "pipe's clocks settle after about 50 calls)")
     ap.add_argument("--rows-per-gpu", type=int, default=65536)
-    ap.add_argument("--preset", choices=("c3", "c5-weak", "c5-strong"), default="c3",
-                    help="c3 (default): 65536 x 65536 per GPU, weak scaling (BASELINE configs[2] at N=1); c5-weak: 131072 x 65536 per GPU "
-                         "(= configs[4] at N=8); c5-strong: the 2^20 x 2^16 matrix of configs[4] split over the N GPUs (needs N * 288 GB >= 32 GiB: any N)")
+    ap.add_argument("--preset", choices=("c3", "c5-weak", "c5-strong"), default=None,
+                    help="default (no preset): the headline is c3 -- 65536 x 65536 per GPU, weak scaling (BASELINE configs[2] at N=1) -- and the SAME "
+                         "line carries a `c5` object timed right behind it: BASELINE configs[4], the 2^20 x 2^16 matrix row-sharded over the N GPUs "
+                         "(2^20 / N rows each, CloverMatrix4.h:1700-1705's split).  c3 / c5-weak (131072 x 65536 per GPU = configs[4] at N=8) / "
+                         "c5-strong (configs[4] split over the N GPUs as the headline): one configuration, no c5 object")
+    ap.add_argument("--no-c5", action="store_true", help="leave the c5 object out of a default (no --preset) run")
     ap.add_argument("--cols", type=int, default=65536)
-    ap.add_argument("--cpu-sample-rows", type=int, default=32768,
-                    help="rows of the matrix the CPU baseline multiplies (32768 x 65536 = 1 GiB of nibbles: beyond the 2 x 256 MB of L3 "
-                         "of the host, so the number is a DRAM number like the reference's)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=65536,
+                    help="rows of the matrix the CPU baseline multiplies (default: all 65536 rows of C3 = 2 GiB of nibbles: beyond the 2 x 256 MB "
+                         "of L3 of the host, so the number is a DRAM number like the reference's)")
     ap.add_argument("--workload", choices=("mvm", "gemm"), default="mvm",
                     help="mvm (default): the headline GEMV of BASELINE configs[2]; gemm: configs[3], one GPU, its own JSON line")
     ap.add_argument("--gemm-size", type=int, default=8192)
@@ -303,139 +324,196 @@ def main() -> None:
                 data_backend = "nccl"
             else:
                 data_group = None
+    # tests: CLOVER_BENCH_FORCE_GLOO_FALLBACK=1 takes the "RCCL group could not be built" branch on purpose, so that the degraded line an
+    # 8-GPU run would print after an RCCL failure is seen (and asserted) before it ever matters
+    if dist_on and not debug_one_gpu and os.environ.get("CLOVER_BENCH_FORCE_GLOO_FALLBACK") == "1":
+        data_group, data_backend, nccl_error = None, "gloo", "forced by CLOVER_BENCH_FORCE_GLOO_FALLBACK=1 (test)"
     host_exchange = dist_on and data_backend == "gloo"       # the packed result travels through host memory
+    degraded = host_exchange                                  # every timed step then carries a device->host copy + a gloo all-gather
 
     hip = CloverHip(device=dev_index)                # raises if libclover_hip.so is missing: no fallback
     lib = hip.lib
     stream = torch.cuda.current_stream().cuda_stream
+    seed = 0xC10FE4
+    cols = args.cols
+    assert cols % 128 == 0
+    hb = cols // 64
 
     scaling = "weak"
-    if args.preset == "c5-weak":
+    preset = args.preset or "c3"
+    if preset == "c5-weak":
         args.rows_per_gpu = 131072
-    elif args.preset == "c5-strong":
+    elif preset == "c5-strong":
         assert (1 << 20) % (64 * world) == 0
         args.rows_per_gpu, scaling = (1 << 20) // world, "strong"
-    rows, cols = args.rows_per_gpu, args.cols
-    assert rows % 64 == 0 and cols % 128 == 0
-    rows_total = rows * world
-    hb = cols // 64
-    seed = 0xC10FE4
 
-    # ---- synthetic operands, resident in HBM (quantised domain: nibbles U[-7,7], scales U[0.5,2)) ----
-    A = torch.empty(rows * cols // 2, dtype=torch.uint8, device=dev)
-    sA = torch.empty((rows // 64) * hb, dtype=torch.float32, device=dev)
     x = torch.empty(cols // 2, dtype=torch.uint8, device=dev)
     sx = torch.empty(hb, dtype=torch.float32, device=dev)
-    hip.check(lib.clv_fill_random_nibbles(A.data_ptr(), A.numel(), seed, rank * rows * cols // 2, stream))
-    hip.check(lib.clv_fill_random_scales(sA.data_ptr(), sA.numel(), seed + 1, rank * (rows // 64) * hb, stream))
     hip.check(lib.clv_fill_random_nibbles(x.data_ptr(), x.numel(), seed + 2, 0, stream))
     hip.check(lib.clv_fill_random_scales(sx.data_ptr(), sx.numel(), seed + 3, 0, stream))
 
-    # packed result of this rank: [rows/2 nibble bytes | rows/64 fp32 scales]; gathered as one buffer
-    assert partition_rows(rows_total, world, rank) == (rank * rows, rows)     # weak scaling: equal contiguous shards
-    # two result buffers: while the gather of step i is in flight on RCCL's stream, step i+1 writes the other one
-    res_bufs = [torch.empty(packed_bytes(rows), dtype=torch.uint8, device=dev) for _ in range(2)]
-    res = res_bufs[0]
-    pending = [None, None]
+    def time_config(rows: int, cold_first: bool) -> dict:
+        """One row-sharded mvm configuration: this rank's `rows` rows of a (rows * world) x cols matrix, generated in HBM, then
+        [cold_first: W warm-up + K timed steps straight away], the clock settle, W warm-up steps and the K timed steps.  Both timed regions
+        are bracketed by barrier + synchronize, their wall time is the max over ranks."""
+        assert rows % 64 == 0
+        rows_total = rows * world
+        # ---- synthetic operands, resident in HBM (quantised domain: nibbles U[-7,7], scales U[0.5,2)) ----
+        A = torch.empty(rows * cols // 2, dtype=torch.uint8, device=dev)
+        sA = torch.empty((rows // 64) * hb, dtype=torch.float32, device=dev)
+        hip.check(lib.clv_fill_random_nibbles(A.data_ptr(), A.numel(), seed, rank * rows * cols // 2, stream))
+        hip.check(lib.clv_fill_random_scales(sA.data_ptr(), sA.numel(), seed + 1, rank * (rows // 64) * hb, stream))
+        # packed result of this rank: [rows/2 nibble bytes | rows/64 fp32 scales]; gathered as one buffer
+        assert partition_rows(rows_total, world, rank) == (rank * rows, rows)     # equal contiguous shards
+        # two result buffers: while the gather of step i is in flight on RCCL's stream, step i+1 writes the other one
+        res_bufs = [torch.empty(packed_bytes(rows), dtype=torch.uint8, device=dev) for _ in range(2)]
+        res = res_bufs[0]
+        pending = [None, None]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        def step(i: int | None, n: int) -> None:
+            buf = res_bufs[n & 1]
+            if pending[n & 1] is not None:            # the gather that last read this buffer must be done before it is overwritten
+                pending[n & 1].wait()
+                pending[n & 1] = None
+            timed = i is not None and i % args.event_every == 0
+            if timed:
+                ev[i][0].record()
+            hip.check(lib.clm4_mvm(A.data_ptr(), sA.data_ptr(), rows, cols, x.data_ptr(), sx.data_ptr(), buf.data_ptr(),
+                                   buf.data_ptr() + rows // 2, None, stream))
+            if timed:
+                ev[i][1].record()
+            if dist_on:                               # RCCL all-gather of [nibbles | scales] from every rank, overlapping the next step
+                pending[n & 1] = gather_packed_async(buf.cpu() if host_exchange else buf, rows_total, group=data_group)
 
-    def step(i: int | None, n: int) -> None:
-        buf = res_bufs[n & 1]
-        if pending[n & 1] is not None:            # the gather that last read this buffer must be done before it is overwritten
-            pending[n & 1].wait()
-            pending[n & 1] = None
-        timed = i is not None and i % args.event_every == 0
-        if timed:
-            ev[i][0].record()
-        hip.check(lib.clm4_mvm(A.data_ptr(), sA.data_ptr(), rows, cols, x.data_ptr(), sx.data_ptr(), buf.data_ptr(),
-                               buf.data_ptr() + rows // 2, None, stream))
-        if timed:
-            ev[i][1].record()
-        if dist_on:                               # RCCL all-gather of [nibbles | scales] from every rank, overlapping the next step
-            pending[n & 1] = gather_packed_async(buf.cpu() if host_exchange else buf, rows_total, group=data_group)
+        def drain() -> None:                          # every gather has landed (the stream waits; synchronize() follows)
+            for j in (0, 1):
+                if pending[j] is not None:
+                    pending[j].wait()
+                    pending[j] = None
 
-    def drain() -> None:                          # every gather has landed (the stream waits; synchronize() follows)
-        for j in (0, 1):
-            if pending[j] is not None:
-                pending[j].wait()
-                pending[j] = None
-
-    # clock settle (untimed, reported): the same step, back to back, until --settle-ms of wall time have passed
-    # (a launch COUNT derived from the shape, not a wall-clock loop: with N > 1 every step carries a collective, so all ranks must issue
-    #  the same number of them)
-    settle_launches = 0
-    if args.settle_ms > 0:
-        est_ms = mvm_bytes(rows, cols) / 6.0e12 * 1e3                      # one launch at ~6 TB/s
-        settle_target = min(256, max(8, int(args.settle_ms / est_ms + 7) // 8 * 8))        # small test shapes: capped
-        torch.cuda.synchronize()
-        while settle_launches < settle_target:
-            for _ in range(8):
-                step(None, settle_launches)
-                settle_launches += 1
+        def timed_region() -> tuple[float, float]:
+            """W untimed + K timed steps -> (wall seconds of the K steps, max over ranks; kernel ms from the sampled event pairs, this rank)"""
+            for w_ in range(args.warmup):
+                step(None, w_)
             drain()
             torch.cuda.synchronize()
-    for w_ in range(args.warmup):
-        step(None, w_)
-    drain()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, i)
-    drain()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    if dist_on:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+            if dist_on:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(i, i)
+            drain()
+            torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            if dist_on:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            km = [a.elapsed_time(b) for i, (a, b) in enumerate(ev) if i % args.event_every == 0]
+            return float(t.item()), sum(km) / len(km)
 
-    kern_ms = [a.elapsed_time(b) for i, (a, b) in enumerate(ev) if i % args.event_every == 0]
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    kt = torch.tensor([kern_avg_ms], dtype=torch.float64, device=red_dev)
-    if dist_on:
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-    kern_avg_ms = float(kt.item())
-    per_rank_kernel_ms, gather_us, rccl_ranks = None, None, None
-    if dist_on:
-        pr = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
-        dist.all_gather(pr, torch.tensor([sum(kern_ms) / len(kern_ms)], dtype=torch.float64, device=red_dev))
-        per_rank_kernel_ms = [round(float(v.item()), 5) for v in pr]
-        rccl_ranks = dist.get_world_size(data_group) if data_backend == "nccl" else 0
-        # the exchange alone, outside the timed region: K blocking all-gathers of the packed result
-        reps = 50
-        dist.barrier()
         torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        for _ in range(reps):
-            gather_packed(res.cpu() if host_exchange else res, rows_total, group=data_group)
-        torch.cuda.synchronize()
-        gt = torch.tensor([(time.perf_counter() - g0) / reps * 1e6], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        gather_us = round(float(gt.item()), 1)
+        cold = timed_region() if cold_first else None
+        # clock settle (untimed, reported): the same step, back to back, until --settle-ms of work have been issued
+        # (a launch COUNT derived from the shape, not a wall-clock loop: with N > 1 every step carries a collective, so all ranks must issue
+        #  the same number of them)
+        settle_launches = 0
+        if args.settle_ms > 0:
+            est_ms = mvm_bytes(rows, cols) / 6.0e12 * 1e3                      # one launch at ~6 TB/s
+            settle_target = min(256, max(8, int(args.settle_ms / est_ms + 7) // 8 * 8))        # small test shapes: capped
+            while settle_launches < settle_target:
+                for _ in range(8):
+                    step(None, settle_launches)
+                    settle_launches += 1
+                drain()
+                torch.cuda.synchronize()
+        elapsed, kern_mine = timed_region()
+        kt = torch.tensor([kern_mine], dtype=torch.float64, device=red_dev)
+        if dist_on:
+            dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        r = {"rows": rows, "rows_total": rows_total, "elapsed": elapsed, "kern_avg_ms": float(kt.item()), "kern_samples": len(range(0, args.steps, args.event_every)),
+             "settle_launches": settle_launches, "cold": cold, "per_rank_kernel_ms": None, "gather_us": None, "gather_ok": None,
+             "A": A, "sA": sA, "res": res}
+        if dist_on:
+            pr = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
+            dist.all_gather(pr, torch.tensor([kern_mine], dtype=torch.float64, device=red_dev))
+            r["per_rank_kernel_ms"] = [round(float(v.item()), 5) for v in pr]
+            # the exchange alone, outside the timed region: K blocking all-gathers of the packed result
+            reps = 50
+            dist.barrier()
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for _ in range(reps):
+                gather_packed(res.cpu() if host_exchange else res, rows_total, group=data_group)
+            torch.cuda.synchronize()
+            gt = torch.tensor([(time.perf_counter() - g0) / reps * 1e6], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            r["gather_us"] = round(float(gt.item()), 1)
+            # outside the timed region: every rank finds its own shard, bit for bit, at its place in the gathered vector
+            from clover_amd.sharding import unpack_gathered
+            g = gather_packed(res.cpu() if host_exchange else res, rows_total, group=data_group)
+            nib, sc = unpack_gathered(g, rows_total, world)
+            mine = res.cpu() if host_exchange else res
+            ok = bool(torch.equal(nib[rank * rows // 2: (rank + 1) * rows // 2], mine[: rows // 2])) and \
+                bool(torch.equal(sc[rank * rows // 64: (rank + 1) * rows // 64], mine[rows // 2:].view(torch.float32)))
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            r["gather_ok"] = bool(okt.item())
+        return r
 
-    # outside the timed region: every rank finds its own shard, bit for bit, at its place in the gathered vector
-    gather_ok = None
-    if dist_on:
-        from clover_amd.sharding import unpack_gathered
-        g = gather_packed(res.cpu() if host_exchange else res, rows_total, group=data_group)
-        nib, sc = unpack_gathered(g, rows_total, world)
-        mine = res.cpu() if host_exchange else res
-        ok = bool(torch.equal(nib[rank * rows // 2: (rank + 1) * rows // 2], mine[: rows // 2])) and \
-            bool(torch.equal(sc[rank * rows // 64: (rank + 1) * rows // 64], mine[rows // 2:].view(torch.float32)))
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        gather_ok = bool(okt.item())
+    rows = args.rows_per_gpu
+    head = time_config(rows, cold_first=True)
+    rows_total = head["rows_total"]
+    rccl_ranks = (dist.get_world_size(data_group) if data_backend == "nccl" else 0) if dist_on else None
+
+    # BASELINE configs[4] in the same line: the 2^20 x 2^16 matrix row-sharded over the N ranks (2^20 / N rows each: strong scaling; 32 GiB
+    # fit one GPU, so N = 1 carries it too).  Only when no --preset was asked for: the presets time one configuration each.
+    c5 = None
+    c5_total = int(os.environ.get("CLOVER_BENCH_C5_ROWS", str(1 << 20)))       # tests shrink it; the object says so
+    if args.preset is None and not args.no_c5:
+        if c5_total % (64 * world) != 0:
+            c5 = {"skipped": f"{c5_total} rows do not split into {world} equal shards of whole 64-row blocks"}
+        else:
+            head_A, head_sA, head_res = head.pop("A"), head.pop("sA"), head.pop("res")
+            keep_for_cpu = world == 1 and not args.no_cpu_baseline
+            if not keep_for_cpu:
+                del head_A, head_sA
+            torch.cuda.empty_cache()
+            c5r = time_config(c5_total // world, cold_first=False)
+            c5r.pop("A"), c5r.pop("sA"), c5r.pop("res")
+            torch.cuda.empty_cache()
+            if keep_for_cpu:
+                head["A"], head["sA"] = head_A, head_sA
+            head["res"] = head_res
+            b_tot, b_gpu = mvm_bytes(c5_total, cols), mvm_bytes(c5_total // world, cols)
+            ms5 = c5r["elapsed"] / args.steps * 1e3
+            ach5 = b_gpu / (c5r["kern_avg_ms"] * 1e-3) / 1e9
+            c5 = {
+                "workload": f"CloverMatrix4::mvm {c5_total}x{cols} int4 row-sharded {world} way(s), {c5_total // world} rows per GPU"
+                            + (" = BASELINE configs[4]" if (c5_total, cols) == (1 << 20, 65536) else " (NOT configs[4]: shrunk by CLOVER_BENCH_C5_ROWS / --cols)"),
+                "scaling": "strong", "n_gpus": world, "rows_per_gpu": c5_total // world, "cols": cols, "steps": args.steps, "warmup": args.warmup,
+                "settle_launches": c5r["settle_launches"],
+                "ms_per_step": round(ms5, 5), "value": round(b_tot / (ms5 * 1e-3) / 1e9, 2), "unit": "GB/s",
+                "frac": round(b_tot / (ms5 * 1e-3) / 1e9 / (world * HBM_PEAK_GBS), 4), "frac_of": f"{world} x {HBM_PEAK_GBS:g} GB/s",
+                "algorithmic_bytes_per_step": b_tot, "algorithmic_bytes_per_launch": b_gpu,
+                "kernel_avg_ms": round(c5r["kern_avg_ms"], 5), "kernel_frac": round(ach5 / HBM_PEAK_GBS, 4),
+                "kernel_only_aggregate_GBs": round(world * ach5, 2),
+                "per_rank_kernel_ms": c5r["per_rank_kernel_ms"], "gather_us_blocking": c5r["gather_us"],
+                "gather_bytes_per_rank": packed_bytes(c5_total // world), "gathered_result_verified": c5r["gather_ok"],
+                **({"backend": data_backend, "rccl_ranks": rccl_ranks} if dist_on else {}),
+                **({"degraded": True} if degraded else {}),
+            }
 
     if rank != 0:
         dist.destroy_process_group()
         return
 
+    elapsed, kern_avg_ms, settle_launches = head["elapsed"], head["kern_avg_ms"], head["settle_launches"]
+    per_rank_kernel_ms, gather_us, gather_ok = head["per_rank_kernel_ms"], head["gather_us"], head["gather_ok"]
     ms_per_step = elapsed / args.steps * 1e3
+    ms_cold = head["cold"][0] / args.steps * 1e3
     bytes_total = mvm_bytes(rows_total, cols)
     bytes_gpu = mvm_bytes(rows, cols)
     value = bytes_total / (ms_per_step * 1e-3) / 1e9
@@ -444,13 +522,22 @@ def main() -> None:
     out = {
         "metric": "int4 GEMV (CloverMatrix4::mvm) effective GB/s, algorithmic operand bytes / time",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 5),
+        # the same K steps measured FIRST, behind nothing but the data fill and the driver's W warm-up steps (no clock settle)
+        "ms_per_step_cold": round(ms_cold, 5), "value_cold": round(bytes_total / (ms_cold * 1e-3) / 1e9, 2),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "int4", "data": "synthetic",
+        # degraded: the RCCL group could not be used and every timed step carried a device->host copy + a gloo all-gather: `value` is NOT
+        # a scaling number then; the kernel-only aggregate is what the GPUs did
+        **({"degraded": True, "degraded_why": ("CLOVER_BENCH_DEBUG_ONE_GPU rehearsal" if debug_one_gpu else
+                                                 f"RCCL unavailable ({nccl_error or 'the RCCL group failed on another rank'}): exchange through gloo and host memory"),
+            "value_kernel_only": round(world * achieved, 2)} if degraded else {}),
         "config": {
-            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 ({rows}x{cols} per GPU; preset {args.preset}: BASELINE "
-                        f"{'configs[2] per GPU' if args.preset == 'c3' else 'configs[4]' + (' at N=8' if args.preset == 'c5-weak' else '')}), "
+            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 ({rows}x{cols} per GPU; preset {preset}: BASELINE "
+                        f"{'configs[2] per GPU' if preset == 'c3' else 'configs[4]' + (' at N=8' if preset == 'c5-weak' else '')}), "
                         f"x and result CloverVector4, STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
             "rows_per_gpu": rows, "cols": cols, "parallelism": f"row-shard x{world}" + (" + all-gather of every step's packed result, overlapped with the next step" if dist_on else ""),
+            "settle_launches": settle_launches, "settle_ms": args.settle_ms,
             **({"gathered_result_verified": gather_ok, "rccl_ranks": rccl_ranks, "backend": data_backend,
                 **({"nccl_fallback_reason": nccl_error or "the RCCL group failed on another rank"} if host_exchange and not debug_one_gpu else {}),
                 "per_rank_kernel_ms": per_rank_kernel_ms, "gather_us_blocking": gather_us,
@@ -460,16 +547,20 @@ def main() -> None:
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1),
             "algorithmic_bytes_per_step": bytes_total,
             "clock_settle": f"{settle_launches} untimed launches of the same step ({args.settle_ms:g} ms) before the {args.warmup} warm-up steps "
-                            "(steady clocks need 20-30 ms of work after idle); the K timed steps and their barriers are unchanged",
+                            "(steady clocks need 20-30 ms of work after idle); the K timed steps and their barriers are unchanged; "
+                            "ms_per_step_cold = the same K steps measured before any of that",
             "arithmetic": "int4 x int4 products summed exactly per 32-bit word (v_dot8_i32_i4), fp32 per-block scale + fma chains in reference order",
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "kernel": "k_m4_mvm64", "kernel_avg_ms": round(kern_avg_ms, 5), "algorithmic_bytes_per_launch": bytes_gpu,
-            "kernel_avg_of": f"HIP event pairs around every {args.event_every}. timed step ({len(kern_ms)} launches) on the launch stream",
+            "kernel_avg_ms_cold": round(head["cold"][1], 5),
+            "kernel_avg_of": f"HIP event pairs around every {args.event_every}. timed step ({head['kern_samples']} launches) on the launch stream",
         },
     }
+    if c5 is not None:
+        out["c5"] = c5
 
     tr = pmc_traffic(rows, cols)
     if tr:
@@ -487,7 +578,8 @@ def main() -> None:
 
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = run_cpu_baseline(hip, A, sA, x, sx, res[: rows // 2], res[rows // 2:].view(torch.float32),
+            res = head["res"]
+            out["cpu_baseline"] = run_cpu_baseline(hip, head["A"], head["sA"], x, sx, res[: rows // 2], res[rows // 2:].view(torch.float32),
                                                    rows_total, cols, args.cpu_sample_rows)
         except Exception as e:                                   # the baseline must never kill the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
@@ -528,74 +620,84 @@ def one_process_main(args, torch, CloverHip) -> None:
     """N GPUs driven by THIS process through the C ABI (clm4_sharded_create / _set_x / _loop_begin / _mvm_enqueue / _sync): the product's
     own multi-GPU path, timed as it would run inside an application loop.  A step = every shard's kernel on its device's compute stream +
     one grouped in-place ncclAllGather pair on its exchange stream (overlapping the next step's kernel); no host synchronisation inside
-    the timed region.  CLOVER_BENCH_DEBUG_ONE_GPU=1 lists device 0 N times (exchanges become copies): a rehearsal, not a measurement."""
+    the timed region.  CLOVER_BENCH_DEBUG_ONE_GPU=1 lists device 0 N times (exchanges become copies): a rehearsal, not a measurement.
+    Without --preset the line also carries the `c5` object (BASELINE configs[4] split N ways), as in ranks mode."""
     import ctypes as C
+
+    import numpy as np
     debug = os.environ.get("CLOVER_BENCH_DEBUG_ONE_GPU") == "1"
     n = args.gpus
     hip = CloverHip(device=0)
     lib = hip.lib
     scaling = "weak"
-    if args.preset == "c5-weak":
+    preset = args.preset or "c3"
+    if preset == "c5-weak":
         args.rows_per_gpu = 131072
-    elif args.preset == "c5-strong":
+    elif preset == "c5-strong":
         assert (1 << 20) % (64 * n) == 0
         args.rows_per_gpu, scaling = (1 << 20) // n, "strong"
-    rows, cols = args.rows_per_gpu, args.cols
-    rows_total = rows * n
-    devs = (C.c_int * n)(*([0] * n if debug else range(n)))
-    ctx = C.c_void_p()
-    hip.check(lib.clm4_sharded_create(C.byref(ctx), n, devs, rows_total, cols))
-    try:
-        hip.check(lib.clm4_sharded_fill_random(ctx, 0xC10FE4))
-        x = torch.empty(cols // 2, dtype=torch.uint8, device="cuda:0")
-        sx = torch.empty(cols // 64, dtype=torch.float32, device="cuda:0")
-        hip.check(lib.clv_fill_random_nibbles(x.data_ptr(), x.numel(), 0xC10FE4 + 2, 0, None))
-        hip.check(lib.clv_fill_random_scales(sx.data_ptr(), sx.numel(), 0xC10FE4 + 3, 0, None))
-        torch.cuda.synchronize()
-        hip.check(lib.clm4_sharded_set_x(ctx, x.data_ptr(), sx.data_ptr(), 0))
-        hip.check(lib.clm4_sharded_loop_begin(ctx, args.steps))
-        if args.settle_ms > 0:                        # clock settle, as in ranks mode (untimed)
-            k_, settle_target = 0, min(256, max(8, int(args.settle_ms / (mvm_bytes(rows, cols) / 6.0e12 * 1e3) + 7) // 8 * 8))
-            while k_ < settle_target:
-                for _ in range(8):
-                    hip.check(lib.clm4_sharded_mvm_enqueue(ctx, k_, 0))
-                    k_ += 1
-                hip.check(lib.clm4_sharded_sync(ctx))
-        for w_ in range(args.warmup):
-            hip.check(lib.clm4_sharded_mvm_enqueue(ctx, w_, 0))
-        hip.check(lib.clm4_sharded_sync(ctx))
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            hip.check(lib.clm4_sharded_mvm_enqueue(ctx, i, 1))
-        hip.check(lib.clm4_sharded_sync(ctx))
-        elapsed = time.perf_counter() - t0
-        per_k, per_g = [], []
-        km, gm = C.c_float(), C.c_float()
-        for d in range(n):
-            ks, gs = 0.0, 0.0
+    cols = args.cols
+    x = torch.empty(cols // 2, dtype=torch.uint8, device="cuda:0")
+    sx = torch.empty(cols // 64, dtype=torch.float32, device="cuda:0")
+    hip.check(lib.clv_fill_random_nibbles(x.data_ptr(), x.numel(), 0xC10FE4 + 2, 0, None))
+    hip.check(lib.clv_fill_random_scales(sx.data_ptr(), sx.numel(), 0xC10FE4 + 3, 0, None))
+    torch.cuda.synchronize()
+
+    def time_config(rows: int) -> dict:
+        rows_total = rows * n
+        devs = (C.c_int * n)(*([0] * n if debug else range(n)))
+        ctx = C.c_void_p()
+        hip.check(lib.clm4_sharded_create(C.byref(ctx), n, devs, rows_total, cols))
+        try:
+            hip.check(lib.clm4_sharded_fill_random(ctx, 0xC10FE4))
+            hip.check(lib.clm4_sharded_set_x(ctx, x.data_ptr(), sx.data_ptr(), 0))
+            hip.check(lib.clm4_sharded_loop_begin(ctx, args.steps))
+            settle = 0
+            if args.settle_ms > 0:                        # clock settle, as in ranks mode (untimed)
+                settle_target = min(256, max(8, int(args.settle_ms / (mvm_bytes(rows, cols) / 6.0e12 * 1e3) + 7) // 8 * 8))
+                while settle < settle_target:
+                    for _ in range(8):
+                        hip.check(lib.clm4_sharded_mvm_enqueue(ctx, settle, 0))
+                        settle += 1
+                    hip.check(lib.clm4_sharded_sync(ctx))
+            for w_ in range(args.warmup):
+                hip.check(lib.clm4_sharded_mvm_enqueue(ctx, w_, 0))
+            hip.check(lib.clm4_sharded_sync(ctx))
+            t0 = time.perf_counter()
             for i in range(args.steps):
-                hip.check(lib.clm4_sharded_step_timing(ctx, d, i, C.byref(km), C.byref(gm)))
-                ks += km.value
-                gs += gm.value
-            per_k.append(ks / args.steps)
-            per_g.append(gs / args.steps)
-        # every device holds the full result, and it equals the unsharded call's (n * 72 KiB: compared on the host)
-        last = (args.steps - 1) & 1
-        import numpy as np
-        full = []
-        for d in range(n):
-            rp, sp = C.c_void_p(), C.c_void_p()
-            hip.check(lib.clm4_sharded_result_buf(ctx, d, last, C.byref(rp), C.byref(sp)))
-            rr = np.empty(rows_total // 2, np.uint8)
-            ss = np.empty(rows_total // 64, np.float32)
-            hip.check(lib.clv_set_device(0 if debug else d))
-            hip.check(lib.clv_memcpy_d2h(rr.ctypes.data, rp, rr.nbytes, None))
-            hip.check(lib.clv_memcpy_d2h(ss.ctypes.data, sp, ss.nbytes, None))
-            hip.check(lib.clv_device_sync())
-            full.append((rr, ss))
-        hip.check(lib.clv_set_device(0))
-        same = all(np.array_equal(full[0][0], f[0]) and np.array_equal(full[0][1].view(np.uint32), f[1].view(np.uint32)) for f in full[1:])
-        # shard 0's rows against a plain clm4_mvm of the same (regenerated) rows on device 0
+                hip.check(lib.clm4_sharded_mvm_enqueue(ctx, i, 1))
+            hip.check(lib.clm4_sharded_sync(ctx))
+            elapsed = time.perf_counter() - t0
+            per_k, per_g = [], []
+            km, gm = C.c_float(), C.c_float()
+            for d in range(n):
+                ks, gs = 0.0, 0.0
+                for i in range(args.steps):
+                    hip.check(lib.clm4_sharded_step_timing(ctx, d, i, C.byref(km), C.byref(gm)))
+                    ks += km.value
+                    gs += gm.value
+                per_k.append(ks / args.steps)
+                per_g.append(gs / args.steps)
+            # every device holds the full result, and it equals the unsharded call's (n * 72 KiB: compared on the host)
+            last = (args.steps - 1) & 1
+            full = []
+            for d in range(n):
+                rp, sp = C.c_void_p(), C.c_void_p()
+                hip.check(lib.clm4_sharded_result_buf(ctx, d, last, C.byref(rp), C.byref(sp)))
+                rr = np.empty(rows_total // 2, np.uint8)
+                ss = np.empty(rows_total // 64, np.float32)
+                hip.check(lib.clv_set_device(0 if debug else d))
+                hip.check(lib.clv_memcpy_d2h(rr.ctypes.data, rp, rr.nbytes, None))
+                hip.check(lib.clv_memcpy_d2h(ss.ctypes.data, sp, ss.nbytes, None))
+                hip.check(lib.clv_device_sync())
+                full.append((rr, ss))
+            hip.check(lib.clv_set_device(0))
+            same = all(np.array_equal(full[0][0], f[0]) and np.array_equal(full[0][1].view(np.uint32), f[1].view(np.uint32)) for f in full[1:])
+            ranks, equal = C.c_int(), C.c_int()
+            hip.check(lib.clm4_sharded_comm_info(ctx, C.byref(ranks), C.byref(equal)))
+        finally:
+            lib.clm4_sharded_destroy(ctx)
+        # shard 0's rows against a plain clm4_mvm of the same (regenerated) rows on device 0 (after the context released its memory)
         A0 = torch.empty(rows * cols // 2, dtype=torch.uint8, device="cuda:0")
         sA0 = torch.empty((rows // 64) * (cols // 64), dtype=torch.float32, device="cuda:0")
         r0 = torch.empty(rows // 2, dtype=torch.uint8, device="cuda:0")
@@ -606,27 +708,36 @@ def one_process_main(args, torch, CloverHip) -> None:
         torch.cuda.synchronize()
         ok0 = bool(np.array_equal(r0.cpu().numpy(), full[0][0][: rows // 2]) and
                    np.array_equal(sr0.cpu().numpy().view(np.uint32), full[0][1][: rows // 64].view(np.uint32)))
-        ranks, equal = C.c_int(), C.c_int()
-        hip.check(lib.clm4_sharded_comm_info(ctx, C.byref(ranks), C.byref(equal)))
-    finally:
-        lib.clm4_sharded_destroy(ctx)
-    ms_per_step = elapsed / args.steps * 1e3
-    kern_avg_ms = max(per_k)
+        del A0, sA0, r0, sr0
+        torch.cuda.empty_cache()
+        return {"rows": rows, "rows_total": rows_total, "elapsed": elapsed, "per_k": per_k, "per_g": per_g, "verified": bool(same and ok0),
+                "rccl_ranks": ranks.value, "settle_launches": settle}
+
+    rows = args.rows_per_gpu
+    h = time_config(rows)
+    rows_total = h["rows_total"]
+    backend = lambda r: "rccl (dlopen, ncclCommInitAll)" if r["rccl_ranks"] else "device copies"       # noqa: E731
+    ms_per_step = h["elapsed"] / args.steps * 1e3
+    kern_avg_ms = max(h["per_k"])
     bytes_total, bytes_gpu = mvm_bytes(rows_total, cols), mvm_bytes(rows, cols)
     achieved = bytes_gpu / (kern_avg_ms * 1e-3) / 1e9
+    degraded = debug or (n > 1 and not h["rccl_ranks"])
     out = {
         "metric": "int4 GEMV (CloverMatrix4::mvm) effective GB/s, algorithmic operand bytes / time",
         "value": round(bytes_total / (ms_per_step * 1e-3) / 1e9, 2), "unit": "GB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int4",
         "data": "synthetic",
+        **({"degraded": True, "degraded_why": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal" if debug else "no RCCL communicator: exchanges are device copies",
+            "value_kernel_only": round(n * achieved, 2)} if degraded else {}),
         "config": {
-            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 ({rows}x{cols} per GPU; preset {args.preset}), x and result CloverVector4, "
+            "workload": f"CloverMatrix4::mvm {rows_total}x{cols} int4 ({rows}x{cols} per GPU; preset {preset}), x and result CloverVector4, "
                         "STOCHASTIC_ROUNDING_DISABLED, bit-exact reference order",
             "rows_per_gpu": rows, "cols": cols, "mode": "one-process",
             "parallelism": f"row-shard x{n}, one process drives all devices (clm4_sharded_mvm_enqueue): grouped in-place ncclAllGather pair per "
                            "step on a second stream per device, overlapped with the next step's kernel",
-            "gathered_result_verified": bool(same and ok0), "rccl_ranks": ranks.value, "backend": "rccl (dlopen, ncclCommInitAll)" if ranks.value else "device copies",
-            "per_rank_kernel_ms": [round(v, 5) for v in per_k], "gather_ms_behind_kernel": [round(v, 5) for v in per_g],
+            "settle_launches": h["settle_launches"], "settle_ms": args.settle_ms,
+            "gathered_result_verified": h["verified"], "rccl_ranks": h["rccl_ranks"], "backend": backend(h),
+            "per_rank_kernel_ms": [round(v, 5) for v in h["per_k"]], "gather_ms_behind_kernel": [round(v, 5) for v in h["per_g"]],
             "gather_bytes_per_rank": rows // 2 + rows // 16,
             **({"DEBUG": "CLOVER_BENCH_DEBUG_ONE_GPU rehearsal: all shards on device 0, exchanges are copies -- not a measurement"} if debug else {}),
             "gflops": round(2.0 * rows_total * cols / (ms_per_step * 1e-3) / 1e9, 1), "algorithmic_bytes_per_step": bytes_total,
@@ -634,11 +745,38 @@ def one_process_main(args, torch, CloverHip) -> None:
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "k_m4_mvm64", "kernel_avg_ms": round(kern_avg_ms, 5), "algorithmic_bytes_per_launch": bytes_gpu},
     }
+    c5_total = int(os.environ.get("CLOVER_BENCH_C5_ROWS", str(1 << 20)))
+    if args.preset is None and not args.no_c5:
+        if c5_total % (64 * n) != 0:
+            out["c5"] = {"skipped": f"{c5_total} rows do not split into {n} equal shards of whole 64-row blocks"}
+        else:
+            c = time_config(c5_total // n)
+            ms5, k5 = c["elapsed"] / args.steps * 1e3, max(c["per_k"])
+            b_tot, b_gpu = mvm_bytes(c5_total, cols), mvm_bytes(c5_total // n, cols)
+            ach5 = b_gpu / (k5 * 1e-3) / 1e9
+            out["c5"] = {
+                "workload": f"CloverMatrix4::mvm {c5_total}x{cols} int4 row-sharded {n} way(s), {c5_total // n} rows per GPU"
+                            + (" = BASELINE configs[4]" if (c5_total, cols) == (1 << 20, 65536) else " (NOT configs[4]: shrunk by CLOVER_BENCH_C5_ROWS / --cols)"),
+                "scaling": "strong", "n_gpus": n, "rows_per_gpu": c5_total // n, "cols": cols, "steps": args.steps, "warmup": args.warmup,
+                "settle_launches": c["settle_launches"], "mode": "one-process",
+                "ms_per_step": round(ms5, 5), "value": round(b_tot / (ms5 * 1e-3) / 1e9, 2), "unit": "GB/s",
+                "frac": round(b_tot / (ms5 * 1e-3) / 1e9 / (n * HBM_PEAK_GBS), 4), "frac_of": f"{n} x {HBM_PEAK_GBS:g} GB/s",
+                "algorithmic_bytes_per_step": b_tot, "algorithmic_bytes_per_launch": b_gpu,
+                "kernel_avg_ms": round(k5, 5), "kernel_frac": round(ach5 / HBM_PEAK_GBS, 4), "kernel_only_aggregate_GBs": round(n * ach5, 2),
+                "per_rank_kernel_ms": [round(v, 5) for v in c["per_k"]], "gather_ms_behind_kernel": [round(v, 5) for v in c["per_g"]],
+                "gather_bytes_per_rank": packed_bytes_of(c5_total // n), "gathered_result_verified": c["verified"],
+                "backend": backend(c), "rccl_ranks": c["rccl_ranks"],
+                **({"degraded": True} if degraded else {}),
+            }
     tr = pmc_traffic(rows, cols)
     if tr:
         out["roofline"]["traffic"] = tr[0]
         out["roofline"]["traffic_source"] = f"profiles/{tr[1]}"
     print(json.dumps(out))
+
+
+def packed_bytes_of(rows: int) -> int:
+    return rows // 2 + rows // 16
 
 
 def gemm_main(args) -> None:

@@ -29,7 +29,7 @@ def test_help_runs_without_a_gpu():
 
 @pytest.mark.gpu
 def test_mvm_line():
-    d = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--rows-per-gpu", "8192", "--cols", "8192", "--cpu-sample-rows", "1024"])
+    d = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--rows-per-gpu", "8192", "--cols", "8192", "--cpu-sample-rows", "1024", "--no-c5"])
     for k in CONTRACT + ("cpu_baseline",):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "GB/s" and d["higher_is_better"] is True
@@ -40,6 +40,8 @@ def test_mvm_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "GB/s" and cb["gpu_result_matches_cpu"] is True
     assert cb["ms_min"] <= cb["ms"] <= cb["ms_max"] and cb["runnable_cpus"] >= 1 and cb["threads_used"] == cb["cores"]
+    assert cb["within_quota"]["GB/s"] > 0 and str(cb["within_quota"]["threads"]) in cb["by_threads"] and cb["value"] >= cb["within_quota"]["GB/s"] * 0.999
+    assert d["ms_per_step_cold"] > 0 and d["config"]["settle_launches"] >= 8
     # the second roofline-bearing object: BASELINE configs[3], normalised to the pipe the kernel runs on
     g = d["gemm"]
     assert g["roofline"]["bound"] == "mfma" and g["roofline"]["peak"] == 10000.0 and abs(g["roofline"]["frac"] - g["value"] / 10000.0) < 1e-3

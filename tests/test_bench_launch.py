@@ -74,7 +74,20 @@ def test_self_launch_builds_the_drivers_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-REHEARSAL = {"CLOVER_BENCH_DEBUG_ONE_GPU": "1"}
+REHEARSAL = {"CLOVER_BENCH_DEBUG_ONE_GPU": "1", "CLOVER_BENCH_C5_ROWS": "16384"}
+
+
+def check_c5(out, n, rows_total=16384, cols=8192):
+    """the object a plain `bench.py --gpus N` adds behind the headline: BASELINE configs[4]'s matrix split N ways (here shrunk)"""
+    c5 = out["c5"]
+    assert c5["scaling"] == "strong" and c5["n_gpus"] == n and c5["rows_per_gpu"] == rows_total // n and c5["cols"] == cols
+    assert c5["algorithmic_bytes_per_step"] == rows_total * cols // 2 + 4 * (rows_total // 64) * (cols // 64) + cols * 9 // 16 + rows_total * 9 // 16
+    assert c5["ms_per_step"] > 0 and c5["value"] > 0 and 0 < c5["frac"] < 1 and 0 < c5["kernel_frac"] < 1
+    assert c5["gather_bytes_per_rank"] == (rows_total // n) * 9 // 16
+    assert ("configs[4]" in c5["workload"]) and (("NOT configs[4]" in c5["workload"]) == ((rows_total, cols) != (1 << 20, 65536)))
+    if n > 1:
+        assert c5["gathered_result_verified"] is True and len(c5["per_rank_kernel_ms"]) == n
+    return c5
 
 
 def check_two_way(out, mode):
@@ -85,6 +98,10 @@ def check_two_way(out, mode):
     assert "rccl_ranks" in cfg and "backend" in cfg and len(cfg["per_rank_kernel_ms"]) == 2
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel_avg_ms"] > 0 and 0 < out["roofline"]["frac"] < 1
     assert out["value"] > 0 and out["ms_per_step"] > 0
+    # a rehearsal is never a measurement: the flag a reader of a scaling curve would look at says so, at top level and in c5
+    assert out["degraded"] is True and out["value_kernel_only"] > 0
+    assert check_c5(out, 2)["degraded"] is True
+    assert cfg["settle_launches"] >= 8
 
 
 @pytest.mark.gpu
@@ -110,11 +127,28 @@ def test_ranks_path_through_rccl_with_one_rank():
     executes on the one-GPU box"""
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", "29733"]
-    out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLOVER_BENCH_FORCE_DIST": "1"}, launcher=launcher))
+    out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLOVER_BENCH_FORCE_DIST": "1", "CLOVER_BENCH_C5_ROWS": "16384"}, launcher=launcher))
     cfg = out["config"]
     assert out["n_gpus"] == 1 and cfg["backend"] == "nccl" and cfg["rccl_ranks"] == 1 and cfg["gathered_result_verified"] is True
     assert cfg["mode"] == "ranks" and "nccl_fallback_reason" not in cfg and "DEBUG" not in cfg
     assert cfg["gather_us_blocking"] > 0 and len(cfg["per_rank_kernel_ms"]) == 1
+    assert "degraded" not in out and "degraded" not in check_c5(out, 1) and out["c5"]["backend"] == "nccl"
+    assert out["ms_per_step_cold"] > 0 and out["roofline"]["kernel_avg_ms_cold"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_failure_falls_back_to_gloo_and_says_degraded():
+    """the branch an 8-GPU run takes when the RCCL group cannot be built, forced: the line still appears, but `degraded` is set at top level
+    and in c5, with the kernel-only aggregate beside the (host-exchange polluted) step time"""
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29735"]
+    out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLOVER_BENCH_FORCE_DIST": "1", "CLOVER_BENCH_FORCE_GLOO_FALLBACK": "1",
+                                                        "CLOVER_BENCH_C5_ROWS": "16384"}, launcher=launcher))
+    cfg = out["config"]
+    assert cfg["backend"] == "gloo" and "CLOVER_BENCH_FORCE_GLOO_FALLBACK" in cfg["nccl_fallback_reason"] and cfg["gathered_result_verified"] is True
+    assert out["degraded"] is True and "RCCL unavailable" in out["degraded_why"] and out["value_kernel_only"] >= out["value"] * 0.5
+    c5 = check_c5(out, 1)
+    assert c5["degraded"] is True and c5["backend"] == "gloo" and c5["kernel_only_aggregate_GBs"] > 0
 
 
 @pytest.mark.gpu
@@ -126,9 +160,11 @@ def test_one_process_rehearsal_two_shards_on_one_gpu():
 @pytest.mark.gpu
 def test_one_process_loop_through_rccl_with_a_communicator_of_one_rank():
     """the enqueue loop's RCCL branch (grouped in-place ncclAllGather pair on the exchange stream) on hardware with one GPU"""
-    out = json_line(run_bench(["--gpus", "1", "--mode", "one-process", *SMALL], {"CLV_SHARDED_RCCL_SELFTEST": "1"}))
+    out = json_line(run_bench(["--gpus", "1", "--mode", "one-process", *SMALL], {"CLV_SHARDED_RCCL_SELFTEST": "1", "CLOVER_BENCH_C5_ROWS": "16384"}))
     assert out["n_gpus"] == 1 and out["config"]["rccl_ranks"] == 1 and out["config"]["gathered_result_verified"] is True
     assert out["config"]["backend"].startswith("rccl")
+    c5 = check_c5(out, 1)
+    assert c5["mode"] == "one-process" and c5["rccl_ranks"] == 1 and c5["gathered_result_verified"] is True and "degraded" not in out
 
 
 @pytest.mark.gpu
@@ -136,4 +172,15 @@ def test_gpus1_preset_c5_weak():
     out = json_line(run_bench(["--gpus", "1", "--preset", "c5-weak", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extras"]))
     assert out["n_gpus"] == 1 and out["config"]["rows_per_gpu"] == 131072 and out["config"]["cols"] == 65536
     assert out["roofline"]["algorithmic_bytes_per_launch"] == 131072 * 65536 // 2 + 4 * 2048 * 1024 + 36864 + 73728
-    assert out["roofline"]["frac"] > 0.5
+    assert out["roofline"]["frac"] > 0.5 and "c5" not in out          # a preset times one configuration
+
+
+@pytest.mark.gpu
+def test_default_line_carries_baseline_config_4():
+    """plain `bench.py --gpus 1 --steps K --warmup W` (what the driver runs): c3 headline with cold + settled figures, and the c5 object =
+    the whole 2^20 x 2^16 matrix (32 GiB) on this one GPU"""
+    out = json_line(run_bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]))
+    assert out["config"]["rows_per_gpu"] == 65536 and out["config"]["settle_launches"] >= 8 and "degraded" not in out
+    assert out["ms_per_step_cold"] >= out["ms_per_step"] * 0.9 and out["value_cold"] > 0
+    c5 = check_c5(out, 1, 1 << 20, 65536)
+    assert c5["algorithmic_bytes_per_step"] == 34427473920 and c5["kernel_frac"] > 0.6
