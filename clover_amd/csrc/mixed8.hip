@@ -641,7 +641,8 @@ extern "C" int clm4_iht_v8(const int8_t *Phi, const float *sPhi, const int8_t *P
     for (uint64_t it = 0; it < iterations; it++) {
         int rc = clm4_mvm_v8_scale_and_add(Phi, sPhi, m, n, x, sx, y, sy, -1.0f, t1, st1, t2, st2, rng_state_dev, stream);      // t1 = Phi x; t2 = y - t1
         if (!rc) rc = clm4_mvm_v8_scale_and_add(PhiT, sPhiT, n, m, t2, st2, x, sx, mu, t3, st3, x, sx, rng_state_dev, stream);  // t3 = Phi' t2; x += mu t3
-        if (!rc && threshold) rc = clv8_threshold(x, sx, x_len, n, K, nullptr, stream);                                        // keep the K largest
+        if (!rc && threshold)                                                                    // keep the K largest (2: the reference's survivor order)
+            rc = clv8_threshold_mode(x, sx, x_len, n, K, threshold == 2 ? CLV_THRESHOLD_REFERENCE : CLV_THRESHOLD_FAST, nullptr, stream);
         if (rc) return rc;
     }
     return CLV_OK;

@@ -1145,6 +1145,204 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
     return threshold4_large((uint32_t *)q, s, n, n_pad, k, workspace, st);
 }
 
+// =================================================================================================
+// f3'  threshold in the REFERENCE's survivor order (CLV_THRESHOLD_REFERENCE): the min-heap walk of CloverVector4.h:1927-1972 /
+//      CloverVector8.h:1680-1740 with the heap helpers of CloverBase.h:208-249 (std::make_heap under gt_idx_t = libstdc++'s bottom-up
+//      __adjust_heap; min_heapify with left-first ties) reproduced step by step.  Which of several EQUAL magnitudes survive is decided by
+//      where they sit in the heap when a larger value arrives, i.e. by the whole history: the walk is sequential by definition, like the
+//      16 fma chains of dot EXACT.  One wavefront runs it: the heap lives in LDS (k <= 16384 entries of {value, index}; beyond that in
+//      global memory), lane 0 writes, all lanes read (same-address broadcast); the stream of the n - k later elements is taken 64 at a
+//      time and a ballot against the current root skips every chunk -- or chunk remainder -- that cannot enter the heap (the root only
+//      grows), so only the inserts cost a sift (one LDS round trip per level).  Around it: a parallel pass that writes |value| per element
+//      (the same expression as CloverVector4::get / CloverVector8::get) and a parallel pass that clears every nibble / byte whose index
+//      is not in the final heap.  Cost: ~1 us per insert (log2 k dependent LDS reads): N = 8192, K = 1024 about 1 ms -- an opt-in
+//      exactness mode, the radix select above stays the default.
+// =================================================================================================
+#define THR_LDS_ENTRIES 16384u
+
+template <int BITS>
+__global__ __launch_bounds__(256) void k_thr_ref_keys(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n, float *__restrict__ vals,
+                                                      uint32_t *__restrict__ keep, uint64_t keep_words)
+{
+    typedef ThreshElems<BITS> E;
+    const uint64_t nwords = (n + E::EPW - 1) / E::EPW, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint32_t w = q[i];
+        const float sc = s[i / E::WPB];
+#pragma unroll
+        for (int e = 0; e < E::EPW; e++)
+            if (i * E::EPW + e < n) vals[i * E::EPW + e] = __uint_as_float(E::key(w, e, sc));
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < keep_words; i += stride) keep[i] = 0;
+}
+
+struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global memory read past the vector L1 (lane 0 writes, every lane reads)
+    template <bool IN_LDS> __device__ static __forceinline__ uint2 ld(const uint2 *h, uint32_t i)
+    {
+        if (IN_LDS) return h[i];
+        const unsigned long long v = __hip_atomic_load((const unsigned long long *)(h + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    }
+    template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *h, uint32_t i, uint2 v)
+    {
+        if (threadIdx.x != 0) return;
+        if (IN_LDS) h[i] = v;
+        else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+#define THR_VAL(e) __uint_as_float((e).x)
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ vals, uint32_t n, uint32_t k, uint2 *__restrict__ gheap,
+                                                     uint32_t *__restrict__ keep)
+{
+    extern __shared__ __attribute__((aligned(16))) uint2 thr_lheap[];
+    uint2 *h = IN_LDS ? thr_lheap : gheap;
+    const uint32_t lane = threadIdx.x;
+    // "Copy the first K-elements" (CloverVector4.h:1933-1940)
+    for (uint32_t i = lane; i < k; i += 64) {
+        const uint2 e = make_uint2(__float_as_uint(vals[i]), i);
+        if (IN_LDS) h[i] = e;
+        else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)e.x | ((unsigned long long)e.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // std::make_heap(min_heap, min_heap + k, gt_idx_t) (:1944): libstdc++ __make_heap = __adjust_heap(first, parent, len, value) for
+    // parent = (len - 2) / 2 ... 0, comp(a, b) = a.value > b.value
+    if (k >= 2) {
+        for (uint32_t parent = (k - 2) / 2 + 1; parent-- > 0;) {
+            const uint2 v = ThrHeap::ld<IN_LDS>(h, parent);
+            const uint32_t top = parent;
+            uint32_t hole = parent, child = parent;
+            while (child < (k - 1) / 2) {
+                child = 2 * (child + 1);
+                uint2 a = ThrHeap::ld<IN_LDS>(h, child);
+                const uint2 b = ThrHeap::ld<IN_LDS>(h, child - 1);
+                if (THR_VAL(a) > THR_VAL(b)) { child--; a = b; }           // comp(first + child, first + (child - 1))
+                ThrHeap::st<IN_LDS>(h, hole, a);
+                hole = child;
+            }
+            if ((k & 1) == 0 && child == (k - 2) / 2) {
+                child = 2 * (child + 1);
+                ThrHeap::st<IN_LDS>(h, hole, ThrHeap::ld<IN_LDS>(h, child - 1));
+                hole = child - 1;
+            }
+            while (hole > top) {                                           // __push_heap
+                const uint32_t par = (hole - 1) / 2;
+                const uint2 pe = ThrHeap::ld<IN_LDS>(h, par);
+                if (!(THR_VAL(pe) > THR_VAL(v))) break;                    // comp(first + parent, value)
+                ThrHeap::st<IN_LDS>(h, hole, pe);
+                hole = par;
+            }
+            ThrHeap::st<IN_LDS>(h, hole, v);
+        }
+    }
+    // the walk over elements k ... n-1 (:1952-1962): strictly larger than the root -> replace the root, min_heapify(0)
+    float root = THR_VAL(ThrHeap::ld<IN_LDS>(h, 0));
+    float vnext = (k + lane < n) ? vals[k + lane] : -1.0f;
+    for (uint32_t base = k; base < n; base += 64) {
+        const float v = vnext;
+        const uint32_t nb = base + 64 + lane;
+        vnext = (base + 64 < n && nb < n) ? vals[nb] : -1.0f;             // |value| >= 0: -1 never enters
+        unsigned long long mask = __ballot(v > root);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            const uint2 m = make_uint2(__float_as_uint(__shfl(v, j)), base + (uint32_t)j);
+            // min_heapify(heap, 0, k) with heap[0] = m (CloverBase.h:226-249): the smaller child moves up while it is smaller than m,
+            // the LEFT child on equal children
+            uint32_t pos = 0;
+            float new_root = THR_VAL(m);
+            for (;;) {
+                const uint32_t l = 2 * pos + 1, r = l + 1;
+                if (l >= k) break;
+                const uint2 cl = ThrHeap::ld<IN_LDS>(h, l);
+                const uint2 cr = ThrHeap::ld<IN_LDS>(h, r < k ? r : l);
+                uint32_t smallest = pos;
+                float sv = THR_VAL(m);
+                uint2 ce = cl;
+                if (THR_VAL(cl) < sv) { smallest = l; sv = THR_VAL(cl); }
+                if (r < k && THR_VAL(cr) < sv) { smallest = r; ce = cr; }
+                if (smallest == pos) break;
+                ThrHeap::st<IN_LDS>(h, pos, ce);
+                if (pos == 0) new_root = THR_VAL(ce);
+                pos = smallest;
+            }
+            ThrHeap::st<IN_LDS>(h, pos, m);
+            root = new_root;
+            mask = __ballot(v > root) & ~((2ull << j) - 1ull);             // later lanes of this chunk, against the new root
+        }
+    }
+    __syncthreads();
+    // "Only copy the max K elements" (:1966-1969): the indices left in the heap survive
+    for (uint32_t i = lane; i < k; i += 64) {
+        const uint32_t idx = ThrHeap::ld<IN_LDS>(h, i).y;
+        atomicOr(&keep[idx >> 5], 1u << (idx & 31));
+    }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void k_thr_ref_apply(uint32_t *__restrict__ q, uint64_t n, const uint32_t *__restrict__ keep)
+{
+    typedef ThreshElems<BITS> E;
+    const uint64_t nwords = (n + E::EPW - 1) / E::EPW, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint64_t e0 = i * E::EPW;
+        const uint32_t bits = keep[e0 >> 5] >> (e0 & 31);                 // EPW divides 32: the word's bits sit in one bitmap word
+        uint32_t w = q[i];
+#pragma unroll
+        for (int e = 0; e < E::EPW; e++)
+            if (e0 + e < n && !((bits >> e) & 1u)) w &= ~E::mask(e);       // setBits(i, 0) for i < length only (:1939, 1961)
+        q[i] = w;
+    }
+}
+
+extern "C" uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad)
+{
+    // [|value| per element: 4 n][survivor bitmap: n / 8][heap when k > 16384: 8 n] + alignment slack
+    return n_pad * 4 + ((n_pad / 8 + 255) & ~255ull) + n_pad * 8 + 512;
+}
+
+template <int BITS>
+static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, hipStream_t st)
+{
+    if (k == 0) {                                                          // nothing survives (the oracle's reading of k = 0)
+        CLV_HIP(hipMemsetAsync(q, 0, (n + ThreshElems<BITS>::EPW - 1) / ThreshElems<BITS>::EPW * 4, st));
+        return CLV_OK;
+    }
+    if (!workspace) {
+        int rc = clv_internal_workspace(&workspace, clv_threshold_reference_workspace_bytes(n_pad), st);
+        if (rc) return rc;
+    }
+    float *vals = (float *)workspace;
+    uint32_t *keep = (uint32_t *)((char *)workspace + n_pad * 4);
+    uint2 *gheap = (uint2 *)((char *)keep + ((n_pad / 8 + 255) & ~255ull));
+    const uint64_t keep_words = (n + 31) / 32;
+    const uint64_t nwords = (n + ThreshElems<BITS>::EPW - 1) / ThreshElems<BITS>::EPW;
+    const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+    const dim3 grid((unsigned)(want < cap ? want : cap));
+    hipLaunchKernelGGL(k_thr_ref_keys<BITS>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, vals, keep, keep_words);
+    if (k <= THR_LDS_ENTRIES) {
+        const size_t lds = (size_t)k * sizeof(uint2);
+        if (lds > 64 * 1024) CLV_HIP(hipFuncSetAttribute((const void *)k_thr_ref_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_thr_ref_walk<true>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
+    } else {
+        hipLaunchKernelGGL(k_thr_ref_walk<false>, dim3(1), dim3(64), 0, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
+    }
+    hipLaunchKernelGGL(k_thr_ref_apply<BITS>, grid, dim3(256), 0, st, q, n, keep);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+extern "C" int clv4_threshold_mode(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, int mode, void *workspace, void *stream)
+{
+    if (mode == CLV_THRESHOLD_FAST) return clv4_threshold(q, s, n, n_pad, k, workspace, stream);
+    CLV_REQUIRE(mode == CLV_THRESHOLD_REFERENCE, "clv4_threshold_mode: unknown mode %d", mode);
+    CLV_REQUIRE(q && s, "clv4_threshold_mode: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0 && n <= n_pad, "clv4_threshold_mode: n=%llu n_pad=%llu", (unsigned long long)n, (unsigned long long)n_pad);
+    CLV_REQUIRE(n < (1ull << 32), "clv4_threshold_mode: vectors of 2^32 or more elements are not supported");
+    if (k >= n || n == 0) return CLV_OK;
+    return threshold_reference<4>((uint32_t *)q, s, n, n_pad, k, workspace, as_stream(stream));
+}
+
 // CloverVector8::threshold(K) (CloverVector8.h:1680-1740): same algorithm and tie rule on |q * scale / 127|
 extern "C" int clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream)
 {
@@ -1171,6 +1369,17 @@ extern "C" int clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
     return threshold_large<8>((uint32_t *)q, s, n, k, workspace, st);
 }
 
+extern "C" int clv8_threshold_mode(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, int mode, void *workspace, void *stream)
+{
+    if (mode == CLV_THRESHOLD_FAST) return clv8_threshold(q, s, n, n_pad, k, workspace, stream);
+    CLV_REQUIRE(mode == CLV_THRESHOLD_REFERENCE, "clv8_threshold_mode: unknown mode %d", mode);
+    CLV_REQUIRE(q && s, "clv8_threshold_mode: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0 && n <= n_pad, "clv8_threshold_mode: n=%llu n_pad=%llu", (unsigned long long)n, (unsigned long long)n_pad);
+    CLV_REQUIRE(n < (1ull << 32), "clv8_threshold_mode: vectors of 2^32 or more elements are not supported");
+    if (k >= n || n == 0) return CLV_OK;
+    return threshold_reference<8>((uint32_t *)q, s, n, n_pad, k, workspace, as_stream(stream));
+}
+
 // =================================================================================================
 // f4  The application loops that call the hot path: quantized Iterative Hard Thresholding / Gradient Descent
 //     (test/performance/01_measure.h:923-946, 999-1021).  One call enqueues all iterations on the stream; nothing
@@ -1190,7 +1399,8 @@ static int iht_iteration(const int8_t *Phi, const float *sPhi, const int8_t *Phi
     // each scaleAndAdd rides in the epilogue of the mvm before it (same bits, same XORShift positions): 3 launches, not 5
     int rc = clm4_mvm_scale_and_add(Phi, sPhi, m, n, x, sx, y, sy, -1.0f, t1, st1, t2, st2, rng, stream);     // t1 = Phi * x; t2 = y - t1
     if (!rc) rc = clm4_mvm_scale_and_add(PhiT, sPhiT, n, m, t2, st2, x, sx, mu, t3, st3, x, sx, rng, stream); // t3 = Phi' * t2; x += mu * t3
-    if (!rc && threshold) rc = clv4_threshold(x, sx, x_len, n, K, nullptr, stream);         // keep the K largest
+    if (!rc && threshold)                                                                    // keep the K largest (2: in the reference's survivor order)
+        rc = clv4_threshold_mode(x, sx, x_len, n, K, threshold == 2 ? CLV_THRESHOLD_REFERENCE : CLV_THRESHOLD_FAST, nullptr, stream);
     return rc;
 }
 

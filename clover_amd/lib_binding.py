@@ -13,6 +13,8 @@ from .build import hip_library_path
 
 DOT_EXACT = 0
 DOT_FAST = 1
+THRESHOLD_FAST = 0          # radix select, lowest-index ties
+THRESHOLD_REFERENCE = 1     # the reference's survivor set (its min-heap walk, CloverVector4.h:1927-1972)
 
 _vp = C.c_void_p
 _u64 = C.c_uint64
@@ -68,6 +70,7 @@ SIGNATURES = {
     "clv8_scale_and_add": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, _u64, _vp, _vp, _vp, _vp]),
     "clv8_threshold_workspace_bytes": (_u64, [_u64]),
     "clv8_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
+    "clv8_threshold_mode": (C.c_int, [_vp, _vp, _u64, _u64, _u64, C.c_int, _vp, _vp]),
     "clm4_mvm_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clm4_mvm_v8_scale_and_add": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clm4_iht_v8": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, C.c_float,
@@ -75,6 +78,8 @@ SIGNATURES = {
     "clm4_rowdots_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clv4_threshold_workspace_bytes": (_u64, [_u64]),
     "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
+    "clv_threshold_reference_workspace_bytes": (_u64, [_u64]),
+    "clv4_threshold_mode": (C.c_int, [_vp, _vp, _u64, _u64, _u64, C.c_int, _vp, _vp]),
     "clm4_transpose": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "clm4_mvm_f32": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "clm4_iht": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64,
@@ -306,9 +311,9 @@ class CloverHip:
         self.check(self.lib.clv8_scale_and_add(b[0].ptr, b[1].ptr, b[2].ptr, b[3].ptr, a, n, dr.ptr, dsr.ptr, rng.ptr if rng else None, None))
         return dr.download(np.int8, n), dsr.download(np.float32, n // 64)
 
-    def v8_threshold(self, q, s, n: int, k: int) -> np.ndarray:
+    def v8_threshold(self, q, s, n: int, k: int, mode: int = THRESHOLD_FAST) -> np.ndarray:
         dq, ds = self.to_device(q), self.to_device(s)
-        self.check(self.lib.clv8_threshold(dq.ptr, ds.ptr, n, q.size, k, None, None))
+        self.check(self.lib.clv8_threshold_mode(dq.ptr, ds.ptr, n, q.size, k, mode, None, None))
         return dq.download(np.int8, q.size)
 
     def m4_mvm_v8(self, qA, sA, rows, cols, qx, sx, rng: DevBuf | None = None):
@@ -323,9 +328,9 @@ class CloverHip:
         self.check(self.lib.clm4_rowdots_v8(b[0].ptr, b[1].ptr, rows, cols, b[2].ptr, b[3].ptr, d.ptr, None))
         return d.download(np.float32, rows)
 
-    def v4_threshold(self, q, s, n: int, k: int) -> np.ndarray:
+    def v4_threshold(self, q, s, n: int, k: int, mode: int = THRESHOLD_FAST) -> np.ndarray:
         dq, ds = self.to_device(q), self.to_device(s)
-        self.check(self.lib.clv4_threshold(dq.ptr, ds.ptr, n, q.size * 2, k, None, None))
+        self.check(self.lib.clv4_threshold_mode(dq.ptr, ds.ptr, n, q.size * 2, k, mode, None, None))
         return dq.download(np.uint8, q.size)
 
     def m4_transpose(self, q, s, rows, cols):

@@ -246,7 +246,7 @@ public:
     /* keep the k largest magnitudes, zero the rest (CloverVector4.h:1913-2060) */
     void threshold(uint64_t k)
     {
-        clover_hip::check(clv4_threshold(dev_values_rw(), dev_scales_ro(), length, length_pad, k, nullptr, nullptr), "CloverVector4::threshold");
+        clover_hip::check(clv4_threshold_mode(dev_values_rw(), dev_scales_ro(), length, length_pad, k, clover_hip::threshold_mode(), nullptr, nullptr), "CloverVector4::threshold");
         commit();
     }
     void threshold_parallel(uint64_t k) { threshold(k); }

@@ -180,7 +180,7 @@ public:
     /* keep the k largest magnitudes, zero the rest (CloverVector8.h:1680-1740) */
     void threshold(uint64_t k)
     {
-        clover_hip::check(clv8_threshold(dev_values_rw(), dev_scales_ro(), length, length_pad, k, nullptr, nullptr), "CloverVector8::threshold");
+        clover_hip::check(clv8_threshold_mode(dev_values_rw(), dev_scales_ro(), length, length_pad, k, clover_hip::threshold_mode(), nullptr, nullptr), "CloverVector8::threshold");
         commit();
     }
     void threshold_parallel(uint64_t k) { threshold(k); }

@@ -84,6 +84,25 @@ inline void check(int rc, const char *what)
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return v % m ? v + m - (v % m) : v; }
 
+/* Tie rule of CloverVector4 / CloverVector8 ::threshold (clover_hip.h: CLV_THRESHOLD_FAST / CLV_THRESHOLD_REFERENCE).  Default FAST (radix
+ * select, lowest-index ties); REFERENCE reproduces the reference's survivor set index for index (its min-heap walk, about 1 us per heap
+ * insert).  Chosen, in this order, by set_threshold_mode(), -DCLOVER_THRESHOLD_REFERENCE at compile time, or CLV_THRESHOLD_REFERENCE=1 in
+ * the environment at first use. */
+inline int &threshold_mode_slot()
+{
+#ifdef CLOVER_THRESHOLD_REFERENCE
+    static int mode = CLV_THRESHOLD_REFERENCE;
+#else
+    static int mode = [] {
+        const char *e = getenv("CLV_THRESHOLD_REFERENCE");
+        return (e && e[0] && e[0] != '0') ? CLV_THRESHOLD_REFERENCE : CLV_THRESHOLD_FAST;
+    }();
+#endif
+    return mode;
+}
+inline int threshold_mode() { return threshold_mode_slot(); }
+inline void set_threshold_mode(int mode) { threshold_mode_slot() = mode; }
+
 class Mirror;
 
 namespace detail {

@@ -196,6 +196,7 @@ int  clv8_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, con
                         int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
 uint64_t clv8_threshold_workspace_bytes(uint64_t n_pad);
 int  clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream);
+int  clv8_threshold_mode(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, int mode, void *workspace, void *stream);
 /* CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &) (CloverMatrix4.h:1093-1441; _parallel :2017-2387):
  * x: cols int8 + cols/64 scales; r: rows int8 + rows/64 scales (re-quantised to 8 bits).  Bit-identical to the
  * reference's SIMD path (8 fp32 fma chains per row) for either rounding mode. */
@@ -220,6 +221,19 @@ int  clm4_rowdots_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t c
  * among EQUAL magnitudes the lowest indices survive (the reference's choice depends on its heap order). */
 uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad);
 int  clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream);
+/* The same with the tie rule chosen by `mode` (the threshold counterpart of clv4_dot's CLV_DOT_EXACT / CLV_DOT_FAST):
+ *   CLV_THRESHOLD_FAST       radix select, lowest-index ties (= clv4_threshold; bandwidth-bound);
+ *   CLV_THRESHOLD_REFERENCE  the reference's survivor SET, index for index: its K-entry min-heap walk (CloverVector4.h:1927-1972,
+ *                            std::make_heap under gt_idx_t + min_heapify, CloverBase.h:208-249) is reproduced step by step by one
+ *                            wavefront with the heap in LDS.  Sequential by definition (which of several equal magnitudes survive
+ *                            depends on the whole insertion history): about 1 us per heap insert -- N = 8192, K = 1024 roughly
+ *                            1 ms -- so it is opt-in, for runs that must follow the reference's Q_IHT trajectory exactly.
+ * `workspace` (NULL = library scratch of the stream) needs clv_threshold_reference_workspace_bytes(n_pad) in REFERENCE mode.
+ * clm4_iht / clm4_iht_v8 take threshold = 2 for this mode (1 = FAST, 0 = no threshold: Q_GD). */
+#define CLV_THRESHOLD_FAST 0
+#define CLV_THRESHOLD_REFERENCE 1
+uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad);
+int  clv4_threshold_mode(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, int mode, void *workspace, void *stream);
 /* CloverMatrix4::transpose (CloverMatrix4.h:1549-1663; _parallel :2508-2640): qt(j,i) = q(i,j), tile scales
  * transposed.  q is rows x cols, qt is cols x rows.  Exact. */
 int  clm4_transpose(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, int8_t *qt, float *st, void *stream);

@@ -239,6 +239,9 @@ def test_gpu_v8_threshold_top_k(hip, oracle, case):
     mags = np.abs((q.astype(np.float32) * np.repeat(s, 64)) / np.float32(127.0))[:n]
     assert np.array_equal(np.sort(mags[out[:n] != 0]), np.sort(mags[ref[:n] != 0]))
     assert same(hip.v8_threshold(out, s, n, k), out)          # idempotent
+    if n <= 32768 + 128:                                       # REFERENCE mode: the reference's survivor set, byte for byte (CloverVector8.h:1680-1740)
+        from clover_amd.lib_binding import THRESHOLD_REFERENCE
+        assert same(hip.v8_threshold(q, s, n, k, mode=THRESHOLD_REFERENCE), ref)
 
 
 @pytest.mark.gpu

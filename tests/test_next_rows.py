@@ -2,9 +2,10 @@
 
 CPU part: the oracle's restatements against independent formulations.  GPU part (-m gpu): HIP vs oracle,
 bit-exact for scaleAndAdd and transpose (the reference's own tests are exact there, 02_vector.cpp:341-447,
-03_matrix.cpp:153-246); threshold compares the surviving multiset of magnitudes (the reference's test is a
+03_matrix.cpp:153-246); threshold in FAST mode compares the surviving multiset of magnitudes (the reference's test is a
 10 % tolerance on sorted magnitudes, 02_vector.cpp:449-498; tie-breaking among equal magnitudes is heap-order
-dependent in the reference and lowest-index-first here)."""
+dependent in the reference and lowest-index-first in FAST mode), and in REFERENCE mode the whole output nibble for nibble
+against the oracle's walk of the reference's min-heap (CloverVector4.h:1927-1972, CloverBase.h:208-249)."""
 import subprocess
 from pathlib import Path
 
@@ -12,6 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import bits, random_packed
+from clover_amd.lib_binding import THRESHOLD_REFERENCE
 
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -150,9 +152,38 @@ def test_gpu_threshold_top_k(hip, oracle, case):
         n_keep = k - int((mags > tau).sum())
         if tau > 0:
             assert np.array_equal(np.flatnonzero(kept & (mags == tau)), tie_idx[:n_keep])
-    assert same(out, _threshold_lowest_index(oracle, q, s, n, k))   # the whole output, bit for bit, under the lowest-index tie rule
+    # FAST mode's own tie rule (lowest index), restated on the CPU: documents WHICH ties FAST keeps -- not a reference comparison
+    assert same(out, _threshold_lowest_index(oracle, q, s, n, k))
     again = hip.v4_threshold(out, s, n, k)                    # idempotent
     assert same(again, out)
+    # REFERENCE mode: the reference's survivor set, nibble for nibble, against the oracle's heap walk (CloverVector4.h:1927-1972)
+    if n <= 131072 + 128:
+        assert same(hip.v4_threshold(q, s, n, k, mode=THRESHOLD_REFERENCE), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(128, 128, 1), (128, 128, 127), (130, 256, 64), (1000, 1024, 250), (8192, 8192, 1024), (8192, 8192, 2048),
+                                  (16384, 16384, 2048), (65536, 65536, 8192), (131072, 131072, 16384), (40000, 40064, 16385),
+                                  (65536, 65536, 40000), (5000, 5120, 4999), (777, 896, 2), (4096, 4096, 4095)])
+@pytest.mark.parametrize("data", ["ints40", "ties", "distinct"])
+def test_gpu_threshold_reference_order(hip, oracle, case, data):
+    """CLV_THRESHOLD_REFERENCE: index-identical to the reference's min-heap walk (make_heap over the first k, strict > against the
+    root, min_heapify with left-first ties) -- LDS heap for k <= 16384, global-memory heap beyond.  `ties`: three magnitudes only
+    (almost everything ties at tau); `distinct`: per-block scales make nearly all magnitudes different."""
+    n, npad, k = case
+    rng = np.random.default_rng(7 * n + k + len(data))
+    x = np.zeros(npad, np.float32)
+    if data == "ints40":
+        x[:n] = rng.integers(-40, 41, size=n)
+    elif data == "ties":
+        x[:n] = rng.choice(np.array([-7, -3, 0, 3, 7], np.float32), size=n)
+    else:
+        x[:n] = rng.normal(size=n) * np.repeat(rng.uniform(0.1, 10, size=npad // 64), 64)[:n]
+    q, s = oracle.v4_quantize(x)
+    ref = oracle.v4_threshold(q, s, n, k)
+    out = hip.v4_threshold(q, s, n, k, mode=THRESHOLD_REFERENCE)
+    assert same(out, ref)
+    assert int((nibbles(out)[:n] != 0).sum()) <= k and np.array_equal(nibbles(out)[n:], nibbles(q)[n:])
 
 
 def _threshold_lowest_index(oracle, q, s, n, k):
@@ -169,7 +200,7 @@ def _threshold_lowest_index(oracle, q, s, n, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["iht_stream", "iht_plain", "gd_stream"])
+@pytest.mark.parametrize("mode", ["iht_stream", "iht_plain", "gd_stream", "iht_reference"])
 def test_gpu_iht_loop_matches_oracle_loop(hip, oracle, mode):
     """clm4_iht = Q_IHT / Q_GD of the reference (01_measure.h:923-946, 999-1021) on the device (own stream or the
     default stream), against the same step sequence evaluated with the oracle."""
@@ -186,7 +217,7 @@ def test_gpu_iht_loop_matches_oracle_loop(hip, oracle, mode):
     stream = C.c_void_p()
     if mode != "iht_plain":
         hip.check(hip.lib.clv_stream_create(C.byref(stream)))
-    thr = 0 if mode.startswith("gd") else 1
+    thr = 0 if mode.startswith("gd") else (2 if mode == "iht_reference" else 1)      # 2: threshold in the reference's survivor order
     hip.check(hip.lib.clm4_iht(d["Phi"].ptr, d["sPhi"].ptr, d["PhiT"].ptr, d["sPhiT"].ptr, m, n, bufs["x"].ptr, bufs["sx"].ptr, n,
                                d["y"].ptr, d["sy"].ptr, bufs["t1"].ptr, bufs["st1"].ptr, bufs["t2"].ptr, bufs["st2"].ptr,
                                bufs["t3"].ptr, bufs["st3"].ptr, iters, K, float(mu), thr, None, stream))
@@ -199,7 +230,9 @@ def test_gpu_iht_loop_matches_oracle_loop(hip, oracle, mode):
         t2 = oracle.v4_scale_and_add(*y, *t1, -1.0)
         t3 = oracle.m4_mvm(qT, sT, n, m, *t2)
         x = oracle.v4_scale_and_add(*x, *t3, float(mu))
-        if thr:
+        if thr == 2:                                    # the oracle's heap walk = the reference's threshold: the reference's trajectory
+            x = (oracle.v4_threshold(x[0], x[1], n, K), x[1])
+        elif thr:
             x = (_threshold_lowest_index(oracle, x[0], x[1], n, K), x[1])
     assert same(xq, x[0]) and same(xs, x[1])
     if stream:

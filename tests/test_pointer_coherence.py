@@ -96,10 +96,10 @@ def test_kept_pointers_and_views_behave_like_the_reference(tmp_path):
     assert us < 200.0
 
 
-def _build_validate(tmp_path):
-    exe = tmp_path / "validate_relations"
+def _build_validate(tmp_path, name="validate_relations"):
+    exe = tmp_path / name
     subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}",
-                    str(CPP / "validate_relations.cpp"), "-o", str(exe), *_link_flags()], check=True)
+                    str(CPP / f"{name}.cpp"), "-o", str(exe), *_link_flags()], check=True)
     return exe
 
 
@@ -113,3 +113,17 @@ def test_device_methods_against_their_scalar_twins_like_the_reference_harness(tm
     """test/validate/02_vector.cpp + 03_matrix.cpp: kernel vs `_scalar` host twin (include/clover_scalar.h), exact where the reference is exact"""
     p = subprocess.run([str(_build_validate(tmp_path))], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "validate ok" in p.stdout, (p.returncode, p.stdout[-3000:], p.stderr[-1000:])
+
+
+def test_validation_grid_client_builds(tmp_path):
+    p = subprocess.run([str(_build_validate(tmp_path, "validate_grid"))], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and ("no_device" in p.stdout or "validate grid ok" in p.stdout), (p.returncode, p.stdout[-2000:], p.stderr)
+
+
+@pytest.mark.gpu
+def test_reference_validation_grid_at_full_density(tmp_path):
+    """the reference's own grid, not a sample of it: every n = 128 ... 2047 (test/validate/02_vector.cpp:111-553) and every
+    (128 i) x (128 j), i, j = 1 ... 10 (03_matrix.cpp:38-573), same relations and strictness"""
+    p = subprocess.run([str(_build_validate(tmp_path, "validate_grid"))], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and "validate grid ok" in p.stdout, (p.returncode, p.stdout[-3000:], p.stderr[-1000:])
+    print(p.stdout.strip().splitlines()[-2])
