@@ -32,6 +32,11 @@ public:
     uint64_t getBitsLength() const { return 32; }
     uint64_t getBytes() const { return rows * cols * sizeof(float); }
 
+    /* Explicit residency (clover_device.h, -DCLOVER_HIP_EXPLICIT_SYNC): move the bytes NOW instead of at the next use.  toDevice(): upload
+     * if the host copy is the newer one; toHost(): bring a device result back.  Optional in every build (the default build's page tracking
+     * and all accessors synchronise by themselves); not in the reference, which has one copy. */
+    void toDevice() const { (void)mem.dev_ro(); }
+    void toHost() const { (void)mem.host_ro(); }
     float *getData() const { return reinterpret_cast<float *>(mem.host_ptr()); }      /* stays valid and current (clover_device.h) */
     float get(uint64_t i, uint64_t j) const { return reinterpret_cast<const float *>(mem.host_ro())[i * cols + j]; }
     void set(uint64_t i, uint64_t j, float v) { reinterpret_cast<float *>(mem.host_rw())[i * cols + j] = v; }

@@ -60,6 +60,11 @@ public:
     uint64_t getBitsLength() const { return 4; }
     uint64_t getBytes() const { return value_bytes + (rows >> 6) * (cols >> 6) * sizeof(float); }
 
+    /* Explicit residency (clover_device.h, -DCLOVER_HIP_EXPLICIT_SYNC): move the bytes NOW instead of at the next use.  toDevice(): upload
+     * if the host copy is the newer one; toHost(): bring a device result back.  Optional in every build (the default build's page tracking
+     * and all accessors synchronise by themselves); not in the reference, which has one copy. */
+    void toDevice() const { (void)mem.dev_ro(); }
+    void toHost() const { (void)mem.host_ro(); }
     /* host views of the packed values and of the tile scales (the reference keeps them protected; exposed for interop) */
     int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_ptr()); }
     float *getScales() const { return reinterpret_cast<float *>(mem.host_ptr() + value_bytes); }

@@ -51,6 +51,11 @@ public:
     float get(uint64_t i) const { return reinterpret_cast<const float *>(mem.host_ro())[i]; }
     float getAbs(uint64_t i) const { float v = get(i); return v < 0 ? -v : v; }
     void set(uint64_t i, float v) { reinterpret_cast<float *>(mem.host_rw())[i] = v; }
+    /* Explicit residency (clover_device.h, -DCLOVER_HIP_EXPLICIT_SYNC): move the bytes NOW instead of at the next use.  toDevice(): upload
+     * if the host copy is the newer one; toHost(): bring a device result back.  Optional in every build (the default build's page tracking
+     * and all accessors synchronise by themselves); not in the reference, which has one copy. */
+    void toDevice() const { (void)mem.dev_ro(); }
+    void toHost() const { (void)mem.host_ro(); }
     float *getData() const { return reinterpret_cast<float *>(mem.host_ptr()); }      /* stays valid and current, see clover_device.h */
 
     void clear() { memset(mem.host_rw(), 0, length_pad * sizeof(float)); }

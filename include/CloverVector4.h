@@ -86,6 +86,11 @@ public:
     uint64_t getBitsLength() const { return 4; }
     uint64_t getBytes() const { return length_pad / 2 + (length_pad / 64) * sizeof(float); }
 
+    /* Explicit residency (clover_device.h, -DCLOVER_HIP_EXPLICIT_SYNC): move the bytes NOW instead of at the next use.  toDevice(): upload
+     * if the host copy is the newer one; toHost(): bring a device result back.  Optional in every build (the default build's page tracking
+     * and all accessors synchronise by themselves); not in the reference, which has one copy. */
+    void toDevice() const { (void)mem.dev_ro(); if (split_view) (void)view_scales.dev_ro(); }
+    void toHost() const { (void)mem.host_ro(); if (split_view) (void)view_scales.host_ro(); }
     /* Raw pointers as in the reference (:229-237): valid for the life of the object and always current -- reads through a
      * kept pointer see the results of later device operations, writes through it reach the next one (clover_device.h). */
     int8_t *getData() const { return reinterpret_cast<int8_t *>(mem.host_ptr()); }

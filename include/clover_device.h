@@ -34,9 +34,21 @@
  * Limits, all loud rather than silent: a system call given a pointer into a DEVICE_DIRTY block returns EFAULT instead of faulting, and
  * a HIP runtime call given such a pointer faults inside the runtime, where the helper's copy may need a lock the faulting thread
  * holds (use the accessors or touch the memory first -- the containers do that for their own copies, detail::touch_for_*);
- * debuggers stop on the resolved SIGSEGVs (gdb: `handle SIGSEGV nostop noprint`).  Building with -DCLOVER_HIP_NO_PAGE_TRACKING
- * disables all of it: getData() then conservatively invalidates the device copy, and a pointer kept across a device operation is
- * stale (the round-1 behaviour).
+ * debuggers stop on the resolved SIGSEGVs (gdb: `handle SIGSEGV nostop noprint`); fork(): tracked blocks are MAP_SHARED memory files, so a
+ * child shares them with its parent instead of getting copy-on-write pages, and it has no helper thread -- a child must not touch the
+ * parent's containers (exec or _exit).
+ *
+ * EXPLICIT RESIDENCY (-DCLOVER_HIP_EXPLICIT_SYNC; the older spelling -DCLOVER_HIP_NO_PAGE_TRACKING is the same switch).  For hosts that
+ * own SIGSEGV themselves (a JVM, sanitizers, a debugger session) or must fork freely: NO signal handler is installed, NO page is ever
+ * protected, no helper thread, no memory files -- the host block is one plain posix_memalign allocation as in the reference.  Coherence is
+ * then by call instead of by fault:
+ *     getData() / getScales()   bring the device's results to the host NOW (if the device copy is newer) and mark the host copy as the
+ *                               one that counts: whatever the caller writes through the pointer reaches the next device operation;
+ *     accessors (get, set, getBits, setBits, clear, toString ...) synchronise by themselves, as in the default build;
+ *     toDevice() / toHost()     optional: move the bytes at a moment of the caller's choosing (e.g. outside a timed region).
+ * The one rule: RE-TAKE the pointer after a device operation (quantize, mvm, scaleAndAdd, threshold, transpose, restore ...) on the
+ * object -- a pointer kept across one still points at valid memory, but shows the bytes from before it, and writes through it are not
+ * seen.  (The reference's contract, CloverVector4.h:229-237, is "valid for the life of the object"; that half still holds.)
  *
  * Non-owning views (CloverVector4(n, values, scales), CloverVector4.h:114-119) alias caller memory that cannot be
  * protected (not page-granular): they are written through -- every device result is copied back into the caller's memory
@@ -71,6 +83,10 @@
 #endif
 
 #include "clover_hip.h"
+
+#if defined(CLOVER_HIP_EXPLICIT_SYNC) && !defined(CLOVER_HIP_NO_PAGE_TRACKING)
+#define CLOVER_HIP_NO_PAGE_TRACKING 1
+#endif
 
 namespace clover_hip {
 
@@ -107,29 +123,6 @@ class Mirror;
 
 namespace detail {
 
-/* test-and-test-and-set lock on a lock-free atomic: usable from the signal handler */
-struct SpinLock {
-    std::atomic<int> v;
-    SpinLock() : v(0) {}
-    void lock()
-    {
-        while (v.exchange(1, std::memory_order_acquire))
-            while (v.load(std::memory_order_relaxed)) {
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
-            }
-    }
-    void unlock() { v.store(0, std::memory_order_release); }
-};
-struct Guard {
-    SpinLock &l;
-    explicit Guard(SpinLock &lk) : l(lk) { l.lock(); }
-    ~Guard() { l.unlock(); }
-    Guard(const Guard &) = delete;
-    Guard &operator=(const Guard &) = delete;
-};
-
 inline long futex(std::atomic<int> *word, int op, int val)
 {
 #if defined(__linux__)
@@ -139,6 +132,50 @@ inline long futex(std::atomic<int> *word, int op, int val)
     return 0;
 #endif
 }
+
+/* Lock on a lock-free atomic, usable from the signal handler: 0 free, 1 held, 2 held with sleepers.  Spins briefly (the common hold
+ * time is a state flip and one mprotect), then sleeps on the word with futex -- a block's lock is also held across a blocking copy of
+ * the whole block (milliseconds for a large one), and waiters must not burn cores that a cgroup-throttled host needs for the copy. */
+struct SpinLock {
+    std::atomic<int> v;
+    SpinLock() : v(0) {}
+    void lock()
+    {
+        int c = 0;
+        if (v.compare_exchange_strong(c, 1, std::memory_order_acquire)) return;
+        for (int spin = 0; spin < 400; spin++) {
+            c = 0;
+            if (v.load(std::memory_order_relaxed) == 0 && v.compare_exchange_strong(c, 1, std::memory_order_acquire)) return;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+#if defined(__linux__)
+        c = v.exchange(2, std::memory_order_acquire);
+        while (c != 0) {
+            futex(&v, FUTEX_WAIT, 2);
+            c = v.exchange(2, std::memory_order_acquire);
+        }
+#else
+        while (v.exchange(1, std::memory_order_acquire)) {}
+#endif
+    }
+    void unlock()
+    {
+#if defined(__linux__)
+        if (v.exchange(0, std::memory_order_release) == 2) futex(&v, FUTEX_WAKE, 1);
+#else
+        v.store(0, std::memory_order_release);
+#endif
+    }
+};
+struct Guard {
+    SpinLock &l;
+    explicit Guard(SpinLock &lk) : l(lk) { l.lock(); }
+    ~Guard() { l.unlock(); }
+    Guard(const Guard &) = delete;
+    Guard &operator=(const Guard &) = delete;
+};
 
 /* process-wide table of tracked blocks (sorted by host address), the chained SIGSEGV handler and the helper thread that performs
  * device -> host copies on behalf of faulting threads.  Lives in an inline function so that every translation unit including

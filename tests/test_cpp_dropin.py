@@ -179,3 +179,44 @@ def test_gemm_operand_cache_follows_the_matrix(tmp_path, tracking):
     _compile_gemm_cache(exe, () if tracking else ("-DCLOVER_HIP_NO_PAGE_TRACKING",))
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "gemm_cache ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+# ---- explicit residency (-DCLOVER_HIP_EXPLICIT_SYNC, include/clover_device.h): no signal handler, no mprotect -----------------------
+def _build_explicit(tmp_path, explicit: bool):
+    lib = build_hip_library()
+    exe = tmp_path / ("explicit_sync" if explicit else "explicit_sync_tracked")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", *(["-DCLOVER_HIP_EXPLICIT_SYNC"] if explicit else []),
+                    f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "explicit_sync.cpp"), "-o", str(exe), f"-L{lib.parent}", "-lclover_hip",
+                    f"-Wl,-rpath,{lib.parent}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+def test_explicit_sync_client_builds(tmp_path, explicit):
+    p = subprocess.run([str(_build_explicit(tmp_path, explicit))], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and ("no_device" in p.stdout or "explicit_sync ok" in p.stdout), (p.returncode, p.stdout, p.stderr)
+    # the explicit build references neither the handler nor the memory-file machinery at run time: no sigaction / mprotect / memfd calls
+    if explicit:
+        syms = subprocess.run(["nm", "-C", "--undefined-only", str(tmp_path / "explicit_sync")], capture_output=True, text=True).stdout
+        assert "mprotect" not in syms and "pthread_create" not in syms, syms
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("explicit", [True, False])
+def test_explicit_sync_mode_on_the_gpu(tmp_path, explicit):
+    """the same client in both builds: explicit residency (host owns SIGSEGV, pointers re-taken after device operations) and the default
+    page-tracked build; device results equal the scalar host twins bit for bit in both"""
+    p = subprocess.run([str(_build_explicit(tmp_path, explicit))], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "explicit_sync ok" in p.stdout and f"mode={'explicit' if explicit else 'tracked'}" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+@pytest.mark.gpu
+def test_dropin_example_in_explicit_mode_gives_the_same_answers(tmp_path):
+    """the README-style client (tests/cpp/dropin_example.cpp) prints the same lines in both builds"""
+    outs = []
+    for name, extra in (("dropin_tracked", ()), ("dropin_explicit", ("-DCLOVER_HIP_EXPLICIT_SYNC",))):
+        exe = tmp_path / name
+        compile_example(exe, extra)
+        outs.append(subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=300).stdout)
+    strip = lambda o: [ln for ln in o.splitlines() if "_us=" not in ln and "_ms=" not in ln]      # noqa: E731 -- timing lines differ
+    assert strip(outs[0]) == strip(outs[1])
