@@ -874,7 +874,8 @@ struct Th4Sel {
     uint32_t prefix, remaining;
 };
 
-// one 256-thread workgroup: from the top of `hist`, the bin in which the cumulative count reaches `need`
+// one workgroup of 256 or more threads (the first 256 do the work, everybody takes the barriers): from the top of `hist`, the bin in
+// which the cumulative count reaches `need`
 template <int LEVEL>
 __device__ __forceinline__ Th4Sel th4_wg_select(const uint32_t *__restrict__ hist, uint32_t need, uint32_t prev, uint32_t *sel /* LDS[2] */,
                                                 uint32_t *wsum /* LDS[4] */)
@@ -882,24 +883,29 @@ __device__ __forceinline__ Th4Sel th4_wg_select(const uint32_t *__restrict__ his
     constexpr int nb = LEVEL == 2 ? 256 : 4096;
     constexpr int per = nb / 256;
     const int t = threadIdx.x;
-    const int top = (255 - t) * per + per - 1;                   // thread t owns the t-th run of `per` bins from the top
+    const bool on = t < 256;
+    const int top = (255 - (on ? t : 0)) * per + per - 1;        // thread t owns the t-th run of `per` bins from the top
     uint32_t bins[per], sum = 0;
 #pragma unroll
-    for (int i = 0; i < per; i++) { bins[i] = hist[top - i]; sum += bins[i]; }
+    for (int i = 0; i < per; i++) bins[i] = hist[top - i];      // unconditional (the idle threads read thread 0's bins): the loads go out together
+#pragma unroll
+    for (int i = 0; i < per; i++) { if (!on) bins[i] = 0u; sum += bins[i]; }
     uint32_t v = wave_scan_incl(sum);
     __syncthreads();                                             // sel / wsum of an earlier call have been read
-    if ((t & 63) == 63) wsum[t >> 6] = v;
+    if (on && (t & 63) == 63) wsum[t >> 6] = v;
     __syncthreads();
-    for (int w = 0; w < (t >> 6); w++) v += wsum[w];
-    if (v >= need && v - sum < need) {
-        uint32_t above = v - sum;
-        int i = 0;
+    if (on) {
+        for (int w = 0; w < (t >> 6); w++) v += wsum[w];
+        if (v >= need && v - sum < need) {
+            uint32_t above = v - sum;
+            int i = 0;
 #pragma unroll
-        for (int j = 0; j < per - 1; j++)
-            if (i == j && above + bins[j] < need) { above += bins[j]; i = j + 1; }
-        const uint32_t bin = (uint32_t)(top - i);
-        sel[0] = LEVEL == 0 ? bin : (LEVEL == 1 ? (prev << 12) | bin : (prev << 8) | bin);
-        sel[1] = need - above;
+            for (int j = 0; j < per - 1; j++)
+                if (i == j && above + bins[j] < need) { above += bins[j]; i = j + 1; }
+            const uint32_t bin = (uint32_t)(top - i);
+            sel[0] = LEVEL == 0 ? bin : (LEVEL == 1 ? (prev << 12) | bin : (prev << 8) | bin);
+            sel[1] = need - above;
+        }
     }
     __syncthreads();
     return Th4Sel{sel[0], sel[1]};
@@ -916,6 +922,54 @@ __device__ __forceinline__ Th4Sel th4_selected(const uint32_t *__restrict__ hist
     return r;
 }
 
+// Bit-sliced magnitude counts of a FULL block (64 nibbles in 8 words).  A 4 x 4 bit transpose inside every nibble column turns four words
+// into the four bit planes of their 32 nibbles (plane j, bit 4e + k = bit j of nibble e of word k); |v| is then taken on the planes
+// (two's complement: a1 = v1 ^ (sign & v0), a2 = v2 ^ (sign & (v1 | v0)), a3 = sign & ~(v2 | v1 | v0), i.e. only for -8) and every
+// magnitude 1..7 is one three-input boolean + one popcount per half block: ~1.5 VALU per element against ~5 for the nibble-by-nibble
+// walk (round 3: the count pass ran at 2.7 TB/s, VALU-bound).  Element order inside the block does not matter for counts.
+__device__ __forceinline__ void th4_planes(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t P[4])
+{
+    uint32_t t;
+    t = ((x0 >> 1) ^ x1) & 0x55555555u; x1 ^= t; x0 ^= t << 1;
+    t = ((x2 >> 1) ^ x3) & 0x55555555u; x3 ^= t; x2 ^= t << 1;
+    t = ((x0 >> 2) ^ x2) & 0x33333333u; x2 ^= t; x0 ^= t << 2;
+    t = ((x1 >> 2) ^ x3) & 0x33333333u; x3 ^= t; x1 ^= t << 2;
+    P[0] = x0; P[1] = x1; P[2] = x2; P[3] = x3;
+}
+
+__device__ __forceinline__ unsigned long long th4_count_full_block(const uint32_t w[8])
+{
+    uint32_t A[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        uint32_t v[4];
+        th4_planes(w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3], v);
+        const uint32_t low = v[1] | v[0];
+        A[h][0] = v[0];
+        A[h][1] = v[1] ^ (v[3] & v[0]);
+        A[h][2] = v[2] ^ (v[3] & low);
+        A[h][3] = v[3] & ~(v[2] | low);
+    }
+    uint32_t c[9], sum = 0;
+#pragma unroll
+    for (int m = 1; m <= 7; m++) {
+        uint32_t n = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t b2 = (m & 4) ? A[h][2] : ~A[h][2], b1 = (m & 2) ? A[h][1] : ~A[h][1], b0 = (m & 1) ? A[h][0] : ~A[h][0];
+            n += __popc(b2 & b1 & b0);
+        }
+        c[m] = n;
+        sum += n;
+    }
+    c[8] = __popc(A[0][3]) + __popc(A[1][3]);
+    c[0] = 64u - sum - c[8];
+    // fields of 7 bits at bit 7 m: m = 0..3 in the low word, m = 4 straddles bit 32
+    const uint32_t lo = c[0] | (c[1] << 7) | (c[2] << 14) | (c[3] << 21) | (c[4] << 28);
+    const uint32_t hi = (c[4] >> 4) | (c[5] << 3) | (c[6] << 10) | (c[7] << 17) | (c[8] << 24);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // every block's 9 magnitude counts, and a clean slate for all three histograms
 __global__ __launch_bounds__(256) void k_th4_count6(const u32x4 *__restrict__ q, uint64_t n, unsigned long long *__restrict__ cnt, uint64_t nblocks,
                                                     uint32_t *hists)
@@ -926,7 +980,11 @@ __global__ __launch_bounds__(256) void k_th4_count6(const u32x4 *__restrict__ q,
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
         const u32x4 lo = q[2 * b], hi = q[2 * b + 1];
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        unsigned long long acc = 0;
+        if (b * 64 + 64 <= n) {                                  // every block but possibly the last
+            cnt[b] = th4_count_full_block(w);
+            continue;
+        }
+        unsigned long long acc = 0;                              // the block that n cuts: element by element, the first n - 64 b of them
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t ab = abs_nibbles(swap_nibbles(w[j]));
@@ -940,36 +998,69 @@ __global__ __launch_bounds__(256) void k_th4_count6(const u32x4 *__restrict__ q,
     }
 }
 
+#ifndef TH4_HU
+#define TH4_HU 4             // blocks per thread and step of a histogram level (8 with half the workgroups: 30-37 us per level at n = 2^28, this: 20-25)
+#endif
+#ifndef TH4_HWG_PER_CU_X2
+#define TH4_HWG_PER_CU_X2 4  // histogram workgroups (of 1024 threads) per TWO CUs
+#endif
 // radix level LEVEL over the candidate tables, with the earlier levels' selections recomputed per workgroup
 template <int LEVEL>
-__global__ __launch_bounds__(256) void k_th4_hist6(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
-                                                   uint32_t *__restrict__ hists, uint32_t k)
+__global__ __launch_bounds__(1024) void k_th4_hist6(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
+                                                    uint32_t *__restrict__ hists, uint32_t k)
 {
     __shared__ uint32_t lh[4096];
     __shared__ uint32_t sel[2], wsum[4];
     constexpr int NB = LEVEL == 2 ? 256 : 4096;
-    for (int i = threadIdx.x; i < NB; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) lh[i] = 0;
     const uint32_t prefix = th4_selected<LEVEL>(hists, k, sel, wsum).prefix;       // ends with a barrier: lh is clear for everybody
     if (LEVEL == 0) __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
-        const unsigned long long c = cnt[b];
-        const float s7 = div7(s[b]);
+    // The 64 lanes of a wave hold 64 neighbouring blocks, whose scales -- hence whose keys for one magnitude m -- mostly fall into the
+    // same bin: with every lane on the same m, one LDS atomic instruction is up to 64 updates of ONE address, which the LDS serialises.
+    // So the lanes walk the nine magnitudes in rotated order, lane l starting at m = l mod 9: one instruction then spreads over nine
+    // bins.  Sums are order-free: same histogram.
+    const uint32_t m0 = (threadIdx.x & 63) % 9u;
+    auto add_block = [&](unsigned long long c, float sc) {
+        const float s7 = div7(sc);
+        uint32_t m = m0;
 #pragma unroll
-        for (int m = 0; m <= 8; m++) {
+        for (int it = 0; it <= 8; it++) {
             const uint32_t wgt = (uint32_t)(c >> (7 * m)) & 0x7Fu;
             if (wgt) {
-                const uint32_t key = cand_key(s7, m);
+                const uint32_t key = __float_as_uint(__builtin_fabsf(s7 * (float)m));        // cand_key(s7, m)
                 if (LEVEL == 0) atomicAdd(&lh[key >> 20], wgt);
                 else if (LEVEL == 1) { if ((key >> 20) == prefix) atomicAdd(&lh[(key >> 8) & 0xFFF], wgt); }
                 else { if ((key >> 8) == prefix) atomicAdd(&lh[key & 0xFF], wgt); }
             }
+            m = m == 8 ? 0 : m + 1;
         }
+    };
+    // TH4_HU blocks per thread and step, all loads first: a thread walks only a handful of steps, so the level is as long as its
+    // chain of load latencies (a block whose table is all zero adds nothing: the tail needs no branch)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += TH4_HU * stride) {
+        unsigned long long c[TH4_HU];
+        float sc[TH4_HU];
+#pragma unroll
+        for (int u = 0; u < TH4_HU; u++) {
+            const uint64_t bu = b + u * stride;
+            const bool in = bu < nblocks;
+            const uint64_t bc = in ? bu : b;                                  // clamped address, unconditional load
+            c[u] = cnt[bc];
+            sc[u] = s[bc];
+            if (!in) c[u] = 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < TH4_HU; u++) add_block(c[u], sc[u]);
     }
     __syncthreads();
     uint32_t *hist = hists + 4096 * LEVEL;
-    for (int i = threadIdx.x; i < NB; i += 256) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
+
+#define TH4_GROUPS 512u      // workgroups of the tie kernel (and entries the apply kernel adds up at most); every one re-reads the
+                             // three histograms (33 KiB) to recompute tau: 2048 groups were slower (68 MB of L2 reads) than 512
+#define TH4_MAX_CPG 512u     // chunks per group at most: n < 2^32 -> fewer than 2^18 chunks of 256 blocks, over 512 groups
 
 // tie counts.  Workgroup g takes the chunks (of 256 blocks = one workgroup of the apply kernel) [g * cpg, (g + 1) * cpg): it
 // leaves the EXCLUSIVE prefix of every chunk inside its group in chunk_ties and the group's total in group_ties; workgroup 0
@@ -983,19 +1074,45 @@ __global__ __launch_bounds__(256) void k_th4_ties6(const unsigned long long *__r
     if (k != 0) r = th4_selected<3>(hists, k, sel, wsum);
     const uint32_t tau = r.prefix, keep = r.remaining;
     if (blockIdx.x == 0 && threadIdx.x == 0) *ts = ThreshState{tau, keep, tau, keep};
-    uint32_t run = 0;
+    // chunk totals first -- a wave per chunk, four lane-steps of 64 blocks and one wave reduction, no barrier inside the loop -- then ONE
+    // block scan over the group's (at most 512) totals.  (Round 3 took a workgroup scan and two barriers per chunk: 24 us at n = 2^28.)
+    __shared__ uint32_t tot[TH4_MAX_CPG];
     const uint32_t c0 = blockIdx.x * cpg, c1 = c0 + cpg < nchunks ? c0 + cpg : nchunks;
-    for (uint32_t c = c0; c < c1; c++) {
-        const uint64_t b = (uint64_t)c * 256 + threadIdx.x;
-        uint32_t t = b < nblocks ? th4_block_ties(cnt[b], div7(s[b]), tau) : 0u;
-        t = wave_scan_incl(t);
-        __syncthreads();                                           // wsum of the previous chunk has been read
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = t;
-        __syncthreads();
-        if (threadIdx.x == 0) chunk_ties[c] = run;
-        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t c = c0 + wave; c < c1; c += 8) {                        // two chunks per step: all sixteen loads first
+        unsigned long long cc[2][4];
+        float sc[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {                              // (an all-zero table has no ties: the tails need no branch)
+                const uint64_t b = (uint64_t)(c + 4 * u) * 256 + 64 * q4 + lane;
+                const bool in = c + 4 * u < c1 && b < nblocks;
+                const uint64_t bc = in ? b : 0;                               // clamped address, unconditional load: all sixteen go out
+                cc[u][q4] = cnt[bc];                                          // back to back (a predicated load becomes a branch + wait)
+                sc[u][q4] = s[bc];
+                if (!in) cc[u][q4] = 0ull;
+            }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) t += th4_block_ties(cc[u][q4], div7(sc[u][q4]), tau);
+            t = wave_scan_incl(t);
+            if (lane == 63 && c + 4 * u < c1) tot[c + 4 * u - c0] = t;
+        }
     }
-    if (threadIdx.x == 0) group_ties[blockIdx.x] = run;
+    __syncthreads();
+    const uint32_t i0 = 2 * threadIdx.x, n_here = c1 > c0 ? c1 - c0 : 0;
+    const uint32_t a = i0 < n_here ? tot[i0] : 0u, b2 = i0 + 1 < n_here ? tot[i0 + 1] : 0u;
+    uint32_t incl = wave_scan_incl(a + b2);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - (a + b2);
+    for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+    if (i0 < n_here) chunk_ties[c0 + i0] = before;
+    if (i0 + 1 < n_here) chunk_ties[c0 + i0 + 1] = before + a;
+    if (threadIdx.x == 0) group_ties[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // thread = one 64-element block: survivors above tau and the first `keep` ties in index order, whole words at a time; the rank of
@@ -1048,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_th4_apply6(u32x4 *__restrict__ q, const
     q[2 * b + 1] = u32x4{w[4], w[5], w[6], w[7]};
 }
 
-#define TH4_GROUPS 512u      // workgroups of the tie kernel (and entries the apply kernel adds up at most)
+// (TH4_GROUPS / TH4_MAX_CPG are defined in front of k_th4_ties6)
 
 // workspace layout: [3 histograms of 4096 u32][ThreshState, 256 B][group_ties: 512 u32][chunk_ties: nblocks/256 + 1 u32, padded to
 // 256 B][cnt: nblocks u64]
@@ -1064,13 +1181,21 @@ static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_
     const uint64_t want = (nblocks + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
     hipLaunchKernelGGL(k_th4_count6, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const u32x4 *)q, n, cnt, nblocks, hists);
     if (k != 0) {
-        // few, fat workgroups (every workgroup clears and flushes 16 KiB of bins): one per 1024 blocks, at most four per CU
-        // (n = 2^24: 256 workgroups, 39 us per call against 41-46 with more; n = 2^28: 1024, 206 us against 260 with 256)
-        const uint64_t hwant = (nblocks + 1023) / 1024, hcap = (uint64_t)clv_cu_count() * 4;
+        // few, fat workgroups: every workgroup clears 16 KiB of bins and flushes its non-empty ones with global atomics, and those land on
+        // the SAME few dozen addresses from every workgroup (the keys of one vector cluster), where they serialise at ~50 ns each -- the
+        // flush, not the table read, was what a level cost at n = 2^28 (round 3: 1024 workgroups of 256 threads, 38 us per 12-bit level).
+        // So: as many THREADS as before but in workgroups of 1024 -- a quarter of the flushes per address -- one per 4096 blocks, at
+        // most two per CU.
+        // Below 2^20 blocks (n < 2^26) a level is all fixed cost and the round-3 shape -- 256-thread workgroups, one per 1024 blocks --
+        // is the faster one (n = 2^24: 6-9 us per level either way, 41 us per call against 49).
+        const bool fat = nblocks >= (1ull << 20);
+        const uint64_t hwant = fat ? (nblocks + 4095) / 4096 : (nblocks + 1023) / 1024;
+        const uint64_t hcap = fat ? (uint64_t)clv_cu_count() * TH4_HWG_PER_CU_X2 / 2 : (uint64_t)clv_cu_count() * 4;
         const dim3 grid((unsigned)(hwant < hcap ? hwant : hcap));
-        hipLaunchKernelGGL(k_th4_hist6<0>, grid, dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k);
-        hipLaunchKernelGGL(k_th4_hist6<1>, grid, dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k);
-        hipLaunchKernelGGL(k_th4_hist6<2>, grid, dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k);
+        const dim3 hthreads(fat ? 1024 : 256);
+        hipLaunchKernelGGL(k_th4_hist6<0>, grid, hthreads, 0, st, cnt, s, nblocks, hists, (uint32_t)k);
+        hipLaunchKernelGGL(k_th4_hist6<1>, grid, hthreads, 0, st, cnt, s, nblocks, hists, (uint32_t)k);
+        hipLaunchKernelGGL(k_th4_hist6<2>, grid, hthreads, 0, st, cnt, s, nblocks, hists, (uint32_t)k);
     }
     const uint32_t cpg = (nchunks + TH4_GROUPS - 1) / TH4_GROUPS;
     const uint32_t groups = (nchunks + cpg - 1) / cpg;

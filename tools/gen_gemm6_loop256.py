@@ -62,8 +62,8 @@ class Emit:
         r = FRAG[frag]
         op = "a" if frag[0] == "A" else "b"
         off = j * SUB + idx * 32 * 48
-        if "lds" in OFF:
-            return
+        if "lds" in OFF or ("lds25" in OFF and frag == "A1"):      # lds25: a QUARTER of the fragment reads left out (what a 128 x 64
+            return                                                  # wave tile would save per MFMA: 6 fragments for 8 MFMAs instead of 8)
         self(f"ds_read_b128 v[{r}:{r+3}], %[{op}16] offset:{off}")
         self(f"ds_read_b64 v[{r+4}:{r+5}], %[{op}8] offset:{off}")
         self.lds_q += [frag, frag]
@@ -243,6 +243,9 @@ def generate():
             fold(e, 3, UNITS[3][2], CREG[3])
         else:
             e.wait_frags("A1")                 # the last counted LDS wait of the stage: SMEM may be outstanding from here on
+            if "lds25" in OFF:
+                e("s_waitcnt lgkmcnt(0)")
+                e.lds_q = []
             assert not e.lds_q
             load_scales(e)                     # next stage's scales, covered by the wait before the barrier
             fold(e, 4, UNITS[4][2], CREG[4])
@@ -263,7 +266,7 @@ def generate():
             e.ds_frag("B1", 0, 1)
             e.ds_frag("A1", 0, 1)
         fold(e, m - 1, UNITS[m - 1][2], CREG[m - 1])
-    assert e.lds_q == Q0 or "lds" in OFF, e.lds_q
+    assert e.lds_q == Q0 or "lds" in OFF or "lds25" in OFF, e.lds_q
     e("s_sub_u32 s60, s60, 1")
     e("s_cmp_lg_u32 s60, 0")
     e("s_cbranch_scc1 1b")
@@ -312,7 +315,10 @@ def generate():
 
 
 EXPERIMENTS = {1: {"dma"}, 2: {"lds"}, 3: {"dma", "lds"}, 4: {"barrier"}, 5: {"fold"}, 6: {"store"}, 7: {"dma", "lds", "barrier", "store"},
-               8: {"dma", "store"}, 9: {"dma", "lds", "barrier", "store", "salu"}, 10: {"dma", "lds", "store", "salu"}}
+               8: {"dma", "store"}, 9: {"dma", "lds", "barrier", "store", "salu"}, 10: {"dma", "lds", "store", "salu"},
+               # round 4: the bound of the one lever left (128 x 64 wave tiles at two waves per SIMD): what a quarter fewer fragment reads
+               # could give at UNCHANGED occupancy (11), and together with a store that costs nothing (12)
+               11: {"lds25"}, 12: {"lds25", "store"}}
 
 
 CANDIDATES = {1: {"FOLD": "fmac"}, 2: {"FOLD": "pk"}, 3: {"FOLD": "mixed"}}      # `candidates`: CORRECT alternative schedules in slots v1..
@@ -345,7 +351,7 @@ def write(out, variants, define_experiments):
 
 def main():
     """no argument: clover_amd/csrc/gemm6_loop256.inc, the product's loops (libclover_hip.so; committed).
-       <out> experiments: the same + the timing-only variants v1..v10 with parts LEFT OUT (wrong results by construction).  The build
+       <out> experiments: the same + the timing-only variants v1..v12 with parts LEFT OUT (wrong results by construction).  The build
             (clover_amd/build.py) generates this into clover_amd/lib/obj/gemm6_loop256_exp.inc and compiles it ONLY into the bench-only probe
             library tools/_build/libclover_hip_probe.so (-DCLV_GEMM_EXPERIMENTS), where CLV_GEMM_LOOP=vN selects a variant --
             bench.py's `gemm.ceiling` and tools/gemm_bench.py load that library explicitly; the product library has no such switch.
