@@ -1429,10 +1429,6 @@ extern "C" uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad)
 template <int BITS>
 static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, hipStream_t st)
 {
-    if (k == 0) {                                                          // nothing survives (the oracle's reading of k = 0)
-        CLV_HIP(hipMemsetAsync(q, 0, (n + ThreshElems<BITS>::EPW - 1) / ThreshElems<BITS>::EPW * 4, st));
-        return CLV_OK;
-    }
     if (!workspace) {
         int rc = clv_internal_workspace(&workspace, clv_threshold_reference_workspace_bytes(n_pad), st);
         if (rc) return rc;
@@ -1445,7 +1441,10 @@ static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t
     const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
     const dim3 grid((unsigned)(want < cap ? want : cap));
     hipLaunchKernelGGL(k_thr_ref_keys<BITS>, grid, dim3(256), 0, st, (const uint32_t *)q, s, n, vals, keep, keep_words);
-    if (k <= THR_LDS_ENTRIES) {
+    if (k == 0) {
+        // nothing survives (the oracle's reading of k = 0): the bitmap the keys pass has just cleared goes to the apply pass as it is,
+        // which clears the first n elements and leaves the padding alone
+    } else if (k <= THR_LDS_ENTRIES) {
         const size_t lds = (size_t)k * sizeof(uint2);
         if (lds > 64 * 1024) CLV_HIP(hipFuncSetAttribute((const void *)k_thr_ref_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_thr_ref_walk<true>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);

@@ -186,6 +186,22 @@ def test_gpu_threshold_reference_order(hip, oracle, case, data):
     assert int((nibbles(out)[:n] != 0).sum()) <= k and np.array_equal(nibbles(out)[n:], nibbles(q)[n:])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 1, 100])
+def test_gpu_threshold_reference_order_leaves_the_padding_alone(hip, oracle, k):
+    """raw ABI input whose nibbles beyond n are NOT zero (a container never produces that): both modes touch the first n elements only,
+    also for k = 0 (everything cleared) -- n = 1003 ends in the middle of a word"""
+    n, npad = 1003, 1024
+    rng = np.random.default_rng(99 + k)
+    q, s = random_packed(rng, npad)
+    ref = oracle.v4_threshold(q, s, n, k)
+    for mode in (THRESHOLD_REFERENCE, 0):
+        out = hip.v4_threshold(q, s, n, k, mode=mode)
+        assert np.array_equal(nibbles(out)[n:], nibbles(q)[n:]) and int((nibbles(out)[:n] != 0).sum()) <= k
+        if mode == THRESHOLD_REFERENCE:
+            assert same(out, ref)
+
+
 def _threshold_lowest_index(oracle, q, s, n, k):
     """the HIP tie rule on the CPU: everything above the K-th magnitude, then the first ties by index"""
     mags = np.abs(oracle.v4_restore(q, s))[:n]
