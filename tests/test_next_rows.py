@@ -326,3 +326,23 @@ def test_gpu_fused_mvm_scale_and_add_rejects_aliasing_the_input(hip):
     buf = hip.alloc(4096)
     assert hip.lib.clm4_mvm_scale_and_add(buf.ptr, buf.ptr, 128, 128, buf.ptr, buf.offset(64), buf.offset(128), buf.offset(256), 1.0,
                                           None, None, buf.ptr, buf.offset(512), None, None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(4096, 4096, 1000), (131072 + 256, 131072 + 256, 30000), ((1 << 21) + 64 * 5 + 17, (1 << 21) + 512, 400000)])
+def test_gpu_threshold_with_raw_nibbles_including_minus_8(hip, oracle, case):
+    """raw ABI input with ALL sixteen nibble values (the quantiser never produces -8, a caller's buffer may): |-8| = 8 is its own magnitude
+    class in the per-block tables (bit-sliced counts, r4) and in the one-workgroup kernel; the surviving multiset equals the oracle's, the
+    survivors follow the lowest-index rule, and REFERENCE mode equals the oracle's heap walk where it applies"""
+    n, npad, k = case
+    rng = np.random.default_rng(n + k)
+    q = rng.integers(0, 256, size=npad // 2, dtype=np.uint8)
+    s = rng.uniform(0.5, 2, size=npad // 64).astype(np.float32)
+    out = hip.v4_threshold(q, s, n, k)
+    mags = np.abs(oracle.v4_restore(q, s))[:n]
+    ref = oracle.v4_threshold(q, s, n, k)
+    kept, kept_ref = nibbles(out)[:n] != 0, nibbles(ref)[:n] != 0
+    assert np.array_equal(np.sort(mags[kept]), np.sort(mags[kept_ref]))
+    assert same(out, _threshold_lowest_index(oracle, q, s, n, k))
+    if n <= 131072 + 256:
+        assert same(hip.v4_threshold(q, s, n, k, mode=THRESHOLD_REFERENCE), ref)
