@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const
 
 // stochastic variant: same segment walk as k_v4_quantize_st (rng4.hip); the nibbles are unpacked by bit
 // position there, so noise group g of AVX lane j meets element 8j + (g ^ 1) (CloverVector4.h:1236-1243).
-template <int S>
+template <int S, bool NT = false>
 __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
                                                              const float *__restrict__ sv, float a, uint32_t *r, float *sr,
                                                              uint64_t nblocks, uint64_t *state, uint64_t seq, RngTables T)
@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
             for (int u = 0; u < STEPS4; u++) {
                 const uint64_t blk = Sh::block(blk0, rr, 32 * u + (lane >> 1));
                 const uint64_t b = blk < nblocks ? blk : 0;
-                wu[u] = reinterpret_cast<const u32x4 *>(qu)[b * 2 + half];
-                wv[u] = reinterpret_cast<const u32x4 *>(qv)[b * 2 + half];
+                const u32x4 *pu = reinterpret_cast<const u32x4 *>(qu) + (b * 2 + half), *pv = reinterpret_cast<const u32x4 *>(qv) + (b * 2 + half);
+                wu[u] = NT ? __builtin_nontemporal_load(pu) : *pu;              // NT: operands + result beyond the Infinity Cache stream past it
+                wv[u] = NT ? __builtin_nontemporal_load(pv) : *pv;
                 fu[u] = su[b];
                 fv[u] = sv[b];
             }
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
                     o[q4] = quant_pack8(v[q4], kq, nz);
                 }
                 if (blk < nblocks) {
-                    reinterpret_cast<u32x4 *>(r)[blk * 2 + half] = u32x4{o[0], o[1], o[2], o[3]};
+                    u32x4 *pr = reinterpret_cast<u32x4 *>(r) + (blk * 2 + half);
+                    if (NT) __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, pr); else *pr = u32x4{o[0], o[1], o[2], o[3]};
                     if (half == 0) sr[blk] = m;
                 }
             }
@@ -224,7 +226,13 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
     case 1: SAA_LAUNCH(1); break;
     case 4: SAA_LAUNCH(4); break;
     case 16: SAA_LAUNCH(16); break;
-    default: SAA_LAUNCH(64); break;
+    default:
+        if (3 * (n_pad / 2) > (256ull << 20))
+            hipLaunchKernelGGL((k_v4_scale_and_add_st<64, true>), dim3((unsigned)((nb + 32 * 64 - 1) / (32 * 64))), dim3(256), 0, st,
+                               (const uint32_t *)qu, su, (const uint32_t *)qv, sv, a, (uint32_t *)r, sr, nb, rng_state_dev, seq, T);
+        else
+            SAA_LAUNCH(64);
+        break;
     }
 #undef SAA_LAUNCH
     CLV_LAUNCH_CHECK();
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256) void k_m4_transpose(const uint32_t *__restrict
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int idx = tid + 256 * k, r = idx >> 3, c = idx & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(q + (r0 + r) * wcols + c0w + 4 * c);
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(q + (r0 + r) * wcols + c0w + 4 * c);      // (nt loads / stores: no difference, r4)
         uint32_t *d = tin + r * TR_S + 4 * c;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
