@@ -96,9 +96,9 @@ def test_kept_pointers_and_views_behave_like_the_reference(tmp_path):
     assert us < 200.0
 
 
-def _build_validate(tmp_path, name="validate_relations"):
-    exe = tmp_path / name
-    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}",
+def _build_validate(tmp_path, name="validate_relations", extra=()):
+    exe = tmp_path / (name + ("_x" if extra else ""))
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", *extra, f"-I{ROOT / 'include'}",
                     str(CPP / f"{name}.cpp"), "-o", str(exe), *_link_flags()], check=True)
     return exe
 
@@ -127,3 +127,12 @@ def test_reference_validation_grid_at_full_density(tmp_path):
     p = subprocess.run([str(_build_validate(tmp_path, "validate_grid"))], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and "validate grid ok" in p.stdout, (p.returncode, p.stdout[-3000:], p.stderr[-1000:])
     print(p.stdout.strip().splitlines()[-2])
+
+
+@pytest.mark.gpu
+def test_reference_validation_grid_in_the_explicit_residency_build(tmp_path):
+    """the same full-density grid with the containers built -DCLOVER_HIP_EXPLICIT_SYNC (no signal handler, no mprotect): every relation
+    is written with accessors or with pointers taken after the device operation, which is that build's one rule"""
+    p = subprocess.run([str(_build_validate(tmp_path, "validate_grid", extra=("-DCLOVER_HIP_EXPLICIT_SYNC",)))], capture_output=True, text=True,
+                       timeout=1500)
+    assert p.returncode == 0 and "validate grid ok" in p.stdout, (p.returncode, p.stdout[-3000:], p.stderr[-1000:])
