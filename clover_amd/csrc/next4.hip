@@ -645,121 +645,207 @@ __device__ __forceinline__ uint32_t ge_nibbles(uint32_t ab, uint32_t t)
 // bit 3 of each of the first `count` nibbles (count 0..8)
 __device__ __forceinline__ uint32_t first_nibbles(uint32_t count) { return count >= 8 ? 0x88888888u : 0x88888888u & ((1u << (4 * count)) - 1u); }
 
-// the vector (<= 64 KiB of nibbles) and the per-block s/7 are staged in LDS once; every pass walks them there
+// Bit-sliced magnitude counts of a FULL block (64 nibbles in 8 words).  A 4 x 4 bit transpose inside every nibble column turns four words
+// into the four bit planes of their 32 nibbles (plane j, bit 4e + k = bit j of nibble e of word k); |v| is then taken on the planes
+// (two's complement: a1 = v1 ^ (sign & v0), a2 = v2 ^ (sign & (v1 | v0)), a3 = sign & ~(v2 | v1 | v0), i.e. only for -8) and every
+// magnitude 1..7 is one three-input boolean + one popcount per half block: ~1.5 VALU per element against ~5 for the nibble-by-nibble
+// walk (round 3: the count pass ran at 2.7 TB/s, VALU-bound).  Element order inside the block does not matter for counts.
+__device__ __forceinline__ void th4_planes(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t P[4])
+{
+    uint32_t t;
+    t = ((x0 >> 1) ^ x1) & 0x55555555u; x1 ^= t; x0 ^= t << 1;
+    t = ((x2 >> 1) ^ x3) & 0x55555555u; x3 ^= t; x2 ^= t << 1;
+    t = ((x0 >> 2) ^ x2) & 0x33333333u; x2 ^= t; x0 ^= t << 2;
+    t = ((x1 >> 2) ^ x3) & 0x33333333u; x3 ^= t; x1 ^= t << 2;
+    P[0] = x0; P[1] = x1; P[2] = x2; P[3] = x3;
+}
+
+__device__ __forceinline__ unsigned long long th4_count_full_block(const uint32_t w[8])
+{
+    uint32_t A[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        uint32_t v[4];
+        th4_planes(w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3], v);
+        const uint32_t low = v[1] | v[0];
+        A[h][0] = v[0];
+        A[h][1] = v[1] ^ (v[3] & v[0]);
+        A[h][2] = v[2] ^ (v[3] & low);
+        A[h][3] = v[3] & ~(v[2] | low);
+    }
+    uint32_t c[9], sum = 0;
+#pragma unroll
+    for (int m = 1; m <= 7; m++) {
+        uint32_t n = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t b2 = (m & 4) ? A[h][2] : ~A[h][2], b1 = (m & 2) ? A[h][1] : ~A[h][1], b0 = (m & 1) ? A[h][0] : ~A[h][0];
+            n += __popc(b2 & b1 & b0);
+        }
+        c[m] = n;
+        sum += n;
+    }
+    c[8] = __popc(A[0][3]) + __popc(A[1][3]);
+    c[0] = 64u - sum - c[8];
+    // fields of 7 bits at bit 7 m: m = 0..3 in the low word, m = 4 straddles bit 32
+    const uint32_t lo = c[0] | (c[1] << 7) | (c[2] << 14) | (c[3] << 21) | (c[4] << 28);
+    const uint32_t hi = (c[4] >> 4) | (c[5] << 3) | (c[6] << 10) | (c[7] << 17) | (c[8] << 24);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// one word's contribution to its block's table: field m += #(|nibble| == m) over the first `valid` elements of the word
+__device__ __forceinline__ unsigned long long th4_count_word(uint32_t w, uint32_t valid)
+{
+    const uint32_t ab = abs_nibbles(swap_nibbles(w));
+    unsigned long long acc = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++)
+        if (e < valid) acc += 1ull << (7u * ((ab >> (4 * e)) & 0xFu));
+    return acc;
+}
+
+// Round 4: the same selection with a third of the synchronisation (measured with cycle stamps at N = 8192, round-3 kernel: 16.5 k cycles
+// = load 1.6 k, counts 1.8 k, four levels 7.2 k, cut-offs 0.8 k, ties + scan 4.0 k, apply 0.6 k; about 20 barriers):
+//  * W = words per thread is a template parameter (1 at N = 8192): the thread's words live in registers, nothing is staged in LDS, no
+//    16-slot loop with dead slots;
+//  * a thread computes the (key, weight) of its <= 9 W / 8 + 1 candidates ONCE, in registers, before the levels;
+//  * a level is: the candidates' LDS atomics, ONE barrier, and then EVERY wave scans the 256 bins itself (4 bins per lane, one DPP scan,
+//    one ballot) -- no second and third barrier to publish the selected bin;
+//  * the per-block cut-offs are computed by each thread for its own words' blocks (9 products): no table, no barrier;
+//  * the tie ranks need one barrier (16 wave totals), not two.
+// Same keys, same selection, same lowest-index tie rule: results are bit-identical (all threshold and IHT tests).
+template <int W>
 __global__ __launch_bounds__(TS_THREADS) void k_thresh_small(uint32_t *__restrict__ q, const float *__restrict__ s, uint32_t n, uint32_t k)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t ts_lds[];
-    uint32_t *hist = ts_lds;                 // 4 levels x 256
-    uint32_t *wsum = hist + 1024;            // 16
-    uint32_t *sel = wsum + 16;               // 2 (+14 pad)
-    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(sel + 16);      // per block: 9 fields of 7 bits, field m = #(|nibble| == m)
-    const int tid = threadIdx.x;
+    constexpr int MAXB = TS_THREADS * TS_MAXW / 8;                       // 2048 blocks at most
+    constexpr int NC = (9 * W + 7) / 8 + 1;                              // candidates per thread at most
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4 * 256];
+    __shared__ unsigned long long cnt[MAXB];                             // per block: 9 fields of 7 bits, field m = #(|nibble| == m)
+    __shared__ float s7[MAXB];
+    __shared__ uint32_t wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nwords = (n + 7) / 8, nblocks = (n + 63) / 64;
-    float *s7 = reinterpret_cast<float *>(cnt + nblocks);
-    uint32_t *words = reinterpret_cast<uint32_t *>(s7 + ((nblocks + 3) & ~3u));
-    const uint32_t W = (nwords + TS_THREADS - 1) / TS_THREADS;          // contiguous words per thread: index order = thread order
-    const uint32_t w0 = tid * W, w1 = (w0 + W) < nwords ? (w0 + W) : nwords;
-    for (uint32_t i = tid; i < nwords; i += TS_THREADS) words[i] = q[i];
-    for (uint32_t i = tid; i < nblocks; i += TS_THREADS) { s7[i] = div7(s[i]); cnt[i] = 0ull; }
+    const uint32_t w0 = tid * W;
+    uint32_t w[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) w[j] = q[w0 + j < nwords ? w0 + j : 0];
+    for (uint32_t i = tid; i < nblocks; i += TS_THREADS) { s7[i] = div7(s[i]); if (W < 8) cnt[i] = 0ull; }
     hist[tid] = 0;
-    __syncthreads();
+    __syncthreads();                                                     // tables zero before anybody adds to them; s7 visible (also for k = 0)
 
     uint32_t tau = 0x7F800000u, keep = 0;
     if (k != 0) {
-        for (uint32_t i = w0; i < w1; i++) {                             // magnitude counts of this word into its block
-            const uint32_t ab = abs_nibbles(swap_nibbles(words[i]));
-            const uint32_t valid = n - 8 * i < 8 ? n - 8 * i : 8;
-            unsigned long long acc = 0;
+        // magnitude tables.  W >= 8: a thread holds whole blocks (plain stores, bit-sliced counts for full blocks); else LDS atomics
+        if constexpr (W >= 8) {
 #pragma unroll
-            for (uint32_t e = 0; e < 8; e++)
-                if (e < valid) acc += 1ull << (7u * ((ab >> (4 * e)) & 0xFu));
-            atomicAdd(&cnt[i >> 3], acc);
+            for (int g = 0; g < W / 8; g++) {
+                const uint32_t b = (w0 >> 3) + g;
+                if (b < nblocks) {
+                    unsigned long long acc = 0;
+                    if (64u * b + 64u <= n) {
+                        acc = th4_count_full_block(&w[8 * g]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const uint32_t first = 64u * b + 8u * j;
+                            acc += th4_count_word(w[8 * g + j], first >= n ? 0u : (n - first < 8 ? n - first : 8u));
+                        }
+                    }
+                    cnt[b] = acc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const uint32_t i = w0 + j;
+                if (i < nwords) atomicAdd(&cnt[i >> 3], th4_count_word(w[j], n - 8 * i < 8 ? n - 8 * i : 8u));
+            }
         }
         __syncthreads();
+        // this thread's candidates (block, magnitude): key and weight, once
+        uint32_t ckey[NC], cwgt[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint32_t ci = tid + TS_THREADS * c;
+            const bool in = ci < 9 * nblocks;
+            const uint32_t b = in ? ci / 9u : 0u, m = ci - 9u * b;
+            cwgt[c] = in ? (uint32_t)(cnt[b] >> (7 * m)) & 0x7Fu : 0u;
+            ckey[c] = cand_key(s7[b], (int)m);
+        }
         uint32_t prefix = 0, need = k;
+#pragma unroll
         for (int level = 0; level < 4; level++) {
             const int shift = 24 - 8 * level;
             uint32_t *h = hist + 256 * level;
-            for (uint32_t c = tid; c < 9 * nblocks; c += TS_THREADS) {
-                const uint32_t b = c / 9, m = c - 9 * b;
-                const uint32_t wgt = (uint32_t)(cnt[b] >> (7 * m)) & 0x7Fu;
-                if (wgt) {
-                    const uint32_t key = cand_key(s7[b], (int)m);
-                    if (level == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&h[(key >> shift) & 0xFFu], wgt);
-                }
-            }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (cwgt[c] && (level == 0 || (ckey[c] >> (shift + 8)) == prefix)) atomicAdd(&h[(ckey[c] >> shift) & 0xFFu], cwgt[c]);
             __syncthreads();
-            // select from the top: thread t < 256 owns bin 255 - t
-            const uint32_t mine = tid < 256 ? h[255 - tid] : 0;
-            uint32_t v = wave_scan_incl(mine);
-            if (tid < 256 && (tid & 63) == 63) wsum[tid >> 6] = v;
-            __syncthreads();
-            if (tid < 256) {
-                for (int w = 0; w < (tid >> 6); w++) v += wsum[w];
-                if (v >= need && v - mine < need) {
-                    sel[0] = 255u - tid;
-                    sel[1] = need - (v - mine);
-                }
-            }
-            __syncthreads();
-            prefix = (prefix << 8) | sel[0];
-            need = sel[1];
+            // every wave selects for itself: lane l owns bins 255 - 4 l ... 252 - 4 l (from the top)
+            const u32x4 h4 = *reinterpret_cast<const u32x4 *>(h + 252 - 4 * lane);
+            const uint32_t t0 = h4.w, t1 = h4.z, t2 = h4.y, t3 = h4.x;
+            const uint32_t sum = t0 + t1 + t2 + t3;
+            const uint32_t incl = wave_scan_incl(sum);
+            const unsigned long long hit = __ballot(incl >= need && incl - sum < need);
+            const int L = __builtin_ctzll(hit);                          // exactly one lane: the level's total weight is >= need
+            uint32_t above = __shfl(incl - sum, L);
+            const uint32_t T0 = __shfl(t0, L), T1 = __shfl(t1, L), T2 = __shfl(t2, L);
+            uint32_t pick = 0;
+            if (above + T0 < need) { above += T0; pick = 1;
+                if (above + T1 < need) { above += T1; pick = 2;
+                    if (above + T2 < need) { above += T2; pick = 3; } } }
+            prefix = (prefix << 8) | (255u - 4u * (uint32_t)L - pick);
+            need -= above;
         }
         tau = prefix;
         keep = need;
     }
-    // per block: magnitudes >= hi_t are above tau, [lo_t, hi_t) equal tau (keys grow with the magnitude)
-    uint32_t *cut = reinterpret_cast<uint32_t *>(cnt);                   // the counts are dead: every level ended with a barrier
-    for (uint32_t b = tid; b < nblocks; b += TS_THREADS) {
-        const float sc = s7[b];
-        uint32_t lo_t = 0, hi_t = 0;
+    // survivors above tau, ties, the rank of this thread's first tie (ties in index order: the first `keep` survive)
+    uint32_t keepbits[W], tiebits[W], c = 0;
+    uint32_t lo_t = 0, hi_t = 0, cur_b = 0xFFFFFFFFu;
 #pragma unroll
-        for (int m = 0; m <= 8; m++) {
-            const uint32_t key = cand_key(sc, m);
-            lo_t += key < tau;
-            hi_t += key <= tau;
-        }
-        cut[b] = lo_t | (hi_t << 8);
-    }
-    __syncthreads();
-    uint32_t c = 0;
-    uint32_t keepbits[TS_MAXW], tiebits[TS_MAXW];
-#pragma unroll
-    for (uint32_t j = 0; j < TS_MAXW; j++) {
+    for (int j = 0; j < W; j++) {
         const uint32_t i = w0 + j;
-        if (j < W && i < w1) {
-            const uint32_t lo_t = cut[i >> 3] & 0xFFu, hi_t = cut[i >> 3] >> 8;
-            const uint32_t ab = abs_nibbles(swap_nibbles(words[i]));
+        keepbits[j] = tiebits[j] = 0;
+        if (i < nwords) {
+            if ((i >> 3) != cur_b) {                                     // per block: magnitudes >= hi_t are above tau, [lo_t, hi_t) equal it
+                cur_b = i >> 3;
+                const float sc = s7[cur_b];
+                lo_t = hi_t = 0;
+#pragma unroll
+                for (int m = 0; m <= 8; m++) {
+                    const uint32_t key = cand_key(sc, m);
+                    lo_t += key < tau;
+                    hi_t += key <= tau;
+                }
+            }
+            const uint32_t ab = abs_nibbles(swap_nibbles(w[j]));
             const uint32_t valid = first_nibbles(n - 8 * i < 8 ? n - 8 * i : 8);
             const uint32_t above = ge_nibbles(ab, hi_t);
             keepbits[j] = above | (0x88888888u & ~valid);                 // padding is left alone
             tiebits[j] = ge_nibbles(ab, lo_t) & ~above & valid;
             c += __popc(tiebits[j]);
-        } else {
-            keepbits[j] = tiebits[j] = 0;
         }
     }
-    // ties in index order: the first `keep` of them survive
-    uint32_t rank = block_scan_incl(c, wsum) - c;
+    const uint32_t v = wave_scan_incl(c);
+    if (lane == 63) wtot[wave] = v;
+    __syncthreads();
+    const uint32_t tot = lane < 16 ? wtot[lane] : 0;
+    const uint32_t inc = wave_scan_incl(tot);
+    uint32_t rank = v - c + __shfl(inc - tot, wave);
 #pragma unroll
-    for (uint32_t j = 0; j < TS_MAXW; j++) {
+    for (int j = 0; j < W; j++) {
         const uint32_t i = w0 + j;
-        if (j < W && i < w1) {
+        if (i < nwords) {
             uint32_t t = tiebits[j], kb = keepbits[j];
             const uint32_t nt = __popc(t), room = keep > rank ? keep - rank : 0;
             if (room >= nt) kb |= t;
             else for (uint32_t r = 0; r < room; r++) { kb |= t & (0u - t); t &= t - 1; }
             rank += nt;
             const uint32_t full = (kb >> 3) * 0xFu;                       // bit 3 -> whole nibble, then back to the stored nibble order
-            q[i] = words[i] & swap_nibbles(full);
+            q[i] = w[j] & swap_nibbles(full);
         }
     }
-}
-
-static inline size_t thresh_small_lds(uint64_t n)
-{
-    const uint64_t nwords = (n + 7) / 8, nblocks = (n + 63) / 64;
-    return (1024 + 16 + 16 + 2 * nblocks + ((nblocks + 3) & ~3ull) + nwords) * sizeof(uint32_t);
 }
 
 // ---- single-workgroup path for CloverVector8 (n_pad <= 32768): element keys live in registers (8 words = 32 elements per
@@ -928,54 +1014,6 @@ __device__ __forceinline__ Th4Sel th4_selected(const uint32_t *__restrict__ hist
     if (UPTO >= 2) r = th4_wg_select<1>(hists + 4096, r.remaining, r.prefix, sel, wsum);
     if (UPTO >= 3) r = th4_wg_select<2>(hists + 8192, r.remaining, r.prefix, sel, wsum);
     return r;
-}
-
-// Bit-sliced magnitude counts of a FULL block (64 nibbles in 8 words).  A 4 x 4 bit transpose inside every nibble column turns four words
-// into the four bit planes of their 32 nibbles (plane j, bit 4e + k = bit j of nibble e of word k); |v| is then taken on the planes
-// (two's complement: a1 = v1 ^ (sign & v0), a2 = v2 ^ (sign & (v1 | v0)), a3 = sign & ~(v2 | v1 | v0), i.e. only for -8) and every
-// magnitude 1..7 is one three-input boolean + one popcount per half block: ~1.5 VALU per element against ~5 for the nibble-by-nibble
-// walk (round 3: the count pass ran at 2.7 TB/s, VALU-bound).  Element order inside the block does not matter for counts.
-__device__ __forceinline__ void th4_planes(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t P[4])
-{
-    uint32_t t;
-    t = ((x0 >> 1) ^ x1) & 0x55555555u; x1 ^= t; x0 ^= t << 1;
-    t = ((x2 >> 1) ^ x3) & 0x55555555u; x3 ^= t; x2 ^= t << 1;
-    t = ((x0 >> 2) ^ x2) & 0x33333333u; x2 ^= t; x0 ^= t << 2;
-    t = ((x1 >> 2) ^ x3) & 0x33333333u; x3 ^= t; x1 ^= t << 2;
-    P[0] = x0; P[1] = x1; P[2] = x2; P[3] = x3;
-}
-
-__device__ __forceinline__ unsigned long long th4_count_full_block(const uint32_t w[8])
-{
-    uint32_t A[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        uint32_t v[4];
-        th4_planes(w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3], v);
-        const uint32_t low = v[1] | v[0];
-        A[h][0] = v[0];
-        A[h][1] = v[1] ^ (v[3] & v[0]);
-        A[h][2] = v[2] ^ (v[3] & low);
-        A[h][3] = v[3] & ~(v[2] | low);
-    }
-    uint32_t c[9], sum = 0;
-#pragma unroll
-    for (int m = 1; m <= 7; m++) {
-        uint32_t n = 0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t b2 = (m & 4) ? A[h][2] : ~A[h][2], b1 = (m & 2) ? A[h][1] : ~A[h][1], b0 = (m & 1) ? A[h][0] : ~A[h][0];
-            n += __popc(b2 & b1 & b0);
-        }
-        c[m] = n;
-        sum += n;
-    }
-    c[8] = __popc(A[0][3]) + __popc(A[1][3]);
-    c[0] = 64u - sum - c[8];
-    // fields of 7 bits at bit 7 m: m = 0..3 in the low word, m = 4 straddles bit 32
-    const uint32_t lo = c[0] | (c[1] << 7) | (c[2] << 14) | (c[3] << 21) | (c[4] << 28);
-    const uint32_t hi = (c[4] >> 4) | (c[5] << 3) | (c[6] << 10) | (c[7] << 17) | (c[8] << 24);
-    return ((unsigned long long)hi << 32) | lo;
 }
 
 // every block's 9 magnitude counts, and a clean slate for all three histograms
@@ -1265,9 +1303,16 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
     hipStream_t st = as_stream(stream);
     if (k >= n || n == 0) return CLV_OK;                       // everything survives
     if (n_pad <= (uint64_t)TS_THREADS * TS_MAXW * 8) {
-        const size_t lds = thresh_small_lds(n);                                    // up to 92 KiB
-        if (lds > 64 * 1024) CLV_HIP(hipFuncSetAttribute((const void *)k_thresh_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_thresh_small, dim3(1), dim3(TS_THREADS), lds, st, (uint32_t *)q, s, (uint32_t)n, (uint32_t)k);
+        const uint64_t wpt = ((n + 7) / 8 + TS_THREADS - 1) / TS_THREADS;         // words per thread
+#define T4_LAUNCH(W) hipLaunchKernelGGL(k_thresh_small<W>, dim3(1), dim3(TS_THREADS), 0, st, (uint32_t *)q, s, (uint32_t)n, (uint32_t)k)
+        // (fewer, fatter threads -- W = 8 so that every block is one thread's and the tables need no atomics -- were measured slower at
+        //  N = 8192 and 32768: 7.7 / 12.4 us against 5.4 / 10.9)
+        if (wpt <= 1) T4_LAUNCH(1);
+        else if (wpt <= 2) T4_LAUNCH(2);
+        else if (wpt <= 4) T4_LAUNCH(4);
+        else if (wpt <= 8) T4_LAUNCH(8);
+        else T4_LAUNCH(16);
+#undef T4_LAUNCH
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
