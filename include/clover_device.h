@@ -88,6 +88,10 @@
 #define CLOVER_HIP_NO_PAGE_TRACKING 1
 #endif
 
+#ifdef CLOVER_HIP_TEST_MPROTECT_ENOMEM
+static int clover_hip_test_mprotect_enomem = 0;      /* tests set it to 1: the next restricting mprotect calls "fail" with ENOMEM */
+#endif
+
 namespace clover_hip {
 
 inline void check(int rc, const char *what)
@@ -255,7 +259,8 @@ class Mirror {
 public:
     enum State { HOST_DIRTY, SHARED, DEVICE_DIRTY };
 
-    Mirror() : host_(nullptr), alias_(nullptr), dev_(nullptr), bytes_(0), span_(0), state_(HOST_DIRTY), owns_host_(true), mapped_(false), pending_(false), version_(0), pins_(0), spurious_(0) {}
+    Mirror() : host_(nullptr), alias_(nullptr), dev_(nullptr), bytes_(0), span_(0), state_(HOST_DIRTY), owns_host_(true), mapped_(false), pending_(false), untracked_(false), restricted_(false), version_(0), pins_(0), spurious_(0) {}
+    bool tracked() const { return !untracked_; }
     ~Mirror() { release(); }
     Mirror(const Mirror &) = delete;
     Mirror &operator=(const Mirror &) = delete;
@@ -301,6 +306,7 @@ public:
 #ifdef CLOVER_HIP_NO_PAGE_TRACKING
         return host_rw();
 #else
+        if (untracked_) return host_rw();          /* a block whose protection the kernel refused (ENOMEM): explicit-residency rules */
         host_ro();                                 /* (a view aliases caller memory, which is always current: write-through) */
         return host_;
 #endif
@@ -431,12 +437,28 @@ private:
     void protect(int prot)
     {
 #ifndef CLOVER_HIP_NO_PAGE_TRACKING
-        if (owns_host_ && host_ && mprotect(host_, span_, prot) != 0) {
-            static const char msg[] = "mprotect failed. Exiting ...\n";      /* may run in signal context: write(2), _exit(2) */
-            ssize_t w = write(1, msg, sizeof(msg) - 1);
+        if (untracked_ || !owns_host_ || !host_) return;
+        int rc;
+#ifdef CLOVER_HIP_TEST_MPROTECT_ENOMEM                                    /* tests: pretend the kernel ran out of map entries */
+        if (prot != (PROT_READ | PROT_WRITE) && clover_hip_test_mprotect_enomem) { rc = -1; errno = ENOMEM; }
+        else
+#endif
+        rc = mprotect(host_, span_, prot);
+        if (rc == 0) { if (prot != (PROT_READ | PROT_WRITE)) restricted_ = true; return; }
+        if (errno == ENOMEM && prot != (PROT_READ | PROT_WRITE) && !restricted_) {
+            /* vm.max_map_count reached (a plain-allocation block: protecting a part of the heap splits its mapping).  The block was
+             * never restricted, so it can simply stay open: from here on it follows the EXPLICIT-RESIDENCY rules (getData() pulls and
+             * marks the host copy; a pointer kept across a device operation shows the bytes from before it) instead of ending the process */
+            untracked_ = true;
+            static const char msg[] = "clover_hip: mprotect: out of map entries, a block falls back to explicit residency\n";
+            ssize_t w = write(2, msg, sizeof(msg) - 1);
             (void)w;
-            _exit(1);
+            return;
         }
+        static const char msg[] = "mprotect failed. Exiting ...\n";          /* may run in signal context: write(2), _exit(2) */
+        ssize_t w = write(1, msg, sizeof(msg) - 1);
+        (void)w;
+        _exit(1);
 #else
         (void)prot;
 #endif
@@ -508,6 +530,7 @@ private:
         span_ = 0;
         state_.store(HOST_DIRTY, std::memory_order_release);
         pending_ = false;
+        untracked_ = restricted_ = false;
     }
     /* the host block: two mappings of one anonymous memory file where the platform has memfd_create (tracked builds), else one
      * page-aligned allocation as in the reference (CloverVector4.h:70-79) */
@@ -548,6 +571,8 @@ private:
     bool owns_host_;
     bool mapped_;                      /* host_/alias_ are two mmaps of one memfd (else: posix_memalign, alias_ == host_) */
     bool pending_;
+    bool untracked_;                   /* mprotect refused with ENOMEM before the block was ever restricted: explicit-residency rules from then on */
+    bool restricted_;                  /* a restricting mprotect has succeeded on this block */
     uint64_t version_;                 /* see device_version() */
     detail::SpinLock lock_;            /* every state change of this block, from methods and from the fault handler */
     std::atomic<int> pins_;            /* fault handlers between table lookup and resolution: the destructor waits for 0 */

@@ -1,0 +1,47 @@
+// mirror_enomem.cpp -- a block whose page protection the kernel refuses with ENOMEM (vm.max_map_count reached) falls back to the
+// explicit-residency rules instead of ending the process (include/clover_device.h, Mirror::protect).  No GPU: linked against
+// tests/cpp/fake_clv.c; the refusal is injected with -DCLOVER_HIP_TEST_MPROTECT_ENOMEM.
+#include <cstdio>
+#include <cstring>
+
+#include "clover_device.h"
+
+extern "C" int fake_copies_d2h, fake_copies_h2d;
+using clover_hip::Mirror;
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAILED line %d: %s\n", __LINE__, #cond); failures++; } } while (0)
+
+int main()
+{
+    // 1. a block that is refused from its first restriction on: explicit rules, right results through re-taken pointers and accessors
+    clover_hip_test_mprotect_enomem = 1;
+    Mirror m;
+    m.allocate(10000);
+    memset(m.host_ptr(), 1, 10000);
+    const uint8_t *d = m.dev_ro();                      // upload: the PROT_READ step "fails" -> the block stays open, untracked
+    EXPECT(!m.tracked() && d[9999] == 1 && fake_copies_h2d == 1);
+    m.host_ptr()[5] = 7;                                // getData() again: marks the host copy as the one that counts
+    EXPECT(m.dev_ro()[5] == 7 && fake_copies_h2d == 2);
+    memset(m.dev_wo(), 9, 10000);                       // a "kernel" writes the device copy
+    m.commit();
+    EXPECT(m.host_ro()[100] == 9 && fake_copies_d2h == 1);        // accessor: pulls
+    memset(m.dev_wo(), 4, 10000);
+    EXPECT(m.host_ptr()[200] == 4);                     // pointer re-taken after the device operation: pulls
+    m.host_rw()[0] = 43;
+    EXPECT(m.dev_ro()[0] == 43);
+    // 2. blocks allocated while the kernel co-operates stay tracked, and a tracked block next to an untracked one still works
+    clover_hip_test_mprotect_enomem = 0;
+    Mirror t;
+    t.allocate(8192);
+    uint8_t *p = t.host_ptr();
+    memset(p, 2, 8192);
+    t.dev_ro();
+    EXPECT(t.tracked() && t.state() == Mirror::SHARED);
+    memset(t.dev_wo(), 6, 8192);
+    EXPECT(p[8000] == 6 && t.state() == Mirror::SHARED);          // kept pointer: fault -> copy back
+    // 3. a block that HAS been restricted before keeps its protection when a later mprotect is refused?  No: that would leave pages
+    //    the state machine cannot account for -- such a refusal is fatal (checked by reading the code path, not by dying here)
+    std::printf(failures ? "mirror enomem FAILED\n" : "mirror enomem ok\n");
+    return failures ? 1 : 0;
+}

@@ -33,6 +33,16 @@ def test_mirror_state_machine_with_fake_device(tmp_path, opt):
     assert p.returncode == 0 and "mirror ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
 
 
+def test_mprotect_enomem_degrades_to_explicit_residency(tmp_path):
+    """a refused mprotect (vm.max_map_count) must not end the process: the block falls back to the explicit-residency rules"""
+    obj, exe = tmp_path / "fake_clv.o", tmp_path / "mirror_enomem"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-c", f"-I{ROOT / 'include'}", str(CPP / "fake_clv.c"), "-o", str(obj)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_HIP_TEST_MPROTECT_ENOMEM", f"-I{ROOT / 'include'}",
+                    str(CPP / "mirror_enomem.cpp"), str(obj), "-o", str(exe), "-lpthread"], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "mirror enomem ok" in p.stdout and "falls back to explicit residency" in p.stderr, (p.returncode, p.stdout, p.stderr)
+
+
 def _build_mirror_threads(tmp_path, *flags):
     obj, exe = tmp_path / "fake_clv.o", tmp_path / "mirror_threads"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-c", f"-I{ROOT / 'include'}", str(CPP / "fake_clv.c"), "-o", str(obj)], check=True)
