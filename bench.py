@@ -244,6 +244,9 @@ def main() -> None:
                          "0.349 ms per step against 0.330 in steady state).  Reported in the JSON; 0 switches it off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-one-process", action="store_true",
+                    help="leave out the `one_process` and `gemm_sharded` objects (the product's clm4_sharded_* loops over the same N devices, "
+                         "driven by rank 0 behind the ranks' timed regions)")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--gemm-probe-child", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -477,7 +480,7 @@ def main() -> None:
             c5 = {"skipped": f"{c5_total} rows do not split into {world} equal shards of whole 64-row blocks"}
         else:
             head_A, head_sA, head_res = head.pop("A"), head.pop("sA"), head.pop("res")
-            keep_for_cpu = world == 1 and not args.no_cpu_baseline
+            keep_for_cpu = rank == 0 and not args.no_cpu_baseline
             if not keep_for_cpu:
                 del head_A, head_sA
             torch.cuda.empty_cache()
@@ -507,6 +510,7 @@ def main() -> None:
             }
 
     if rank != 0:
+        dist.barrier()                                           # pairs with rank 0's barrier in front of its one-process loops
         dist.destroy_process_group()
         return
 
@@ -567,6 +571,23 @@ def main() -> None:
         out["roofline"]["traffic"] = tr[0]
         out["roofline"]["traffic_source"] = f"profiles/{tr[1]} (FETCH_SIZE x1024 x2 gfx950 correction + WRITE_SIZE x1024, per launch)"
 
+    # The product's own multi-GPU loops, timed by the very command the driver runs: rank 0 -- the other ranks have left their timed regions
+    # and are idle or gone -- drives all N devices through the C ABI: `one_process` = clm4_sharded_mvm_enqueue over the same shards (c3
+    # headline + c5), `gemm_sharded` = configs[3] split by rows of A with the C row panels all-gathered
+    if dist_on:
+        dist.barrier()                                           # every rank is past its last kernel and collective
+        dist.destroy_process_group()                             # torch's RCCL communicators are gone before the product builds its own
+    n_dev = world
+    if not args.no_one_process and (world == 1 or debug_one_gpu or torch.cuda.device_count() >= world):
+        for key, fn in (("one_process", one_process_object), ("gemm_sharded", gemm_sharded_measure)):
+            try:
+                torch.cuda.empty_cache()
+                out[key] = fn(args, torch, hip, n_dev)
+            except Exception as e:                               # noqa: BLE001 -- a side measurement must never cost the headline line
+                out[key] = {"failed": f"{type(e).__name__}: {e}"[:400]}
+        hip.check(lib.clv_set_device(dev_index))
+        torch.cuda.set_device(dev_index)
+
     # side measurements first, while the chip is warm from the timed loop (the matrix pipe's clocks need ~50 calls to settle after an idle
     # period, and the CPU baseline below leaves the GPU idle for half a minute: round 3 measured the GEMM 5 % slower behind it)
     if world == 1 and not args.no_extras:
@@ -576,7 +597,7 @@ def main() -> None:
             except Exception as e:
                 out[key] = {"failed": f"{type(e).__name__}: {e}"}
 
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:                                  # rank 0's own shard (the whole C3 matrix by default), at every N
         try:
             res = head["res"]
             out["cpu_baseline"] = run_cpu_baseline(hip, head["A"], head["sA"], x, sx, res[: rows // 2], res[rows // 2:].view(torch.float32),
@@ -595,8 +616,6 @@ def main() -> None:
     except (KeyError, TypeError):
         pass
     print(json.dumps(out))
-    if dist_on:
-        dist.destroy_process_group()
 
 
 def self_launch(args) -> None:
@@ -617,18 +636,24 @@ def self_launch(args) -> None:
 
 
 def one_process_main(args, torch, CloverHip) -> None:
+    """`--mode one-process`: the line of one_process_measure on its own."""
+    print(json.dumps(one_process_measure(args, torch, CloverHip(device=0), args.gpus)))
+
+
+def one_process_measure(args, torch, hip, n: int) -> dict:
     """N GPUs driven by THIS process through the C ABI (clm4_sharded_create / _set_x / _loop_begin / _mvm_enqueue / _sync): the product's
     own multi-GPU path, timed as it would run inside an application loop.  A step = every shard's kernel on its device's compute stream +
     one grouped in-place ncclAllGather pair on its exchange stream (overlapping the next step's kernel); no host synchronisation inside
     the timed region.  CLOVER_BENCH_DEBUG_ONE_GPU=1 lists device 0 N times (exchanges become copies): a rehearsal, not a measurement.
-    Without --preset the line also carries the `c5` object (BASELINE configs[4] split N ways), as in ranks mode."""
+    Without --preset the result also carries the `c5` object (BASELINE configs[4] split N ways), as in ranks mode.  Returns the JSON
+    object: printed as the line by --mode one-process, merged as `one_process` into the line of a ranks run (rank 0, after the ranks'
+    timed regions -- the other ranks are idle by then)."""
     import ctypes as C
 
     import numpy as np
     debug = os.environ.get("CLOVER_BENCH_DEBUG_ONE_GPU") == "1"
-    n = args.gpus
-    hip = CloverHip(device=0)
     lib = hip.lib
+    hip.check(lib.clv_set_device(0))
     scaling = "weak"
     preset = args.preset or "c3"
     if preset == "c5-weak":
@@ -772,7 +797,124 @@ def one_process_main(args, torch, CloverHip) -> None:
     if tr:
         out["roofline"]["traffic"] = tr[0]
         out["roofline"]["traffic_source"] = f"profiles/{tr[1]}"
-    print(json.dumps(out))
+    return out
+
+
+def one_process_object(args, torch, hip, n: int) -> dict:
+    """one_process_measure as an object of the ranks line: the step time of the product's own loop beside the ranks' (torch.distributed)"""
+    o = one_process_measure(args, torch, hip, n)
+    cfg = o["config"]
+    return {
+        "what": "the same shards through the product's own loop: ONE process drives the N devices (clm4_sharded_create / _set_x / _loop_begin / "
+                "_mvm_enqueue / _sync), RCCL through dlopen, grouped in-place ncclAllGather pair per step on a second stream per device",
+        "workload": cfg["workload"], "n_gpus": o["n_gpus"], "steps": o["steps"], "warmup": o["warmup"], "settle_launches": cfg["settle_launches"],
+        "ms_per_step": o["ms_per_step"], "value": o["value"], "unit": o["unit"],
+        "frac": round(o["value"] / (n * HBM_PEAK_GBS), 4), "frac_of": f"{n} x {HBM_PEAK_GBS:g} GB/s",
+        "kernel_avg_ms": o["roofline"]["kernel_avg_ms"], "kernel_frac": o["roofline"]["frac"],
+        "per_rank_kernel_ms": cfg["per_rank_kernel_ms"], "gather_ms_behind_kernel": cfg["gather_ms_behind_kernel"],
+        "gather_bytes_per_rank": cfg["gather_bytes_per_rank"], "gathered_result_verified": cfg["gathered_result_verified"],
+        "rccl_ranks": cfg["rccl_ranks"], "backend": cfg["backend"],
+        **({"degraded": True, "degraded_why": o["degraded_why"], "value_kernel_only": o["value_kernel_only"]} if o.get("degraded") else {}),
+        **({"c5": o["c5"]} if "c5" in o else {}),
+    }
+
+
+def gemm_sharded_measure(args, torch, hip, n: int) -> dict:
+    """BASELINE configs[3] (CloverMatrix4 GEMM G^3, G = 8192) split by rows of A over the N GPUs -- mvm_parallel's row split
+    (CloverMatrix4.h:1700-1705) applied to C = A * B^T: G / N rows of A per device (multiples of 128), B replicated, and the fp32 C ROW
+    PANELS ALL-GATHERED over RCCL on each device's exchange stream, through the product's own loop (clm4_sharded_gemm_begin /
+    _enqueue / _sync) driven by this one process.  A step = every device's clm4_gemm (FP6 re-code + MFMA kernel) + one in-place
+    ncclAllGather of the panel it produced; the gather of step i overlaps the kernel of step i + 1 (two C buffers).  Strong scaling: the
+    exchange moves (N-1)/N of the 4 G^2 bytes of C into every device, so beyond N = 1 the step is exchange-bound -- both figures are
+    reported: `value` (whole step) and `kernel_only_aggregate_TOPs`.  The gathered C of the first and the last device are compared
+    with the unsharded clm4_gemm, bit for bit."""
+    import ctypes as C
+
+    import numpy as np
+    debug = os.environ.get("CLOVER_BENCH_DEBUG_ONE_GPU") == "1"
+    lib = hip.lib
+    G = int(os.environ.get("CLOVER_BENCH_GEMM_SIZE", str(args.gemm_size)))
+    if G % (128 * n) != 0:
+        return {"skipped": f"{G} rows of A do not split into {n} equal shards of whole 128-row units"}
+    steps, warm = 60, 80
+    hip.check(lib.clv_set_device(0))
+    B = torch.empty(G * G // 2, dtype=torch.uint8, device="cuda:0")
+    sB = torch.empty((G // 64) ** 2, dtype=torch.float32, device="cuda:0")
+    hip.check(lib.clv_fill_random_nibbles(B.data_ptr(), B.numel(), 22, 0, None))
+    hip.check(lib.clv_fill_random_scales(sB.data_ptr(), sB.numel(), 24, 0, None))
+    torch.cuda.synchronize()
+    devs = (C.c_int * n)(*([0] * n if debug else range(n)))
+    ctx = C.c_void_p()
+    hip.check(lib.clm4_sharded_create(C.byref(ctx), n, devs, G, G))
+    try:
+        hip.check(lib.clm4_sharded_fill_random(ctx, 21))                      # A: nibbles seed 21, tile scales seed 22 (= 21 + 1)
+        hip.check(lib.clm4_sharded_gemm_begin(ctx, B.data_ptr(), sB.data_ptr(), G, 0, steps))
+        for w_ in range(warm):                                                # the matrix pipe's clocks settle after ~50 calls
+            hip.check(lib.clm4_sharded_gemm_enqueue(ctx, w_, 0))
+        hip.check(lib.clm4_sharded_sync(ctx))
+        t0 = time.perf_counter()
+        for i in range(steps):
+            hip.check(lib.clm4_sharded_gemm_enqueue(ctx, i, 1))
+        hip.check(lib.clm4_sharded_sync(ctx))
+        elapsed = time.perf_counter() - t0
+        per_k, per_g = [], []
+        km, gm = C.c_float(), C.c_float()
+        for d in range(n):
+            ks = gs = 0.0
+            for i in range(steps):
+                hip.check(lib.clm4_sharded_step_timing(ctx, d, i, C.byref(km), C.byref(gm)))
+                ks += km.value
+                gs += gm.value
+            per_k.append(ks / steps)
+            per_g.append(gs / steps)
+        ranks, equal = C.c_int(), C.c_int()
+        hip.check(lib.clm4_sharded_comm_info(ctx, C.byref(ranks), C.byref(equal)))
+        full = []
+        for d in sorted({0, n - 1}):
+            cp = C.c_void_p()
+            hip.check(lib.clm4_sharded_gemm_full(ctx, d, (steps - 1) & 1, C.byref(cp)))
+            host = np.empty(G * G, np.float32)
+            hip.check(lib.clv_set_device(0 if debug else d))
+            hip.check(lib.clv_memcpy_d2h(host.ctypes.data, cp, host.nbytes, None))
+            hip.check(lib.clv_device_sync())
+            full.append(host)
+        hip.check(lib.clv_set_device(0))
+    finally:
+        lib.clm4_sharded_destroy(ctx)
+        hip.check(lib.clv_set_device(0))
+    # the unsharded product of the same (regenerated) operands on device 0
+    A0 = torch.empty(G * G // 2, dtype=torch.uint8, device="cuda:0")
+    sA0 = torch.empty((G // 64) ** 2, dtype=torch.float32, device="cuda:0")
+    C0 = torch.empty(G * G, dtype=torch.float32, device="cuda:0")
+    hip.check(lib.clv_fill_random_nibbles(A0.data_ptr(), A0.numel(), 21, 0, None))
+    hip.check(lib.clv_fill_random_scales(sA0.data_ptr(), sA0.numel(), 22, 0, None))
+    hip.check(lib.clm4_gemm(A0.data_ptr(), sA0.data_ptr(), G, G, B.data_ptr(), sB.data_ptr(), G, C0.data_ptr(), None))
+    torch.cuda.synchronize()
+    ref = C0.cpu().numpy().view(np.uint32)
+    verified = all(np.array_equal(f.view(np.uint32), ref) for f in full)
+    del A0, sA0, C0, B, sB
+    torch.cuda.empty_cache()
+    ops = 2.0 * G ** 3
+    ms = elapsed / steps * 1e3
+    kmax = max(per_k)
+    tops, ktops = ops / ms / 1e9, ops / kmax / 1e9
+    degraded = debug or (n > 1 and not ranks.value)
+    return {
+        "workload": f"CloverMatrix4::gemm {G}x{G}x{G} int4 x int4 -> fp32" + (" (BASELINE configs[3])" if G == 8192 else " (NOT configs[3]: shrunk)")
+                    + f", rows of A split {n} way(s): {G // n} rows per GPU, B replicated, fp32 C row panels all-gathered",
+        "scaling": "strong", "n_gpus": n, "rows_per_gpu": G // n, "steps": steps, "warmup": warm, "mode": "one-process (clm4_sharded_gemm_begin / _enqueue)",
+        "ms_per_step": round(ms, 5), "value": round(tops, 1), "unit": "TOP/s",
+        "frac": round(tops / (n * FP6_PEAK_TOPS), 4), "frac_of": f"{n} x {FP6_PEAK_TOPS:g} TOP/s (dense FP6 MFMA, the pipe the kernel runs on)",
+        "per_rank_kernel_ms": [round(v, 5) for v in per_k], "kernel_only_aggregate_TOPs": round(ktops, 1),
+        "kernel_only_frac": round(ktops / (n * FP6_PEAK_TOPS), 4),
+        "gather_ms_behind_kernel": [round(v, 5) for v in per_g],
+        "gather_bytes_received_per_rank": (n - 1) * (G // n) * G * 4, "c_panel_bytes": (G // n) * G * 4,
+        "exchange": ("device copies (same-device rehearsal)" if debug else "ncclAllGather of the fp32 panels, in place, one per device and step"
+                     if ranks.value and equal.value else "none (one shard)" if n == 1 and not ranks.value else "per-owner ncclBroadcast"),
+        "rccl_ranks": ranks.value, "gathered_c_verified": bool(verified),
+        "verified_how": "the whole C held by the first and the last device after the last step == clm4_gemm of the unsharded operands, all bits",
+        **({"degraded": True} if degraded else {}),
+    }
 
 
 def packed_bytes_of(rows: int) -> int:
@@ -1058,6 +1200,118 @@ def hbm_resident(hip, torch, dev, stream) -> dict:
     }
 
 
+def iht_through_headers() -> dict:
+    """tools/iht_dropin.cpp: Q_IHT of include/CloverIHT.h on container objects (the reference's caller, 01_measure.h:923-946), N = 8192, in
+    both container builds (page-tracked mirrors / -DCLOVER_HIP_EXPLICIT_SYNC) and both settings of the exactness switch; compiled here
+    with g++ against the in-tree library (a few seconds), run as child processes"""
+    from clover_amd.build import hip_library_path
+    lib = hip_library_path()
+    outd = ROOT / "tools" / "_build"
+    outd.mkdir(parents=True, exist_ok=True)
+    res = {}
+    for key, flags in (("page_tracked", []), ("explicit_sync", ["-DCLOVER_HIP_EXPLICIT_SYNC"])):
+        exe = outd / f"iht_dropin_{key}"
+        try:
+            subprocess.run(["g++", "-std=c++11", "-O2", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", *flags, f"-I{ROOT / 'include'}", str(ROOT / "tools" / "iht_dropin.cpp"),
+                            "-o", str(exe), f"-L{lib.parent}", "-lclover_hip", f"-Wl,-rpath,{lib.parent}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"],
+                           check=True, capture_output=True, text=True, timeout=300)
+            out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=300).stdout
+            res[key] = json.loads(out.strip().splitlines()[-1])
+        except Exception as e:                                    # noqa: BLE001
+            res[key] = {"failed": f"{type(e).__name__}: {e}"[:300]}
+    res["what"] = ("us per iteration of Q_IHT(Phi, PhiT, x, y, t1, t2, t3, iterations, K, mu) through include/CloverIHT.h with CloverMatrix4 / "
+                   "CloverVector4 (fast, reference_bits) and CloverVector8 (_v8) objects, wall clock incl. reading x back; fast_generic_five_calls = the "
+                   "reference's five-call template unchanged; reference_bits = the default build of the headers (threshold = the reference's heap walk)")
+    return res
+
+
+INFINITY_CACHE_BYTES = 256 << 20
+
+
+def published_sizes(hip, torch, dev, stream) -> dict:
+    """The sizes the REFERENCE publishes for this path (doc/results/performance.txt: mvm 8192^2 / 32768^2 at :357, 369, 438, 450; dot
+    n = 2^24 / 2^26 / 2^29 at :171-176, 202-207), plus 16384^2 and C3, each measured two ways and labelled:
+      warm = the same operands again and again (what fits stays in the 8 x 4 MiB of L2 / the 256 MiB Infinity Cache),
+      cold = a rotation over distinct operands whose total footprint exceeds the Infinity Cache (every call streams from HBM).
+    An operand set that exceeds the cache by itself is HBM-resident either way.  HIP events on the launch stream, mean over the calls."""
+    from clover_amd.lib_binding import DOT_FAST
+    lib = hip.lib
+    pool = torch.empty(2 << 30, dtype=torch.uint8, device=dev)                 # nibbles of every matrix / vector below
+    spool = torch.empty(1 << 24, dtype=torch.float32, device=dev)              # their scales (64 MiB)
+    hip.check(lib.clv_fill_random_nibbles(pool.data_ptr(), pool.numel(), 71, 0, stream))
+    hip.check(lib.clv_fill_random_scales(spool.data_ptr(), spool.numel(), 72, 0, stream))
+    x = torch.empty(65536 // 2, dtype=torch.uint8, device=dev)
+    sx = torch.empty(65536 // 64, dtype=torch.float32, device=dev)
+    r = torch.empty(65536 // 2, dtype=torch.uint8, device=dev)
+    sr = torch.empty(65536 // 64, dtype=torch.float32, device=dev)
+    o = torch.empty(1, dtype=torch.float32, device=dev)
+    hip.check(lib.clv_fill_random_nibbles(x.data_ptr(), x.numel(), 73, 0, stream))
+    hip.check(lib.clv_fill_random_scales(sx.data_ptr(), sx.numel(), 74, 0, stream))
+    ref_mvm = {8192: (8533.23, 23250.02, "performance.txt:357, 438"), 16384: (8214.25, 21316.01, "performance.txt:361, 442"),
+               32768: (8193.62, 21409.47, "performance.txt:369, 450")}
+    ref_dot = {24: (15031.08, 24385.78, "performance.txt:171, 202"), 26: (14169.39, 21045.92, "performance.txt:173, 204"),
+               29: (14340.13, 21040.33, "performance.txt:176, 207")}
+
+    def entry(nbytes, ms, footprint, rotation):
+        gbs = nbytes / ms / 1e6
+        return {"ms": round(ms, 5), "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
+                "resident": ("HBM" if footprint > INFINITY_CACHE_BYTES else "cache") + f" ({footprint >> 20} MiB touched" + (f", {rotation}" if rotation else "") + ")"}
+
+    def rotate(fn_of_k, count):                  # one call per operand set, round-robin
+        state = [0]
+
+        def fn():
+            fn_of_k(state[0] % count)
+            state[0] += 1
+        return fn
+
+    sweep = []
+    for S in (8192, 16384, 32768, 65536):
+        mat, nsc = S * S // 2, (S // 64) ** 2
+        nmat = max(1, min(pool.numel() // mat, max(2, -(-(3 * INFINITY_CACHE_BYTES) // mat))))     # >= 768 MiB of distinct matrices where the pool allows
+        nb = mvm_bytes(S, S)
+
+        def call(k, S=S, mat=mat, nsc=nsc):
+            hip.check(lib.clm4_mvm(pool.data_ptr() + k * mat, spool.data_ptr() + 4 * k * nsc, S, S, x.data_ptr(), sx.data_ptr(), r.data_ptr(), sr.data_ptr(), None, stream))
+        reps = max(20, min(400, int(40e-3 / (nb / 5e12))))                      # about 40 ms of work per timing
+        warm = _timeit(torch, lambda: call(0), reps, warm=max(3, reps // 10))
+        row = {"size": f"{S}x{S}", "algorithmic_bytes": nb, "workgroups": S // 64, "warm": entry(nb, warm, mat, None)}
+        if nmat > 1:
+            reps_c = -(-reps // nmat) * nmat
+            cold = _timeit(torch, rotate(call, nmat), reps_c, warm=nmat)
+            row["cold"] = entry(nb, cold, nmat * mat, f"{nmat} distinct matrices round-robin")
+        else:
+            row["cold"] = dict(row["warm"], note="one matrix exceeds the Infinity Cache by itself: warm == cold")
+        if S in ref_mvm:
+            row["reference_published_MiBs"] = {"sequential": ref_mvm[S][0], "4_threads": ref_mvm[S][1], "source": ref_mvm[S][2],
+                                               "hardware": "Xeon E3-1285L v3, 4 cores, 25.6 GB/s DRAM"}
+        sweep.append(row)
+
+    dots = []
+    for logn in (24, 26, 29):
+        n = 1 << logn
+        pair, spair = n, 2 * (n // 64)                                          # bytes of nibbles / floats of scales per operand pair
+        npairs = max(1, min(pool.numel() // pair, spool.numel() // spair, max(2, -(-(3 * INFINITY_CACHE_BYTES) // (pair * 9 // 8)))))
+        nb = 1.125 * n
+
+        def call(k, n=n, pair=pair, spair=spair):
+            qa, sa = pool.data_ptr() + k * pair, spool.data_ptr() + 4 * k * spair
+            hip.check(lib.clv4_dot(qa, sa, qa + n // 2, sa + 4 * (n // 64), n, DOT_FAST, o.data_ptr(), None, stream))
+        reps = max(20, min(400, int(40e-3 / (nb / 5e12))))
+        warm = _timeit(torch, lambda: call(0), reps, warm=max(3, reps // 10))
+        row = {"n": n, "algorithmic_bytes": int(nb), "warm": entry(nb, warm, int(nb), None)}
+        if npairs > 1:
+            cold = _timeit(torch, rotate(call, npairs), -(-reps // npairs) * npairs, warm=npairs)
+            row["cold"] = entry(nb, cold, int(npairs * nb), f"{npairs} distinct operand pairs round-robin")
+        else:
+            row["cold"] = dict(row["warm"], note="one operand pair exceeds the Infinity Cache by itself: warm == cold")
+        row["reference_published_MiBs"] = {"sequential": ref_dot[logn][0], "4_threads": ref_dot[logn][1], "source": ref_dot[logn][2],
+                                           "hardware": "Xeon E3-1285L v3, 4 cores, 25.6 GB/s DRAM"}
+        dots.append(row)
+    return {"what": published_sizes.__doc__.split("\n\n")[0].replace("\n    ", " "),
+            "mvm_sweep": sweep, "dot_fast": dots}
+
+
 def extras(hip, torch, dev, stream) -> dict:
     """Secondary numbers of the same path.  `hbm_resident`: configs[1]'s operations at n = 2^30, each with its own achieved / peak /
     frac.  The n = 2^24 figures of configs[1] itself fit the 256 MiB Infinity Cache: cache-resident rates, kept as a footnote."""
@@ -1166,8 +1420,20 @@ def extras(hip, torch, dev, stream) -> dict:
            "note": "Q_IHT step sequence (mvm, scaleAndAdd, mvm^T, scaleAndAdd, threshold) at N=8192 (4096x8192), bytes counted like "
                    "01_measure.h:1117-1125; _v8 = the published configuration (4-bit matrix, 8-bit vectors); reference published "
                    "19.5 GB/s with 4 threads (performance.txt:581)"}
+    iht["through_headers"] = iht_through_headers()
+    try:
+        iht["header_overhead_vs_clm4_iht"] = round(iht["through_headers"]["page_tracked"]["us_per_iteration"]["fast"] / (g_ms * 1e3), 3)
+    except (KeyError, TypeError):
+        pass
+    del xs, ys, qa, qb, sa, sb
+    torch.cuda.empty_cache()
+    try:
+        published = published_sizes(hip, torch, dev, stream)
+    except Exception as e:                                          # noqa: BLE001
+        published = {"failed": f"{type(e).__name__}: {e}"[:300]}
     return {
         "hbm_resident_n2^30": hbm,
+        "published_sizes": published,
         "iht_iteration_N8192": iht,
         "footnote_cache_resident_n2^24": {
             "note": "BASELINE configs[1] sizes: the operands (76.5 MB / 18.9 MB) fit the 256 MiB Infinity Cache -- cache-resident, "

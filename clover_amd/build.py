@@ -80,7 +80,8 @@ def probe_library_path() -> Path:
 def build_probe_library(force: bool = False) -> Path:
     """libclover_hip_probe.so = the product's objects with gemm6.hip compiled a second time under -DCLV_GEMM_EXPERIMENTS: the GEMM main
     loop's timing-only variants with parts left out (tools/gen_gemm6_loop256.py ... experiments; results wrong by construction), selected
-    by CLV_GEMM_LOOP=vN.  It lives under tools/_build/, and clv_version() of it reads "clover_hip_probe ..." (load_library refuses that unless
+    by CLV_GEMM_LOOP=vN -- and matrix4.hip under -DCLV_EXPERIMENTS: the mvm kernel variants and the plain read-bandwidth kernel behind
+    tools/microbench.py (clvx_mvm_variant, clvx_read_bw).  It lives under tools/_build/, and clv_version() of it reads "clover_hip_probe ..." (load_library refuses that unless
     allow_probe=True).  BENCH INFRASTRUCTURE: bench.py's `gemm.ceiling` and tools/gemm_bench.py load it explicitly to measure what the
     arithmetic alone costs on the box the bench runs on; nothing else ever loads it and the product library has no such switch."""
     import sys
@@ -94,13 +95,18 @@ def build_probe_library(force: bool = False) -> Path:
     build_hip_library(force=force)
     obj_dir = hip_library_path().parent / "obj"
     gen = root / "tools" / "gen_gemm6_loop256.py"
-    deps = [src_dir / "gemm6.hip", gen, hip_library_path()] + list(src_dir.glob("*.h")) + list(src_dir.glob("*.inc"))
+    deps = [src_dir / "gemm6.hip", src_dir / "matrix4.hip", gen, hip_library_path()] + list(src_dir.glob("*.h")) + list(src_dir.glob("*.inc"))
     if force or _stale(out, deps):
         subprocess.run([sys.executable, str(gen), str(obj_dir / "gemm6_loop256_exp.inc"), "experiments"], check=True, stdout=subprocess.DEVNULL)
         obj = obj_dir / "gemm6_probe.o"
         subprocess.run([_hipcc(), *HIP_FLAGS, "-DCLV_GEMM_EXPERIMENTS", f"-I{root / 'include'}", f"-I{src_dir}", f"-I{obj_dir}", "-c", "-o", str(obj),
                         str(src_dir / "gemm6.hip")], check=True)
-        objs = [str(obj_dir / (Path(s).stem + ".o")) for s in HIP_SOURCES if s != "gemm6.hip"] + [str(obj)]
+        # matrix4.hip with its experiment entry points (clvx_read_bw, clvx_mvm_variant: tools/microbench.py, pmc_probe.py) -- the product
+        # library is compiled without them
+        obj_m = obj_dir / "matrix4_probe.o"
+        subprocess.run([_hipcc(), *HIP_FLAGS, "-DCLV_EXPERIMENTS", f"-I{root / 'include'}", f"-I{src_dir}", "-c", "-o", str(obj_m),
+                        str(src_dir / "matrix4.hip")], check=True)
+        objs = [str(obj_dir / (Path(s).stem + ".o")) for s in HIP_SOURCES if s not in ("gemm6.hip", "matrix4.hip")] + [str(obj), str(obj_m)]
         subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *objs, "-ldl"], check=True)
     return out
 

@@ -45,6 +45,8 @@ int clv_cu_count();
 // grow-only per-device scratch buffer used when the caller passes workspace == NULL
 int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream);      // grow-only scratch per (device, stream)
 void clv_internal_workspace_forget(hipStream_t stream);
+// zero-initialised hand-over slots per (device, stream), <= 64 KiB; every user leaves them zero again (runtime.hip)
+int clv_internal_sync_slots(void **ptr, uint64_t bytes, hipStream_t stream);
 
 // ---- device helpers ---------------------------------------------------------------------------
 #define CLV_RCP49 (1.0f / 49.0f)   // 0x3CA72F05, the reference's clover_mm256_rcp_49_ps (CloverBase.h:88)

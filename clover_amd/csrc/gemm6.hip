@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 3) void k_m4_gemm_fp6_asm(const uint8_t *__res
 #ifdef CLV_GEMM_EXPERIMENTS          // the bench-only probe library (clover_amd/build.py): the product's loops + timing-only variants
 #include "gemm6_loop256_exp.inc"
 // marks the library as the probe build: clv_version() then reads "clover_hip_probe ..." (runtime.hip), which load_library() refuses by default
-extern "C" const char *clvx_probe_tag(void) { return "clover_hip_probe 0.1 (gfx950; GEMM loop timing variants, results WRONG by construction)"; }
+extern "C" const char *clvx_probe_tag(void) { return "clover_hip_probe 0.1 (gfx950; GEMM loop timing variants -- results WRONG by construction -- and the mvm / read-bandwidth experiment kernels)"; }
 #else
 #include "gemm6_loop256.inc"
 #endif

@@ -430,7 +430,9 @@ static int launch_mvm(const int8_t *A, const float *sA, uint64_t rows, uint64_t 
     return CLV_OK;
 }
 
-// ---- experiments (not part of the public header): kernel variants for tools/microbench.py -------------
+// ---- experiments: kernel variants for tools/microbench.py.  Compiled ONLY into the bench-only probe build (-DCLV_EXPERIMENTS,
+// clover_amd/build.py build_probe_library -> tools/_build/libclover_hip_probe.so); the product library exports none of this ----------
+#ifdef CLV_EXPERIMENTS
 __global__ __launch_bounds__(256) void k_read_bw(const u32x4 *__restrict__ p, uint64_t n16, uint32_t *__restrict__ out, int nt)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -488,6 +490,7 @@ extern "C" int clvx_mvm_variant(int variant, const int8_t *A, const float *sA, u
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
+#endif      // CLV_EXPERIMENTS
 
 static int check_mvm_args(const char *fn, const void *A, const void *sA, uint64_t rows, uint64_t cols, const void *x, const void *sx)
 {

@@ -109,9 +109,13 @@ struct clm4_shard_ctx {
     std::vector<char> gpending;             // [2*d + buf]: gdone was recorded
     std::vector<hipEvent_t> slot_ev;        // [(3*step + e) * ndev + d]
     // GEMM (clm4_sharded_gemm): B replicated, one row shard of C per device
-    uint64_t gemm_n = 0;
+    uint64_t gemm_n = 0, gemm_b_n = 0;      // N the C shards / the replicated B are allocated for
     std::vector<int8_t *> B;
     std::vector<float *> sB, C;
+    // GEMM loop form (clm4_sharded_gemm_begin / _enqueue): two FULL C buffers per device, [2*d + buf]; device d computes its row panel
+    // in place and the panels are all-gathered on the exchange stream ("shard rows of A, replicate B, all-gather C row panels")
+    uint64_t gemm_loop_n = 0;
+    std::vector<float *> Cf;
 };
 
 // contiguous shards in units of 64 rows, remainder spread over the first ranks (as a static OpenMP split)
@@ -153,6 +157,8 @@ extern "C" int clm4_sharded_destroy(clm4_shard_ctx *c)
         void *gptrs[] = {d < (int)c->B.size() ? (void *)c->B[d] : nullptr, d < (int)c->sB.size() ? (void *)c->sB[d] : nullptr,
                          d < (int)c->C.size() ? (void *)c->C[d] : nullptr};
         for (void *p : gptrs) if (p) (void)hipFree(p);
+        for (int e = 0; e < 2; e++)
+            if (2 * d + e < (int)c->Cf.size() && c->Cf[2 * d + e]) (void)hipFree(c->Cf[2 * d + e]);
     }
     delete c;
     return CLV_OK;
@@ -573,6 +579,25 @@ extern "C" int clm4_sharded_result_buf(const clm4_shard_ctx *c, int part, int bu
     return CLV_OK;
 }
 
+// B (N x cols nibbles + tile scales) on every device, (re)allocated when N changes; shared by the blocking and the loop form
+static int gemm_ensure_B(clm4_shard_ctx *c, uint64_t N)
+{
+    if (c->gemm_b_n == N) return CLV_OK;
+    const uint64_t b_bytes = N * c->cols / 2, sb_count = (N / 64) * (c->cols / 64);
+    c->B.resize(c->ndev, nullptr); c->sB.resize(c->ndev, nullptr);
+    for (int d = 0; d < c->ndev; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        CLV_HIP(hipStreamSynchronize(c->st[d]));
+        if (c->B[d]) CLV_HIP(hipFree(c->B[d]));
+        if (c->sB[d]) CLV_HIP(hipFree(c->sB[d]));
+        c->B[d] = nullptr; c->sB[d] = nullptr;
+        CLV_HIP(hipMalloc((void **)&c->B[d], b_bytes));
+        CLV_HIP(hipMalloc((void **)&c->sB[d], sb_count * sizeof(float)));
+    }
+    c->gemm_b_n = N;
+    return CLV_OK;
+}
+
 // C = A * B^T with A the sharded matrix (rows x cols) and B an N x cols CloverMatrix4 replicated on every device: device d ends
 // with rows [row_begin_d, +row_count_d) of C (fp32, row-major, N columns).  Every element of C is its own fma chain over the
 // K-blocks, so the shards equal the unsharded clm4_gemm bit for bit and nothing needs to be exchanged; C_host
@@ -584,17 +609,17 @@ extern "C" int clm4_sharded_gemm(clm4_shard_ctx *c, const int8_t *B, const float
         CLV_REQUIRE(c->row_count[d] % 128 == 0, "clm4_sharded_gemm: shard %d has %llu rows, not a multiple of 128", d, (unsigned long long)c->row_count[d]);
     DeviceGuard guard;
     const uint64_t K = c->cols, b_bytes = N * K / 2, sb_count = (N / 64) * (K / 64);
-    if (c->gemm_n != N) {                                      // (re)allocate B and the C shards for this N
-        c->B.resize(c->ndev, nullptr); c->sB.resize(c->ndev, nullptr); c->C.resize(c->ndev, nullptr);
+    {
+        int brc = gemm_ensure_B(c, N);
+        if (brc != CLV_OK) return brc;
+    }
+    if (c->gemm_n != N) {                                      // (re)allocate the C shards for this N
+        c->C.resize(c->ndev, nullptr);
         for (int d = 0; d < c->ndev; d++) {
             CLV_HIP(hipSetDevice(c->dev[d]));
             CLV_HIP(hipStreamSynchronize(c->st[d]));
-            if (c->B[d]) CLV_HIP(hipFree(c->B[d]));
-            if (c->sB[d]) CLV_HIP(hipFree(c->sB[d]));
             if (c->C[d]) CLV_HIP(hipFree(c->C[d]));
-            c->B[d] = nullptr; c->sB[d] = nullptr; c->C[d] = nullptr;
-            CLV_HIP(hipMalloc((void **)&c->B[d], b_bytes));
-            CLV_HIP(hipMalloc((void **)&c->sB[d], sb_count * sizeof(float)));
+            c->C[d] = nullptr;
             CLV_HIP(hipMalloc((void **)&c->C[d], c->row_count[d] * N * sizeof(float)));
         }
         c->gemm_n = N;
@@ -626,5 +651,126 @@ extern "C" int clm4_sharded_gemm_result(const clm4_shard_ctx *c, int part, const
 {
     CLV_REQUIRE(c && part >= 0 && part < c->ndev && C_dev && c->gemm_n, "clm4_sharded_gemm_result: bad argument");
     *C_dev = c->C[part];
+    return CLV_OK;
+}
+
+// ---- GEMM, loop form with the C row panels all-gathered (round 5) -----------------------------------------------------------------
+// "GEMM: shard rows of A, replicate B, all-gather C row panels" -- the row split of mvm_parallel (CloverMatrix4.h:1700-1705)
+// applied to the M rows of C = A * B^T.  Every element of C is its own fma chain over the K-blocks, so a panel computed by
+// device d equals those rows of the unsharded clm4_gemm bit for bit; the exchange moves fp32 panels (rows_d x N x 4 bytes: 32 MiB per
+// device for configs[3] split 8 ways), ONE in-place ncclAllGather per device and step on the exchange stream.  Two full C buffers per
+// device: the gather of step i runs beside the kernel of step i + 1, and the kernel of step i + 2 waits on the device until the
+// gather of step i has left its buffer.  Ragged shards: one broadcast per owner; shards that repeat a device (test layout): copies.
+//     clm4_sharded_gemm_begin    B replicated (stream-ordered), both C buffers, exchange streams and `slots` event triples;
+//     clm4_sharded_gemm_enqueue  step i: clm4_gemm of the shard into its panel of C buffer i & 1, then the all-gather of that buffer;
+//     clm4_sharded_sync          the one host wait;
+//     clm4_sharded_step_timing   kernel (re-code + MFMA kernel) and exchange time of a timed step;
+//     clm4_sharded_gemm_full     device pointer of the whole C (rows x N fp32) in buffer `buf` on shard `part`.
+extern "C" int clm4_sharded_gemm_begin(clm4_shard_ctx *c, const int8_t *B, const float *sB, uint64_t N, int b_on_host, int slots)
+{
+    CLV_REQUIRE(c && B && sB && N && N % 128 == 0, "clm4_sharded_gemm_begin: bad argument");
+    for (int d = 0; d < c->ndev; d++)
+        CLV_REQUIRE(c->row_count[d] % 128 == 0, "clm4_sharded_gemm_begin: shard %d has %llu rows, not a multiple of 128", d, (unsigned long long)c->row_count[d]);
+    int rc = clm4_sharded_loop_begin(c, slots);
+    if (rc != CLV_OK) return rc;
+    DeviceGuard guard;
+    const int n = c->ndev;
+    const uint64_t K = c->cols, b_bytes = N * K / 2, sb_count = (N / 64) * (K / 64);
+    rc = gemm_ensure_B(c, N);
+    if (rc != CLV_OK) return rc;
+    if (c->gemm_loop_n != N) {
+        c->Cf.resize(2 * (size_t)n, nullptr);
+        for (int d = 0; d < n; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            CLV_HIP(hipStreamSynchronize(c->st[d]));
+            CLV_HIP(hipStreamSynchronize(c->cs[d]));
+            for (int e = 0; e < 2; e++) {
+                if (c->Cf[2 * d + e]) CLV_HIP(hipFree(c->Cf[2 * d + e]));
+                c->Cf[2 * d + e] = nullptr;
+                CLV_HIP(hipMalloc((void **)&c->Cf[2 * d + e], c->rows * N * sizeof(float)));
+            }
+        }
+        c->gemm_loop_n = N;
+    }
+    CLV_HIP(hipSetDevice(c->dev[0]));
+    const hipMemcpyKind kind = b_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    CLV_HIP(hipMemcpyAsync(c->B[0], B, b_bytes, kind, c->st[0]));
+    CLV_HIP(hipMemcpyAsync(c->sB[0], sB, sb_count * sizeof(float), kind, c->st[0]));
+    rc = replicate_from_0(c, (void *const *)c->B.data(), b_bytes);
+    if (rc == CLV_OK) rc = replicate_from_0(c, (void *const *)c->sB.data(), sb_count * sizeof(float));
+    return rc;
+}
+
+extern "C" int clm4_sharded_gemm_enqueue(clm4_shard_ctx *c, int step, int timed)
+{
+    CLV_REQUIRE(c && step >= 0, "clm4_sharded_gemm_enqueue: bad argument");
+    CLV_REQUIRE(c->loop_ready && c->gemm_loop_n, "clm4_sharded_gemm_enqueue: call clm4_sharded_gemm_begin first");
+    CLV_REQUIRE(!timed || step < c->slots, "clm4_sharded_gemm_enqueue: step %d has no event slot (%d reserved)", step, c->slots);
+    DeviceGuard guard;
+    const int n = c->ndev, b = step & 1;
+    const uint64_t N = c->gemm_loop_n, K = c->cols;
+    auto slot = [&](int e, int d) { return c->slot_ev[(3 * (size_t)step + e) * n + d]; };
+    auto Cb = [&](int d) { return c->Cf[2 * d + b]; };
+    for (int d = 0; d < n; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        // the exchange of step - 2 has left this buffer (see clm4_sharded_mvm_enqueue: the same-device test layout is pull-based)
+        if (c->loopback && n > 1) {
+            for (int o = 0; o < n; o++)
+                if (c->gpending[2 * o + b]) CLV_HIP(hipStreamWaitEvent(c->st[d], c->gdone[2 * o + b], 0));
+        } else if (c->gpending[2 * d + b]) {
+            CLV_HIP(hipStreamWaitEvent(c->st[d], c->gdone[2 * d + b], 0));
+        }
+        if (timed) CLV_HIP(hipEventRecord(slot(0, d), c->st[d]));
+        int rc = clm4_gemm(c->A[d], c->sA[d], c->row_count[d], K, c->B[d], c->sB[d], N, Cb(d) + c->row_begin[d] * N, c->st[d]);
+        if (rc != CLV_OK) return rc;
+        if (timed) CLV_HIP(hipEventRecord(slot(1, d), c->st[d]));
+        CLV_HIP(hipEventRecord(c->kdone[2 * d + b], c->st[d]));
+    }
+    if (n > 1 && c->loopback) {
+        for (int d = 0; d < n; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            for (int o = 0; o < n; o++) {
+                CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * o + b], 0));
+                if (o == d) continue;
+                CLV_HIP(hipMemcpyAsync(Cb(d) + c->row_begin[o] * N, Cb(o) + c->row_begin[o] * N, c->row_count[o] * N * sizeof(float),
+                                       hipMemcpyDeviceToDevice, c->cs[d]));
+            }
+        }
+    } else {
+        for (int d = 0; d < n; d++) {
+            CLV_HIP(hipSetDevice(c->dev[d]));
+            CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * d + b], 0));
+        }
+        if (c->use_rccl) {
+            RcclGroup g;
+            CLV_NCCL(g.start());
+            if (c->equal) {
+                // in place: rank d's panel already sits at offset d * count of its receive buffer
+                for (int d = 0; d < n; d++)
+                    CLV_NCCL(rccl()->AllGather(Cb(d) + c->row_begin[d] * N, Cb(d), c->row_count[0] * N, ncclFloat32, c->comm[d], c->cs[d]));
+            } else {
+                for (int root = 0; root < n; root++)
+                    for (int d = 0; d < n; d++) {
+                        float *p = Cb(d) + c->row_begin[root] * N;
+                        CLV_NCCL(rccl()->Broadcast(p, p, c->row_count[root] * N, ncclFloat32, root, c->comm[d], c->cs[d]));
+                    }
+            }
+            CLV_NCCL(g.end());
+        }
+    }
+    for (int d = 0; d < n; d++) {
+        CLV_HIP(hipSetDevice(c->dev[d]));
+        if (timed) CLV_HIP(hipEventRecord(slot(2, d), c->cs[d]));
+        CLV_HIP(hipEventRecord(c->gdone[2 * d + b], c->cs[d]));
+        c->gpending[2 * d + b] = 1;
+    }
+    return CLV_OK;
+}
+
+// device pointer of the whole C (rows x N fp32, row-major) in buffer `buf` (= step & 1 of the enqueue that wrote it) on shard `part`
+extern "C" int clm4_sharded_gemm_full(const clm4_shard_ctx *c, int part, int buf, const float **C_dev)
+{
+    CLV_REQUIRE(c && part >= 0 && part < c->ndev && (buf == 0 || buf == 1) && C_dev && c->gemm_loop_n, "clm4_sharded_gemm_full: bad argument");
+    *C_dev = c->Cf[2 * part + buf];
     return CLV_OK;
 }

@@ -32,39 +32,58 @@ __device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, 
     }
 }
 
-// lane = 4 dwords (half a block) of u and of v: 16-byte loads/stores, one shuffle for the block maximum
-template <bool NT>
+// lane = 4 dwords (half a block) of u and of v: 16-byte loads/stores, one shuffle for the block maximum.  U grid-stride steps per
+// iteration, all 2 U loads requested before the first value is computed (r5: with one step per iteration a wave had 2 KiB in flight and the
+// kernel sat at 0.69 of the HBM peak with the VALU 65 % busy)
+#ifndef SAA_U
+#define SAA_U 2
+#endif
+template <bool NT, int U>
 __global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
                                                           const float *__restrict__ sv, float a, u32x4 *r, float *sr,
                                                           uint64_t nquads)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += stride) {
-        const uint64_t b = i >> 1;
-        const u32x4 wu = NT ? __builtin_nontemporal_load(qu + i) : qu[i];
-        const u32x4 wv = NT ? __builtin_nontemporal_load(qv + i) : qv[i];
-        const float su7 = div7(su[b]);
-        const float sv7 = div7(sv[b] * a);
-        float v[4][8];
-        saa_values(wu.x, wv.x, su7, sv7, v[0]);
-        saa_values(wu.y, wv.y, su7, sv7, v[1]);
-        saa_values(wu.z, wv.z, su7, sv7, v[2]);
-        saa_values(wu.w, wv.w, su7, sv7, v[3]);
-        float m = 0.0f;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nquads; i0 += U * stride) {
+        u32x4 wu[U], wv[U];
+        float fu[U], fv[U];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int u = 0; u < U; u++) {                          // r may alias qu: every load of the iteration precedes its stores, lane by lane
+            const uint64_t i = i0 + u * stride, ic = i < nquads ? i : i0;      // nquads is even, i0 and stride have one parity: lane pairs stay whole
+            wu[u] = NT ? __builtin_nontemporal_load(qu + ic) : qu[ic];
+            wv[u] = NT ? __builtin_nontemporal_load(qv + ic) : qv[ic];
+            fu[u] = su[ic >> 1];
+            fv[u] = sv[ic >> 1];
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
-            for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[q][e]));
-        m = fmaxf(m, __shfl_xor(m, 1));
-        m = fix_zero_max(m);
-        const float k = 7.0f / m;
-        u32x4 o;
-        o.x = quant_pack8(v[0], k, nullptr);
-        o.y = quant_pack8(v[1], k, nullptr);
-        o.z = quant_pack8(v[2], k, nullptr);
-        o.w = quant_pack8(v[3], k, nullptr);
-        if (NT) __builtin_nontemporal_store(o, r + i); else r[i] = o;
-        if ((i & 1) == 0) sr[b] = m;
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = i0 + u * stride, b = i >> 1;
+            const float su7 = div7(fu[u]);
+            const float sv7 = div7(fv[u] * a);
+            float v[4][8];
+            saa_values(wu[u].x, wv[u].x, su7, sv7, v[0]);
+            saa_values(wu[u].y, wv[u].y, su7, sv7, v[1]);
+            saa_values(wu[u].z, wv[u].z, su7, sv7, v[2]);
+            saa_values(wu[u].w, wv[u].w, su7, sv7, v[3]);
+            float m = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[q][e]));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fix_zero_max(m);
+            const float k = 7.0f / m;
+            u32x4 o;
+            o.x = quant_pack8(v[0], k, nullptr);
+            o.y = quant_pack8(v[1], k, nullptr);
+            o.z = quant_pack8(v[2], k, nullptr);
+            o.w = quant_pack8(v[3], k, nullptr);
+            if (i < nquads) {
+                if (NT) __builtin_nontemporal_store(o, r + i); else r[i] = o;
+                if ((i & 1) == 0) sr[b] = m;
+            }
+        }
     }
 }
 
@@ -207,10 +226,10 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
         const uint64_t want = (nquads + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
         const dim3 grid((unsigned)(want < cap ? want : cap));
         if (3 * (n_pad / 2) > (256ull << 20))           // operands + result exceed the Infinity Cache: stream past it
-            hipLaunchKernelGGL(k_v4_scale_and_add<true>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a,
+            hipLaunchKernelGGL((k_v4_scale_and_add<true, SAA_U>), grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a,
                                (u32x4 *)r, sr, nquads);
         else
-            hipLaunchKernelGGL(k_v4_scale_and_add<false>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a,
+            hipLaunchKernelGGL((k_v4_scale_and_add<false, 1>), grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a,
                                (u32x4 *)r, sr, nquads);
         CLV_LAUNCH_CHECK();
         return CLV_OK;
@@ -1612,10 +1631,21 @@ extern "C" int clm4_iht(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
 //      LDS as fp32 (16384-column chunks = 64 KiB) together with f32(s/7) per block.  Products are
 //      f32((float)q * f32(s/7)) * x with one fma, as there.
 // =================================================================================================
+#ifndef MVF_CHUNK
 #define MVF_CHUNK 16384u
+#endif
+#ifndef MVF_U
+#define MVF_U 4                     // matrix loads (dwordx4 per lane) requested one step ahead
+#endif
+#ifndef MVF_FENCE
+#define MVF_FENCE 0
+#endif
+#ifndef MVF_WAVES
+#define MVF_WAVES 1                 // minimum waves per SIMD the register allocation must leave room for (A/B builds: 3, 4)
+#endif
 
 template <bool NT>
-__global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
+__global__ __launch_bounds__(256, MVF_WAVES) void k_m4_mvm_f32(const u32x4 *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
                                                     const float *__restrict__ x, float *__restrict__ r)
 {
     extern __shared__ __attribute__((aligned(16))) float mvf_x[];        // MVF_CHUNK floats of x, then MVF_CHUNK/64 block factors
@@ -1648,7 +1678,7 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
         fast = __builtin_amdgcn_readfirstlane(__syncthreads_and(fast));      // scalar: a real branch, not two predicated bodies
         const u32x4 *Ap = Arow + c0 / 32;
         const uint32_t ngroups = cw / 128;                                // 16 words = 128 columns per quad and step
-        constexpr int U = 4;
+        constexpr int U = MVF_U;
         // FAST: every block factor c of the chunk survives c / 16 exactly (see the barrier above)
         auto chunk = [&](auto fast_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
@@ -1689,7 +1719,12 @@ __global__ __launch_bounds__(256) void k_m4_mvm_f32(const u32x4 *__restrict__ A,
                 for (int u = 0; u < U; u++) nxt[u] = ld(g + U + u);
                 asm volatile("" ::: "memory");                              // the next step's loads are issued HERE, before this step's arithmetic
 #pragma unroll
-                for (int u = 0; u < U; u++) group(cur[u], g + u);
+                for (int u = 0; u < U; u++) {
+                    group(cur[u], g + u);
+#if MVF_FENCE
+                    asm volatile("" ::: "memory");                          // one group's x reads at a time: keeps the live registers of a step down
+#endif
+                }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int u = 0; u < U; u++) cur[u] = nxt[u];

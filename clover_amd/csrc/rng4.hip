@@ -318,12 +318,13 @@ __global__ __launch_bounds__(256) void k_m4_quantize_strip_st(const float *__res
 
 // ---- host side ---------------------------------------------------------------------------------------------
 // segments (of 8 blocks) per wave for the vector kernels.  The choice never changes results, only speed;
-// clvx_set_st_segments (tests, experiments; not in the public header) or CLV_ST_SEGMENTS=1|4|16 force one shape.
+// clv_rng_set_segments (clover_hip.h: a tuning knob, and how the tests reach every kernel shape at small sizes) or
+// CLV_ST_SEGMENTS=1|4|16|64 force one shape.
 static int g_st_forced = [] { const char *e = getenv("CLV_ST_SEGMENTS"); return e ? atoi(e) : 0; }();
 
-extern "C" int clvx_set_st_segments(int s)
+extern "C" int clv_rng_set_segments(int s)
 {
-    CLV_REQUIRE(s == 0 || s == 1 || s == 4 || s == 16 || s == 64, "clvx_set_st_segments: %d is not one of 0, 1, 4, 16, 64", s);
+    CLV_REQUIRE(s == 0 || s == 1 || s == 4 || s == 16 || s == 64, "clv_rng_set_segments: %d is not one of 0, 1, 4, 16, 64", s);
     g_st_forced = s;
     return CLV_OK;
 }

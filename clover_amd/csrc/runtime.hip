@@ -115,10 +115,44 @@ int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream)
     return CLV_OK;
 }
 
+// Hand-over slots, one small buffer per (device, stream), ZERO when handed out for the first time and zero again after every kernel
+// that used them (the consumer clears what it read): single-launch reductions (clv4_dot FAST) pass their workgroup partials through
+// them without a second kernel.  Separate from the scratch above, which other calls on the stream overwrite.
+#define CLV_SYNC_SLOT_BYTES (64u << 10)
+static std::vector<WsEntry> g_slots;
+
+int clv_internal_sync_slots(void **ptr, uint64_t bytes, hipStream_t stream)
+{
+    CLV_REQUIRE(bytes <= CLV_SYNC_SLOT_BYTES, "clv_internal_sync_slots: %llu bytes wanted, %u kept per stream", (unsigned long long)bytes, CLV_SYNC_SLOT_BYTES);
+    int dev = 0;
+    CLV_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (auto &w : g_slots)
+        if (w.dev == dev && w.stream == stream) { *ptr = w.ptr; return CLV_OK; }
+    void *p = nullptr;
+    CLV_HIP(hipMalloc(&p, CLV_SYNC_SLOT_BYTES));
+    if (hipMemsetAsync(p, 0, CLV_SYNC_SLOT_BYTES, stream) != hipSuccess) {       // stream-ordered in front of the first kernel that uses them
+        (void)hipFree(p);
+        clv_set_error("clv_internal_sync_slots: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+        return CLV_ERR_HIP;
+    }
+    g_slots.push_back(WsEntry{dev, stream, p, CLV_SYNC_SLOT_BYTES});
+    *ptr = p;
+    return CLV_OK;
+}
+
 // a destroyed stream's handle may be re-used by the runtime for a new stream: drop its scratch with it
 void clv_internal_workspace_forget(hipStream_t stream)
 {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (size_t k = 0; k < g_slots.size();) {
+        if (g_slots[k].stream == stream && stream != nullptr) {
+            if (g_slots[k].ptr) (void)hipFree(g_slots[k].ptr);
+            g_slots.erase(g_slots.begin() + (long)k);
+        } else {
+            k++;
+        }
+    }
     for (size_t k = 0; k < g_ws.size();) {
         if (g_ws[k].stream == stream && stream != nullptr) {
             if (g_ws[k].ptr) (void)hipFree(g_ws[k].ptr);

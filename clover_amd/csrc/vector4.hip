@@ -230,6 +230,86 @@ __global__ __launch_bounds__(DOT_FAST_THREADS) void k_v4_dot_final(const float *
     if (threadIdx.x == 0) *out = t;
 }
 
+// The same dot in ONE launch (round 5).  At configs[1]'s size (n = 2^24: 18.9 MB, cache-resident) the two-kernel form is two fixed
+// costs: k_v4_dot_partial 5.5 us + k_v4_dot_final 4.6 us (profiles/r04_dot_n2p24_kernel_stats.txt) for 2.4 us worth of bytes.
+// Here every workgroup hands its partial over through an 8-byte slot {valid = 1, partial} -- one agent-scope store, partial and flag
+// arrive together -- and the LAST workgroup of the grid, once its own share is done, collects the slots and runs k_v4_dot_final's
+// tree: thread t adds slots t, t + 256, ... in that order, then block_sum_256 -- the same bits as the two-kernel form, whatever
+// order the workgroups finish in.  No atomic read-modify-write anywhere: same-address device-scope atomics cost 42-62 ns EACH on this
+// chip (DESIGN_HISTORY 5), a ticket per workgroup would be 50 us.  The collector clears every slot it has read, so the slots are zero
+// again when the kernel ends (clv_internal_sync_slots' contract) and a captured graph replays correctly.  Forward progress: the grid
+// never exceeds what is resident at once (dot_fast_grid: 4 workgroups of 256 per CU), so the workgroups the collector waits for are
+// running or about to be scheduled whatever else shares the device.
+// Loads: all U steps of a thread are requested before the first is used (two dependent round trips at n = 2^24 became one).
+template <int U>
+__global__ __launch_bounds__(DOT_FAST_THREADS) void k_v4_dot_fast1(const u32x4 *__restrict__ qu, const float *__restrict__ su,
+                                                                   const u32x4 *__restrict__ qv, const float *__restrict__ sv,
+                                                                   uint64_t nvec, unsigned long long *slots, float *__restrict__ out)
+{
+    __shared__ float sh[4];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    float acc = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += U * stride) {
+        u32x4 a[U], b[U];
+        float cu[U], cv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t j = i + u * stride, jc = j < nvec ? j : i;         // nvec is even and i, stride have one parity: lane pairs stay together
+            a[u] = __builtin_nontemporal_load(&qu[jc]);
+            b[u] = __builtin_nontemporal_load(&qv[jc]);
+            cu[u] = su[jc >> 1];
+            cv[u] = sv[jc >> 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int I = dot32(a[u], b[u]);
+            I += __shfl_xor(I, 1);
+            const uint64_t j = i + u * stride;
+            // branch-free (a branch lets hipcc sink the scale loads into it, behind the nibble loads' round trip): odd lanes and lanes past
+            // the end multiply by 0 -- fma(0, I, acc) == acc exactly -- so every lane's sum is k_v4_dot_partial's, in the same order
+            const float c = ((j & 1) == 0 && j < nvec) ? (cu[u] * CLV_RCP49) * cv[u] : 0.0f;
+            acc = __builtin_fmaf(c, (float)I, acc);
+        }
+    }
+    const float t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&slots[blockIdx.x], (1ull << 32) | __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x != gridDim.x - 1) return;
+    // collector: every round requests all of this thread's outstanding slots at once
+    constexpr int MAXS = 8;                                                    // grid <= 256 * MAXS (dot_fast_grid: 4 per CU)
+    const int count = (int)gridDim.x;
+    float part[MAXS];
+    uint32_t need = 0;
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+        part[k] = 0.0f;
+        if ((int)threadIdx.x + DOT_FAST_THREADS * k < count) need |= 1u << k;
+    }
+    while (need) {
+        unsigned long long v[MAXS];
+#pragma unroll
+        for (int k = 0; k < MAXS; k++)
+            if (need & (1u << k)) v[k] = __hip_atomic_load(&slots[threadIdx.x + DOT_FAST_THREADS * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < MAXS; k++)
+            if ((need & (1u << k)) && (v[k] >> 32)) {
+                part[k] = __uint_as_float((uint32_t)v[k]);
+                need &= ~(1u << k);
+            }
+        if (need) __builtin_amdgcn_s_sleep(1);
+    }
+    float acc2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+        acc2 += part[k];                                                       // slots beyond `count` contribute +0.0f: acc2 + 0 == acc2 bit for bit
+        // zero again for the next launch: plain stores (nobody reads the slots any more in this launch; the end of the kernel writes them back)
+        if ((int)threadIdx.x + DOT_FAST_THREADS * k < count) slots[threadIdx.x + DOT_FAST_THREADS * k] = 0ull;
+    }
+    __syncthreads();                                                           // sh is reused
+    const float r = block_sum_256(acc2, sh);
+    if (threadIdx.x == 0) *out = r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -340,10 +420,25 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
         return CLV_OK;
     }
     const int grid = dot_fast_grid(n_pad);
-    hipLaunchKernelGGL(k_v4_dot_partial, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv,
-                       n_pad / 32, (float *)workspace);
-    CLV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_v4_dot_final, dim3(1), dim3(DOT_FAST_THREADS), 0, st, (const float *)workspace, grid, out_dev);
+    static const bool two_launches = getenv("CLV_DOT_FAST_TWO_LAUNCHES") != nullptr;      // A/B switch: the round-1..4 form (same bits)
+    if (two_launches || grid > 256 * 8) {
+        hipLaunchKernelGGL(k_v4_dot_partial, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv,
+                           n_pad / 32, (float *)workspace);
+        CLV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_v4_dot_final, dim3(1), dim3(DOT_FAST_THREADS), 0, st, (const float *)workspace, grid, out_dev);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
+    void *slots = nullptr;
+    int rc = clv_internal_sync_slots(&slots, (uint64_t)grid * 8, st);
+    if (rc) return rc;
+    const uint64_t nvec = n_pad / 32, per_thread = (nvec + (uint64_t)grid * DOT_FAST_THREADS - 1) / ((uint64_t)grid * DOT_FAST_THREADS);
+    if (per_thread >= 4)
+        hipLaunchKernelGGL(k_v4_dot_fast1<4>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec,
+                           (unsigned long long *)slots, out_dev);
+    else
+        hipLaunchKernelGGL(k_v4_dot_fast1<2>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec,
+                           (unsigned long long *)slots, out_dev);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "clv_rng_set": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), _vp]),
     "clv_rng_get": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), _vp]),
     "clv_rng_graph_mode": (C.c_int, [_vp, C.c_int, _vp]),
+    "clv_rng_set_segments": (C.c_int, [C.c_int]),
     "clv4_quantize": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
     "clv4_restore": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "clv4_dot_workspace_bytes": (_u64, [_u64]),
@@ -102,6 +103,9 @@ SIGNATURES = {
     "clm4_sharded_result_buf": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     "clm4_sharded_gemm": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _vp]),
     "clm4_sharded_gemm_result": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "clm4_sharded_gemm_begin": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, C.c_int]),
+    "clm4_sharded_gemm_enqueue": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "clm4_sharded_gemm_full": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "clv_fill_random_nibbles": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),
     "clv_fill_random_scales": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),
     "clv_fill_random_ints_f32": (C.c_int, [_vp, _u64, C.c_int, _u64, _u64, _vp]),

@@ -177,17 +177,14 @@ public:
         clover_hip::scalar::restore4(values_ro(), scales_ro(), length_pad, other.host_rw());
     }
 
-    /* dot(): the reference's summation order, bit for bit (16 sequential fma chains: latency-bound by definition, 0.385 ms at
-     * n = 2^24 -- NOT faster than one host core running the same order, 0.32 ms on the bench host; the floor is n/128 dependent
-     * fmas).  dot_parallel() / dot_fast(): exact integer block sums, fp32 tree order -- memory-bound (6.8 TB/s), within
-     * 2e-6 * sum|terms| of dot(), as the reference's own dot_parallel differs from its dot.
-     * RULE OF THUMB: n >= 2^20 -> call dot_parallel() (the reference's own name for "any order"), or build with -DCLOVER_DOT_FAST,
-     * which makes dot() the fast order for code that calls dot() in a loop and does not need the reference's last bits. */
-#ifdef CLOVER_DOT_FAST
-    float dot(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
-#else
-    float dot(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_EXACT); }
-#endif
+    /* dot(): by default the reference's summation order, bit for bit (16 sequential fma chains: latency-bound by definition, 0.38 ms at
+     * n = 2^24 -- NOT faster than one host core running the same order; the floor is n/128 dependent fmas).  Under -DCLOVER_FAST (or
+     * clover_hip::set_exactness(clover_hip::FAST), or the older -DCLOVER_DOT_FAST) dot() is the fast order: exact integer block sums,
+     * fp32 tree order -- memory-bound, one launch, within 2e-6 * sum|terms| of the exact order, as the reference's own dot_parallel
+     * differs from its dot.  The switch and its threshold() half: clover_device.h.  dot_parallel() / dot_fast(): always the fast order;
+     * dot_exact(): always the reference's.  RULE OF THUMB: n >= 2^20 and no need for the last bits -> dot_parallel(). */
+    float dot(const CloverVector4 &other) const { return dot_mode(other, clover_hip::dot_mode()); }
+    float dot_exact(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_EXACT); }
     float dot_parallel(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
     float dot_fast(const CloverVector4 &other) const { return dot_mode(other, CLV_DOT_FAST); }
 

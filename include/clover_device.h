@@ -104,24 +104,71 @@ inline void check(int rc, const char *what)
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return v % m ? v + m - (v % m) : v; }
 
-/* Tie rule of CloverVector4 / CloverVector8 ::threshold (clover_hip.h: CLV_THRESHOLD_FAST / CLV_THRESHOLD_REFERENCE).  Default FAST (radix
- * select, lowest-index ties); REFERENCE reproduces the reference's survivor set index for index (its min-heap walk, about 1 us per heap
- * insert).  Chosen, in this order, by set_threshold_mode(), -DCLOVER_THRESHOLD_REFERENCE at compile time, or CLV_THRESHOLD_REFERENCE=1 in
- * the environment at first use. */
+/* ONE exactness switch for the containers (round 5).  Two methods of this path have a definition-bound slow form and a fast form:
+ *
+ *   method                     reference's bits                                            fast
+ *   dot()                      CLV_DOT_EXACT: the reference's 16 sequential fma chains     CLV_DOT_FAST: exact block integers, fp32 tree order,
+ *                              (n/128 dependent fmas: 0.38 ms at n = 2^24, what one host    within 2e-6 * sum|terms| (the reference's own
+ *                              core takes for the same order)                               dot_parallel is "any order" too); memory-bound
+ *   threshold()                CLV_THRESHOLD_REFERENCE: the reference's K-entry min-heap   CLV_THRESHOLD_FAST: radix select; the same MULTISET of
+ *                              walk, survivors index for index (one wavefront, about 1 us    magnitudes survives, ties at the K-th value go to
+ *                              per heap insert: ~1 ms at N = 8192, K = 1024)                 the lowest indices (5 us at N = 8192)
+ *
+ *   -DCLOVER_REFERENCE_BITS   both methods return the reference's bits.  THE DEFAULT when neither macro is given: a drop-in first of all
+ *                             reproduces what it replaces (a Q_IHT through CloverIHT.h then follows the reference's trajectory tie for tie);
+ *   -DCLOVER_FAST             both take the fast form (a quantized IHT iteration at N = 8192: 20 us instead of ~1 ms).
+ * At run time: clover_hip::set_exactness(clover_hip::REFERENCE_BITS | clover_hip::FAST) switches both; CLV_EXACTNESS=fast|reference in the
+ * environment picks the start value of a build without either macro.  Finer: set_dot_mode() / set_threshold_mode(), and the older
+ * single-method macros -DCLOVER_DOT_FAST, -DCLOVER_THRESHOLD_REFERENCE / -DCLOVER_THRESHOLD_FAST and CLV_THRESHOLD_REFERENCE=0|1 still
+ * override their one method.  dot_parallel() / dot_fast() are always the fast order, dot_exact() always the reference's. */
+#if defined(CLOVER_REFERENCE_BITS) && defined(CLOVER_FAST)
+#error "-DCLOVER_REFERENCE_BITS and -DCLOVER_FAST exclude each other"
+#endif
+enum Exactness { REFERENCE_BITS = 0, FAST = 1 };
+inline int start_exactness()
+{
+#if defined(CLOVER_FAST)
+    return FAST;
+#elif defined(CLOVER_REFERENCE_BITS)
+    return REFERENCE_BITS;
+#else
+    const char *e = getenv("CLV_EXACTNESS");
+    return (e && (e[0] == 'f' || e[0] == 'F')) ? FAST : REFERENCE_BITS;
+#endif
+}
 inline int &threshold_mode_slot()
 {
-#ifdef CLOVER_THRESHOLD_REFERENCE
+#if defined(CLOVER_THRESHOLD_REFERENCE)
     static int mode = CLV_THRESHOLD_REFERENCE;
+#elif defined(CLOVER_THRESHOLD_FAST)
+    static int mode = CLV_THRESHOLD_FAST;
 #else
     static int mode = [] {
         const char *e = getenv("CLV_THRESHOLD_REFERENCE");
-        return (e && e[0] && e[0] != '0') ? CLV_THRESHOLD_REFERENCE : CLV_THRESHOLD_FAST;
+        if (e && e[0]) return e[0] != '0' ? CLV_THRESHOLD_REFERENCE : CLV_THRESHOLD_FAST;
+        return start_exactness() == FAST ? CLV_THRESHOLD_FAST : CLV_THRESHOLD_REFERENCE;
     }();
+#endif
+    return mode;
+}
+inline int &dot_mode_slot()
+{
+#if defined(CLOVER_DOT_FAST)
+    static int mode = CLV_DOT_FAST;
+#else
+    static int mode = start_exactness() == FAST ? CLV_DOT_FAST : CLV_DOT_EXACT;
 #endif
     return mode;
 }
 inline int threshold_mode() { return threshold_mode_slot(); }
 inline void set_threshold_mode(int mode) { threshold_mode_slot() = mode; }
+inline int dot_mode() { return dot_mode_slot(); }
+inline void set_dot_mode(int mode) { dot_mode_slot() = mode; }
+inline void set_exactness(int e)
+{
+    set_dot_mode(e == FAST ? CLV_DOT_FAST : CLV_DOT_EXACT);
+    set_threshold_mode(e == FAST ? CLV_THRESHOLD_FAST : CLV_THRESHOLD_REFERENCE);
+}
 
 class Mirror;
 

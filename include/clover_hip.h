@@ -103,6 +103,10 @@ int  clv_rng_get(const uint64_t *state_dev, uint64_t key1[4], uint64_t key2[4], 
  * part of the XORShift stream, exactly as the same calls issued one after another would.  Enable it before capturing (outside the
  * capture), on the stream the calls will use; on == 0 returns the state to host stamps.  clv_rng_set / clv_rng_seed keep the mode. */
 int  clv_rng_graph_mode(uint64_t *state_dev, int on, void *stream);
+/* Tuning knob (process-wide): how many 8-block segments of the stream one wavefront of the stochastic VECTOR kernels walks -- 1, 4, 16,
+ * 64 (= 16 segments of 32 blocks), or 0 = by size (the default).  The choice never changes a result, only the speed at a given length;
+ * the parity tests use it to take every kernel shape through the small cases.  Environment: CLV_ST_SEGMENTS. */
+int  clv_rng_set_segments(int segments);
 
 /* ---- CloverVector4 ---------------------------------------------------------------------------- */
 /* CloverVector4::quantize (CloverVector4.h:605-807).  x: n_pad floats; q: n_pad/2 bytes; s: n_pad/64
@@ -293,6 +297,17 @@ int  clm4_sharded_result_buf(const clm4_shard_ctx *ctx, int part, int buf, const
  * between the shards.  Every shard must be a multiple of 128 rows.  C_host (optional) receives the whole C. */
 int  clm4_sharded_gemm(clm4_shard_ctx *ctx, const int8_t *B, const float *sB, uint64_t N, int b_on_host, float *C_host);
 int  clm4_sharded_gemm_result(const clm4_shard_ctx *ctx, int part, const float **C_dev);
+/* The same product as a loop, with the C ROW PANELS ALL-GATHERED: every device ends with the whole C (rows x N fp32).
+ *   clm4_sharded_gemm_begin    B to every device (stream-ordered), two full C buffers per device, `slots` timed steps;
+ *   clm4_sharded_gemm_enqueue  step i: every device's clm4_gemm into its panel of C buffer i & 1 on its compute stream, then ONE in-place
+ *                              ncclAllGather of that buffer per device on its exchange stream (ragged shards: a broadcast per owner;
+ *                              shards repeating a device: copies) -- overlapping the kernel of step i + 1; no host wait;
+ *   clm4_sharded_sync / clm4_sharded_step_timing (kernel ms, exchange ms) as for the mvm loop;
+ *   clm4_sharded_gemm_full     device pointer of the whole C in buffer `buf` on shard `part`.
+ * Bit-identical to clm4_gemm on the unsharded matrix.  A context runs ONE loop at a time (mvm or gemm: they share the step events). */
+int  clm4_sharded_gemm_begin(clm4_shard_ctx *ctx, const int8_t *B, const float *sB, uint64_t N, int b_on_host, int slots);
+int  clm4_sharded_gemm_enqueue(clm4_shard_ctx *ctx, int step, int timed);
+int  clm4_sharded_gemm_full(const clm4_shard_ctx *ctx, int part, int buf, const float **C_dev);
 
 /* ---- synthetic data (bench / tests): fills device buffers without an fp32 source ------------------ */
 /* nibbles uniform in [-7,7], scales uniform in [0.5,2): counter-based splitmix64 of (seed, index), so any

@@ -117,6 +117,27 @@ static int run_layout(const char *name, Whole &w, int nparts, const int *devices
         CHECK(clv_device_sync());
         CHECK(clm4_sharded_gemm(ctx, B, sB, N, 0, C2.data()));
         gemm_ok = std::memcmp(C1.data(), C2.data(), C1.size() * 4) == 0;
+        // the loop form: three steps, the C row panels all-gathered (RCCL where the layout has a communicator, copies in the same-device
+        // layout): EVERY shard's copy of the whole C, in the buffer the last step wrote, equals the unsharded product
+        if (gemm_ok) {
+            CHECK(clm4_sharded_gemm_begin(ctx, B, sB, N, 0, 3));
+            for (int step = 0; step < 3; step++) CHECK(clm4_sharded_gemm_enqueue(ctx, step, 1));
+            CHECK(clm4_sharded_sync(ctx));
+            for (int p = 0; p < nparts && gemm_ok; p++) {
+                const float *cf; int dev;
+                CHECK(clm4_sharded_gemm_full(ctx, p, 2 & 1, &cf));
+                CHECK(clm4_sharded_info(ctx, p, &dev, nullptr, nullptr, nullptr, nullptr));
+                CHECK(clv_set_device(dev));
+                CHECK(clv_memcpy_d2h(C2.data(), cf, C2.size() * 4, nullptr));
+                CHECK(clv_device_sync());
+                CHECK(clv_set_device(before));
+                gemm_ok = std::memcmp(C1.data(), C2.data(), C1.size() * 4) == 0;
+                float k, g;
+                CHECK(clm4_sharded_step_timing(ctx, p, 2, &k, &g));
+                if (!(k > 0.0f) || !(g >= 0.0f)) gemm_ok = 0;
+            }
+            if (!gemm_ok) { std::printf("%s: a shard's all-gathered C differs from clm4_gemm\n", name); return 1; }
+        }
         CHECK(clv_free(B)); CHECK(clv_free(sB)); CHECK(clv_free(C));
         if (!gemm_ok) { std::printf("%s: sharded GEMM differs from clm4_gemm\n", name); return 1; }
     }

@@ -88,6 +88,7 @@ static void vectors()
             expect(s3.get(i) == s2.get(i), "scaleAndAdd_parallel vs scalar", n, i);                                          // :395-447
             expect(s4.get(i) == s5.get(i), "scaleAndAdd vs scalar (3 operands)", n, i);
         }
+        clover_hip::set_threshold_mode(CLV_THRESHOLD_FAST);          // every n in FAST mode; every 8th also in the default: the reference's survivor order
         threshold_relation<CloverVector4>(w, n, "threshold: sorted magnitudes");                                             // :449-553
         if (n % 8 == 0) {
             clover_hip::set_threshold_mode(CLV_THRESHOLD_REFERENCE);

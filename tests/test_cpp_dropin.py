@@ -31,9 +31,13 @@ def test_dropin_example_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
-def test_dropin_example_matches_reference_answers(tmp_path, oracle):
+@pytest.mark.parametrize("exactness", ["reference_bits", "fast"])
+def test_dropin_example_matches_reference_answers(tmp_path, oracle, exactness):
+    """the README-style client in both settings of the headers' ONE exactness switch (clover_device.h): the default build
+    (= -DCLOVER_REFERENCE_BITS: dot() in the reference's order, threshold() the reference's heap walk -- Q_IHT through CloverIHT.h
+    must follow the ORACLE's loop, whose threshold is the reference's, tie for tie) and -DCLOVER_FAST (lowest-index ties)."""
     exe = tmp_path / "dropin"
-    compile_example(exe)
+    compile_example(exe, extra=("-DCLOVER_FAST",) if exactness == "fast" else ())
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=300).stdout
     kv = {}
     for line in out.splitlines():
@@ -45,8 +49,15 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
     assert float(kv["kat1_dot_parallel"]) == 256.0 and kv["kat1_bytes"] == "77" * 8 and kv["kat1_scales"] == "1,2"
     assert kv["kat1_get"] == "2" and kv["bytes"] == "72"
     assert kv["kat2_qx"] == KAT["KAT2"]["qx_bytes_0_31"] and kv["kat2_qy"] == KAT["KAT2"]["qy_bytes_0_31"]
-    assert kv["kat2_dot"] == KAT["KAT2"]["dot_bits"] and kv["kat2_dot_scalar"] == KAT["KAT2"]["dot_scalar_bits"]
-    assert kv["kat2_copy_dot"] == KAT["KAT2"]["dot_bits"] and kv["kat2_view_dot"] == KAT["KAT2"]["dot_bits"]
+    assert kv["kat2_dot_scalar"] == KAT["KAT2"]["dot_scalar_bits"]
+    if exactness == "fast":       # dot() is the fast order under -DCLOVER_FAST: exact block integers, other fp32 order (tolerance as test_gpu_parity)
+        want = float(np.array([int(KAT["KAT2"]["dot_bits"], 16)], np.uint32).view(np.float32)[0])
+        for key in ("kat2_dot", "kat2_copy_dot", "kat2_view_dot"):
+            got = float(np.array([int(kv[key], 16)], np.uint32).view(np.float32)[0])
+            assert abs(got - want) <= 1e-5 * abs(want), (key, got, want)
+    else:
+        assert kv["kat2_dot"] == KAT["KAT2"]["dot_bits"]
+        assert kv["kat2_copy_dot"] == KAT["KAT2"]["dot_bits"] and kv["kat2_view_dot"] == KAT["KAT2"]["dot_bits"]
     assert kv["kat2_restore"].split(",") == KAT["KAT2"]["restore_qx_0_3_bits"]
     assert kv["kat3_r"] == KAT["KAT3"]["r_bytes_0_63"] and kv["kat3_r_parallel"] == KAT["KAT3"]["r_bytes_0_63"]
     assert kv["kat3_scales"].split(",") == KAT["KAT3"]["r_scale_bits"]
@@ -101,7 +112,8 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
             t3 = oracle.m4_mvm(*PhiT, N, M, *t2)
             x = oracle.v4_scale_and_add(*x, *t3, 0.001)
             if thr:
-                x = (threshold_lowest_index(x[0], x[1], K), x[1])
+                # default build: the reference's survivors (orc_v4_threshold = its min-heap walk, CloverVector4.h:1913-2060)
+                x = ((threshold_lowest_index(x[0], x[1], K) if exactness == "fast" else oracle.v4_threshold(x[0], x[1], N, K)), x[1])
         return x
     xi = loop(3, True)
     assert kv["qiht_x"] == xi[0].tobytes().hex()
@@ -126,7 +138,7 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle):
             t3 = oracle.m4_mvm_v8(*PhiT, N, M, *t2)
             x = oracle.v8_scale_and_add(*x, *t3, 0.001)
             if thr:
-                x = (threshold8_lowest_index(x[0], x[1], K), x[1])
+                x = ((threshold8_lowest_index(x[0], x[1], K) if exactness == "fast" else oracle.v8_threshold(x[0], x[1], N, K)), x[1])
         return x
     x8 = loop8(3, True)
     assert kv["qiht8_x"] == x8[0].tobytes().hex()

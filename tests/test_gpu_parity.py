@@ -336,7 +336,7 @@ def test_stochastic_vector_ops_every_kernel_shape(hip, oracle, segments):
     rng = np.random.default_rng(segments)
     x = (rng.normal(size=n) * 3).astype(np.float32)
     (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
-    assert hip.lib.clvx_set_st_segments(segments) == 0
+    assert hip.lib.clv_rng_set_segments(segments) == 0
     try:
         st, o = hip.new_rng(77, 88), oracle.rng(77, 88)
         for _ in range(2):
@@ -353,7 +353,7 @@ def test_stochastic_vector_ops_every_kernel_shape(hip, oracle, segments):
         o1, o2 = oracle.rng_keys(o)
         assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
     finally:
-        hip.lib.clvx_set_st_segments(0)
+        hip.lib.clv_rng_set_segments(0)
 
 
 @pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 640), (192 * 2, 1280)])

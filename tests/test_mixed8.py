@@ -91,7 +91,7 @@ def test_gpu_v8_quantize_stochastic_same_stream(hip, oracle, segments):
     n += (-n) % 128
     rng = np.random.default_rng(n)
     x = (rng.normal(size=n) * 2).astype(np.float32)
-    assert hip.lib.clvx_set_st_segments(segments) == 0
+    assert hip.lib.clv_rng_set_segments(segments) == 0
     try:
         st, o = hip.new_rng(21, 43), oracle.rng(21, 43)
         for _ in range(2):
@@ -100,7 +100,7 @@ def test_gpu_v8_quantize_stochastic_same_stream(hip, oracle, segments):
             assert same(q, qo) and same(s, so)
         assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
     finally:
-        hip.lib.clvx_set_st_segments(0)
+        hip.lib.clv_rng_set_segments(0)
 
 
 @pytest.mark.gpu
@@ -212,7 +212,7 @@ def test_gpu_v8_scale_and_add_stochastic_every_kernel_shape(hip, oracle, segment
     n += (-n) % 128
     rng = np.random.default_rng(segments + 40)
     (qu, su), (qv, sv) = _rand_v8(rng, n), _rand_v8(rng, n)
-    assert hip.lib.clvx_set_st_segments(segments) == 0
+    assert hip.lib.clv_rng_set_segments(segments) == 0
     try:
         st, o = hip.new_rng(7, 8), oracle.rng(7, 8)
         for in_place in (False, True):
@@ -221,7 +221,7 @@ def test_gpu_v8_scale_and_add_stochastic_every_kernel_shape(hip, oracle, segment
             assert same(r, ro) and same(sr, sro)
         assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
     finally:
-        hip.lib.clvx_set_st_segments(0)
+        hip.lib.clv_rng_set_segments(0)
 
 
 @pytest.mark.gpu

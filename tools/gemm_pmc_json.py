@@ -22,8 +22,9 @@ G = 8192
 if len(sys.argv) > 1 and sys.argv[1] == "--probe":
     import ctypes as C
     sys.path.insert(0, str(ROOT))
+    from clover_amd.build import build_probe_library
     from clover_amd.lib_binding import CloverHip
-    hip = CloverHip()
+    hip = CloverHip(path=build_probe_library(), allow_probe=True)      # clvx_* live in the bench-only probe build
     lib = hip.lib
     lib.clvx_read_bw.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     big = hip.alloc(2 << 30)

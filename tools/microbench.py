@@ -9,9 +9,10 @@ from pathlib import Path
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clover_amd.build import build_probe_library  # noqa: E402
 from clover_amd.lib_binding import CloverHip  # noqa: E402
 
-hip = CloverHip()
+hip = CloverHip(path=build_probe_library(), allow_probe=True)      # clvx_* live in the bench-only probe build
 lib = hip.lib
 vp, u64 = C.c_void_p, C.c_uint64
 lib.clvx_read_bw.argtypes = [vp, u64, C.c_int, C.c_int, vp, vp]
