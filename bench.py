@@ -307,7 +307,18 @@ def main() -> None:
         # otherwise stop it before the first collective)
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dist.init_process_group("gloo")
+        # gloo announces its connections with printf ("[Gloo] Rank 0 is connected to 1 peer ranks ...") on STDOUT, where the contract wants
+        # exactly one JSON line: file descriptor 1 points at stderr while the groups are built
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         if not debug_one_gpu:
             # data plane: an RCCL (backend "nccl") group for the per-step all-gather.  If it cannot be built or its first collective
             # fails on ANY rank, every rank falls back to gloo through the host for the 72 KiB exchange -- slower, reported as such, but
@@ -689,20 +700,21 @@ def one_process_measure(args, torch, hip, n: int) -> dict:
                 hip.check(lib.clm4_sharded_mvm_enqueue(ctx, w_, 0))
             hip.check(lib.clm4_sharded_sync(ctx))
             t0 = time.perf_counter()
+            sampled = list(range(0, args.steps, args.event_every))       # event triples around every Nth step only (see --event-every)
             for i in range(args.steps):
-                hip.check(lib.clm4_sharded_mvm_enqueue(ctx, i, 1))
+                hip.check(lib.clm4_sharded_mvm_enqueue(ctx, i, 1 if i % args.event_every == 0 else 0))
             hip.check(lib.clm4_sharded_sync(ctx))
             elapsed = time.perf_counter() - t0
             per_k, per_g = [], []
             km, gm = C.c_float(), C.c_float()
             for d in range(n):
                 ks, gs = 0.0, 0.0
-                for i in range(args.steps):
+                for i in sampled:
                     hip.check(lib.clm4_sharded_step_timing(ctx, d, i, C.byref(km), C.byref(gm)))
                     ks += km.value
                     gs += gm.value
-                per_k.append(ks / args.steps)
-                per_g.append(gs / args.steps)
+                per_k.append(ks / len(sampled))
+                per_g.append(gs / len(sampled))
             # every device holds the full result, and it equals the unsharded call's (n * 72 KiB: compared on the host)
             last = (args.steps - 1) & 1
             full = []
@@ -853,20 +865,21 @@ def gemm_sharded_measure(args, torch, hip, n: int) -> dict:
             hip.check(lib.clm4_sharded_gemm_enqueue(ctx, w_, 0))
         hip.check(lib.clm4_sharded_sync(ctx))
         t0 = time.perf_counter()
+        sampled = list(range(0, steps, 6))                                    # event triples around every 6th step
         for i in range(steps):
-            hip.check(lib.clm4_sharded_gemm_enqueue(ctx, i, 1))
+            hip.check(lib.clm4_sharded_gemm_enqueue(ctx, i, 1 if i % 6 == 0 else 0))
         hip.check(lib.clm4_sharded_sync(ctx))
         elapsed = time.perf_counter() - t0
         per_k, per_g = [], []
         km, gm = C.c_float(), C.c_float()
         for d in range(n):
             ks = gs = 0.0
-            for i in range(steps):
+            for i in sampled:
                 hip.check(lib.clm4_sharded_step_timing(ctx, d, i, C.byref(km), C.byref(gm)))
                 ks += km.value
                 gs += gm.value
-            per_k.append(ks / steps)
-            per_g.append(gs / steps)
+            per_k.append(ks / len(sampled))
+            per_g.append(gs / len(sampled))
         ranks, equal = C.c_int(), C.c_int()
         hip.check(lib.clm4_sharded_comm_info(ctx, C.byref(ranks), C.byref(equal)))
         full = []

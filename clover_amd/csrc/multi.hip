@@ -478,6 +478,7 @@ extern "C" int clm4_sharded_mvm_enqueue(clm4_shard_ctx *c, int step, int timed)
     CLV_REQUIRE(!timed || step < c->slots, "clm4_sharded_mvm_enqueue: step %d has no event slot (%d reserved)", step, c->slots);
     DeviceGuard guard;
     const int n = c->ndev, b = step & 1;
+    const bool exchange = n > 1 || c->use_rccl;
     auto slot = [&](int e, int d) { return c->slot_ev[(3 * (size_t)step + e) * n + d]; };
     auto rb = [&](int d) { return b ? c->r2[d] : c->r[d]; };
     auto sb = [&](int d) { return b ? c->sr2[d] : c->sr[d]; };
@@ -497,7 +498,13 @@ extern "C" int clm4_sharded_mvm_enqueue(clm4_shard_ctx *c, int step, int timed)
                           sb(d) + c->row_begin[d] / 64, nullptr, c->st[d]);
         if (rc != CLV_OK) return rc;
         if (timed) CLV_HIP(hipEventRecord(slot(1, d), c->st[d]));
-        CLV_HIP(hipEventRecord(c->kdone[2 * d + b], c->st[d]));
+        if (exchange) CLV_HIP(hipEventRecord(c->kdone[2 * d + b], c->st[d]));
+    }
+    if (!exchange) {
+        // one shard and no communicator: nothing leaves the device, the exchange stream stays out of it (every event record and
+        // cross-stream wait is a barrier packet in the queue: ~5 us each between back-to-back launches)
+        if (timed) CLV_HIP(hipEventRecord(slot(2, 0), c->st[0]));
+        return CLV_OK;
     }
     if (n > 1 && c->loopback) {
         for (int d = 0; d < n; d++) {
@@ -532,11 +539,6 @@ extern "C" int clm4_sharded_mvm_enqueue(clm4_shard_ctx *c, int step, int timed)
                 }
         }
         CLV_NCCL(g.end());
-    } else {
-        for (int d = 0; d < n; d++) {                           // one shard: nothing to exchange, the exchange stream only follows
-            CLV_HIP(hipSetDevice(c->dev[d]));
-            CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * d + b], 0));
-        }
     }
     for (int d = 0; d < n; d++) {
         CLV_HIP(hipSetDevice(c->dev[d]));
@@ -708,6 +710,7 @@ extern "C" int clm4_sharded_gemm_enqueue(clm4_shard_ctx *c, int step, int timed)
     CLV_REQUIRE(!timed || step < c->slots, "clm4_sharded_gemm_enqueue: step %d has no event slot (%d reserved)", step, c->slots);
     DeviceGuard guard;
     const int n = c->ndev, b = step & 1;
+    const bool exchange = n > 1 || c->use_rccl;
     const uint64_t N = c->gemm_loop_n, K = c->cols;
     auto slot = [&](int e, int d) { return c->slot_ev[(3 * (size_t)step + e) * n + d]; };
     auto Cb = [&](int d) { return c->Cf[2 * d + b]; };
@@ -724,7 +727,11 @@ extern "C" int clm4_sharded_gemm_enqueue(clm4_shard_ctx *c, int step, int timed)
         int rc = clm4_gemm(c->A[d], c->sA[d], c->row_count[d], K, c->B[d], c->sB[d], N, Cb(d) + c->row_begin[d] * N, c->st[d]);
         if (rc != CLV_OK) return rc;
         if (timed) CLV_HIP(hipEventRecord(slot(1, d), c->st[d]));
-        CLV_HIP(hipEventRecord(c->kdone[2 * d + b], c->st[d]));
+        if (exchange) CLV_HIP(hipEventRecord(c->kdone[2 * d + b], c->st[d]));
+    }
+    if (!exchange) {                                            // one shard, no communicator: see clm4_sharded_mvm_enqueue
+        if (timed) CLV_HIP(hipEventRecord(slot(2, 0), c->st[0]));
+        return CLV_OK;
     }
     if (n > 1 && c->loopback) {
         for (int d = 0; d < n; d++) {

@@ -33,10 +33,11 @@ __device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, 
 }
 
 // lane = 4 dwords (half a block) of u and of v: 16-byte loads/stores, one shuffle for the block maximum.  U grid-stride steps per
-// iteration, all 2 U loads requested before the first value is computed (r5: with one step per iteration a wave had 2 KiB in flight and the
-// kernel sat at 0.69 of the HBM peak with the VALU 65 % busy)
+// iteration, all 2 U loads requested before the first value is computed.  Round 5 measured U = 1 / 2 / 4 on one box at n = 2^30
+// (tools/build_variant.py, profiles/r05_weak_kernels_ab.txt): 0.3442 / 0.3430 / 0.3377 ms -- the loads in flight are not what bounds
+// this 2-reads-1-write stream (5.3 TB/s, in family with the chip's copy-shaped kernels), so the plain U = 1 form stays.
 #ifndef SAA_U
-#define SAA_U 2
+#define SAA_U 1
 #endif
 template <bool NT, int U>
 __global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
@@ -1382,12 +1383,24 @@ struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global 
     }
     template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *h, uint32_t i, uint2 v)
     {
-        if (threadIdx.x != 0) return;
-        if (IN_LDS) h[i] = v;
-        else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            if (IN_LDS) h[i] = v;
+            else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // global-memory heap: lane 0's store and the other lanes' later loads of the same entry are ordered by the memory model, not by
+        // the in-order issue of one wavefront: release / acquire at wavefront scope (no instruction on gfx950 beyond a wait
+        // for the store; the LDS heap is ordered by the wave's own lgkmcnt waits)
+        if (!IN_LDS) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 };
 #define THR_VAL(e) __uint_as_float((e).x)
+// gt_idx_t (CloverBase.h:216-218): (a.value > b.value) || isnan(a.value).  The NaN clause decides only where a NaN magnitude (a block
+// scale that is NaN, or infinite over a zero nibble) sits in the initial heap -- kept so that the walk is the reference's for every input
+#define THR_GT(a, b) ((THR_VAL(a) > THR_VAL(b)) || THR_VAL(a) != THR_VAL(a))
 
 template <bool IN_LDS>
 __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ vals, uint32_t n, uint32_t k, uint2 *__restrict__ gheap,
@@ -1414,7 +1427,7 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
                 child = 2 * (child + 1);
                 uint2 a = ThrHeap::ld<IN_LDS>(h, child);
                 const uint2 b = ThrHeap::ld<IN_LDS>(h, child - 1);
-                if (THR_VAL(a) > THR_VAL(b)) { child--; a = b; }           // comp(first + child, first + (child - 1))
+                if (THR_GT(a, b)) { child--; a = b; }                      // comp(first + child, first + (child - 1))
                 ThrHeap::st<IN_LDS>(h, hole, a);
                 hole = child;
             }
@@ -1426,7 +1439,7 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
             while (hole > top) {                                           // __push_heap
                 const uint32_t par = (hole - 1) / 2;
                 const uint2 pe = ThrHeap::ld<IN_LDS>(h, par);
-                if (!(THR_VAL(pe) > THR_VAL(v))) break;                    // comp(first + parent, value)
+                if (!THR_GT(pe, v)) break;                                 // comp(first + parent, value)
                 ThrHeap::st<IN_LDS>(h, hole, pe);
                 hole = par;
             }
@@ -1501,6 +1514,8 @@ extern "C" uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad)
 template <int BITS>
 static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, hipStream_t st)
 {
+    // the walk steps a 32-bit element index 64 at a time (k_thr_ref_walk): base + 64 must not wrap
+    CLV_REQUIRE(n <= 0xFFFFFFFFull - 64, "threshold (reference order): n=%llu, at most 2^32 - 65 elements", (unsigned long long)n);
     if (!workspace) {
         int rc = clv_internal_workspace(&workspace, clv_threshold_reference_workspace_bytes(n_pad), st);
         if (rc) return rc;

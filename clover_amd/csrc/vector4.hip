@@ -433,12 +433,15 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
     int rc = clv_internal_sync_slots(&slots, (uint64_t)grid * 8, st);
     if (rc) return rc;
     const uint64_t nvec = n_pad / 32, per_thread = (nvec + (uint64_t)grid * DOT_FAST_THREADS - 1) / ((uint64_t)grid * DOT_FAST_THREADS);
-    if (per_thread >= 4)
-        hipLaunchKernelGGL(k_v4_dot_fast1<4>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec,
-                           (unsigned long long *)slots, out_dev);
-    else
-        hipLaunchKernelGGL(k_v4_dot_fast1<2>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec,
-                           (unsigned long long *)slots, out_dev);
+    static const int force_u = [] { const char *e = getenv("CLV_DOT_FAST_U"); return e ? atoi(e) : 0; }();      // A/B switch
+    const int u = force_u ? force_u : per_thread >= 4 ? 4 : 2;
+#define DOT1_LAUNCH(U)                                                                                                                      \
+    hipLaunchKernelGGL(k_v4_dot_fast1<U>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec, \
+                       (unsigned long long *)slots, out_dev)
+    if (u >= 4) DOT1_LAUNCH(4);
+    else if (u == 2) DOT1_LAUNCH(2);
+    else DOT1_LAUNCH(1);
+#undef DOT1_LAUNCH
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

@@ -172,6 +172,15 @@ inline void set_exactness(int e)
 
 class Mirror;
 
+/* blocks of this process that fell back from page tracking to explicit residency because mprotect ran out of map entries (see
+ * Mirror::protect): 0 in a healthy process.  A host that keeps pointers across device operations can assert on it. */
+inline std::atomic<uint64_t> &untracked_count()
+{
+    static std::atomic<uint64_t> n(0);
+    return n;
+}
+inline uint64_t untracked_blocks() { return untracked_count().load(std::memory_order_relaxed); }
+
 namespace detail {
 
 inline long futex(std::atomic<int> *word, int op, int val)
@@ -307,7 +316,10 @@ public:
     enum State { HOST_DIRTY, SHARED, DEVICE_DIRTY };
 
     Mirror() : host_(nullptr), alias_(nullptr), dev_(nullptr), bytes_(0), span_(0), state_(HOST_DIRTY), owns_host_(true), mapped_(false), pending_(false), untracked_(false), restricted_(false), version_(0), pins_(0), spurious_(0) {}
-    bool tracked() const { return !untracked_; }
+    /* false once the kernel refused to protect this block's pages (ENOMEM: vm.max_map_count) while they were fully open: the block then
+     * follows the EXPLICIT-RESIDENCY rules -- re-take getData() after a device operation -- for the rest of its life.  Process-wide:
+     * clover_hip::untracked_blocks(). */
+    bool tracked() const { return !untracked_.load(std::memory_order_acquire); }
     ~Mirror() { release(); }
     Mirror(const Mirror &) = delete;
     Mirror &operator=(const Mirror &) = delete;
@@ -353,7 +365,7 @@ public:
 #ifdef CLOVER_HIP_NO_PAGE_TRACKING
         return host_rw();
 #else
-        if (untracked_) return host_rw();          /* a block whose protection the kernel refused (ENOMEM): explicit-residency rules */
+        if (!tracked()) return host_rw();          /* a block whose protection the kernel refused (ENOMEM): explicit-residency rules */
         host_ro();                                 /* (a view aliases caller memory, which is always current: write-through) */
         return host_;
 #endif
@@ -484,19 +496,23 @@ private:
     void protect(int prot)
     {
 #ifndef CLOVER_HIP_NO_PAGE_TRACKING
-        if (untracked_ || !owns_host_ || !host_) return;
+        if (!tracked() || !owns_host_ || !host_) return;
         int rc;
 #ifdef CLOVER_HIP_TEST_MPROTECT_ENOMEM                                    /* tests: pretend the kernel ran out of map entries */
         if (prot != (PROT_READ | PROT_WRITE) && clover_hip_test_mprotect_enomem) { rc = -1; errno = ENOMEM; }
         else
 #endif
         rc = mprotect(host_, span_, prot);
-        if (rc == 0) { if (prot != (PROT_READ | PROT_WRITE)) restricted_ = true; return; }
+        /* restricted_ = the pages are NOT fully open right now (it follows the last successful call, r5: a long-lived block that is back
+         * to read/write when the kernel runs out of map entries can fall back like a fresh one) */
+        if (rc == 0) { restricted_ = prot != (PROT_READ | PROT_WRITE); return; }
         if (errno == ENOMEM && prot != (PROT_READ | PROT_WRITE) && !restricted_) {
-            /* vm.max_map_count reached (a plain-allocation block: protecting a part of the heap splits its mapping).  The block was
-             * never restricted, so it can simply stay open: from here on it follows the EXPLICIT-RESIDENCY rules (getData() pulls and
-             * marks the host copy; a pointer kept across a device operation shows the bytes from before it) instead of ending the process */
-            untracked_ = true;
+            /* vm.max_map_count reached (a plain-allocation block: protecting a part of the heap splits its mapping).  The block is fully
+             * open at this moment, so it can simply stay open: from here on it follows the EXPLICIT-RESIDENCY rules (getData() pulls and
+             * marks the host copy; a pointer kept across a device operation shows the bytes from before it) instead of ending the
+             * process.  Observable: Mirror::tracked(), clover_hip::untracked_blocks(), and one line on stderr per block. */
+            untracked_.store(true, std::memory_order_release);
+            untracked_count().fetch_add(1, std::memory_order_relaxed);
             static const char msg[] = "clover_hip: mprotect: out of map entries, a block falls back to explicit residency\n";
             ssize_t w = write(2, msg, sizeof(msg) - 1);
             (void)w;
@@ -577,7 +593,8 @@ private:
         span_ = 0;
         state_.store(HOST_DIRTY, std::memory_order_release);
         pending_ = false;
-        untracked_ = restricted_ = false;
+        untracked_.store(false, std::memory_order_release);
+        restricted_ = false;
     }
     /* the host block: two mappings of one anonymous memory file where the platform has memfd_create (tracked builds), else one
      * page-aligned allocation as in the reference (CloverVector4.h:70-79) */
@@ -618,8 +635,9 @@ private:
     bool owns_host_;
     bool mapped_;                      /* host_/alias_ are two mmaps of one memfd (else: posix_memalign, alias_ == host_) */
     bool pending_;
-    bool untracked_;                   /* mprotect refused with ENOMEM before the block was ever restricted: explicit-residency rules from then on */
-    bool restricted_;                  /* a restricting mprotect has succeeded on this block */
+    std::atomic<bool> untracked_;      /* mprotect refused with ENOMEM while the block was fully open: explicit-residency rules from then on
+                                        * (read without lock_ by host_ptr() / tracked(): atomic) */
+    bool restricted_;                  /* the pages are not fully open at the moment (under lock_) */
     uint64_t version_;                 /* see device_version() */
     detail::SpinLock lock_;            /* every state change of this block, from methods and from the fault handler */
     std::atomic<int> pins_;            /* fault handlers between table lookup and resolution: the destructor waits for 0 */

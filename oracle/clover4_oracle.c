@@ -438,7 +438,10 @@ static void sift_min(heap_item *h, uint64_t pos, uint64_t k)      /* min_heapify
     }
 }
 
-/* std::make_heap(first, last, gt): libstdc++'s bottom-up construction with comparator "a > b" (min-heap) */
+/* gt_idx_t (CloverBase.h:216-218): (a.value > b.value) || isnan(a.value) -- the NaN clause only matters for non-finite block scales */
+static int gt_item(const heap_item *a, const heap_item *b) { return (a->value > b->value) || isnan(a->value); }
+
+/* std::make_heap(first, last, gt_idx_t): libstdc++'s bottom-up construction (min-heap) */
 static void push_down_gt(heap_item *h, uint64_t hole, uint64_t len, heap_item v)
 {
     /* __adjust_heap: move the hole down to a leaf choosing the child that is NOT "less" under comp,
@@ -447,7 +450,7 @@ static void push_down_gt(heap_item *h, uint64_t hole, uint64_t len, heap_item v)
     uint64_t child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (h[child].value > h[child - 1].value) child--;            /* comp(first+child, first+child-1) */
+        if (gt_item(&h[child], &h[child - 1])) child--;               /* comp(first+child, first+child-1) */
         h[hole] = h[child];
         hole = child;
     }
@@ -457,7 +460,7 @@ static void push_down_gt(heap_item *h, uint64_t hole, uint64_t len, heap_item v)
         hole = child - 1;
     }
     uint64_t parent = (hole - 1) / 2;
-    while (hole > top && h[parent].value > v.value) {                 /* comp(first+parent, value) */
+    while (hole > top && gt_item(&h[parent], &v)) {                   /* comp(first+parent, value) */
         h[hole] = h[parent];
         hole = parent;
         parent = (hole - 1) / 2;

@@ -40,8 +40,19 @@ int main()
     EXPECT(t.tracked() && t.state() == Mirror::SHARED);
     memset(t.dev_wo(), 6, 8192);
     EXPECT(p[8000] == 6 && t.state() == Mirror::SHARED);          // kept pointer: fault -> copy back
-    // 3. a block that HAS been restricted before keeps its protection when a later mprotect is refused?  No: that would leave pages
-    //    the state machine cannot account for -- such a refusal is fatal (checked by reading the code path, not by dying here)
+    // 3. the fallback is observable in code: a process-wide count of the blocks that fell back
+    EXPECT(clover_hip::untracked_blocks() == 1);
+    // 4. a LONG-LIVED block: restricted earlier, fully open again (HOST_DIRTY) at the moment the kernel runs out of map entries -- it
+    //    falls back like a fresh one (restricted_ follows the CURRENT protection) instead of ending the process
+    t.host_rw()[1] = 11;                                           // SHARED -> HOST_DIRTY: pages read/write again
+    EXPECT(t.state() == Mirror::HOST_DIRTY && t.tracked());
+    clover_hip_test_mprotect_enomem = 1;
+    EXPECT(t.dev_ro()[1] == 11 && !t.tracked() && clover_hip::untracked_blocks() == 2);
+    memset(t.dev_wo(), 8, 8192);
+    EXPECT(t.host_ptr()[4000] == 8);                               // explicit rules from here on: re-taken pointer pulls
+    clover_hip_test_mprotect_enomem = 0;
+    // 5. a refusal while the pages are NOT fully open stays fatal: the state machine could not account for them (read in the code path,
+    //    Mirror::protect; not exercised here because it ends the process)
     std::printf(failures ? "mirror enomem FAILED\n" : "mirror enomem ok\n");
     return failures ? 1 : 0;
 }

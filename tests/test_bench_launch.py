@@ -74,7 +74,27 @@ def test_self_launch_builds_the_drivers_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-REHEARSAL = {"CLOVER_BENCH_DEBUG_ONE_GPU": "1", "CLOVER_BENCH_C5_ROWS": "16384"}
+REHEARSAL = {"CLOVER_BENCH_DEBUG_ONE_GPU": "1", "CLOVER_BENCH_C5_ROWS": "16384", "CLOVER_BENCH_GEMM_SIZE": "1024"}
+
+
+def check_product_loops(out, n, rehearsal, gemm_size=1024):
+    """round 5: the line of a ranks run also carries the PRODUCT's own multi-GPU loops over the same N devices, driven by rank 0 behind the
+    ranks' timed regions -- `one_process` (clm4_sharded_mvm_enqueue: c3 shards + its own c5) and `gemm_sharded` (configs[3] split by rows of
+    A, C row panels all-gathered: SURVEY 8(e))"""
+    op = out["one_process"]
+    assert "failed" not in op, op
+    assert op["n_gpus"] == n and op["ms_per_step"] > 0 and op["value"] > 0 and 0 < op["kernel_frac"] < 1
+    assert op["gathered_result_verified"] is True and len(op["per_rank_kernel_ms"]) == n and len(op["gather_ms_behind_kernel"]) == n
+    assert op["c5"]["mode"] == "one-process" and op["c5"]["gathered_result_verified"] is True and op["c5"]["n_gpus"] == n
+    g = out["gemm_sharded"]
+    assert "failed" not in g and "skipped" not in g, g
+    assert g["n_gpus"] == n and g["rows_per_gpu"] == gemm_size // n and g["unit"] == "TOP/s" and g["value"] > 0 and g["ms_per_step"] > 0
+    assert g["gathered_c_verified"] is True and len(g["per_rank_kernel_ms"]) == n and len(g["gather_ms_behind_kernel"]) == n
+    assert g["kernel_only_aggregate_TOPs"] >= g["value"] * 0.999 and g["c_panel_bytes"] == (gemm_size // n) * gemm_size * 4
+    assert ("NOT configs[3]" in g["workload"]) == (gemm_size != 8192)
+    if rehearsal:
+        assert op["degraded"] is True and g["degraded"] is True and "copies" in g["exchange"]
+    return op, g
 
 
 def check_c5(out, n, rows_total=16384, cols=8192):
@@ -102,6 +122,8 @@ def check_two_way(out, mode):
     assert out["degraded"] is True and out["value_kernel_only"] > 0
     assert check_c5(out, 2)["degraded"] is True
     assert cfg["settle_launches"] >= 8
+    if mode == "ranks":
+        check_product_loops(out, 2, rehearsal=True)
 
 
 @pytest.mark.gpu
@@ -109,6 +131,17 @@ def test_two_rank_rehearsal_self_launched():
     out = json_line(run_bench(["--gpus", "2", *SMALL], REHEARSAL))
     check_two_way(out, "ranks")
     assert out["config"]["backend"] == "gloo" and "self-launch" in out["config"]["launcher"]
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_line_carries_everything_the_8_gpu_record_needs():
+    """VERDICT r4 #1: ONE `bench.py --gpus 2` line (rehearsal: both ranks on device 0) with c5, one_process, gemm_sharded AND cpu_baseline"""
+    args = [a for a in SMALL if a != "--no-cpu-baseline"] + ["--cpu-sample-rows", "1024"]
+    out = json_line(run_bench(["--gpus", "2", *args], REHEARSAL))
+    check_two_way(out, "ranks")
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["gpu_result_matches_cpu"] is True and cb["cores"] >= 1
+    assert "gemm" not in out and "extras" not in out                 # the one-GPU side measurements stay with N = 1
 
 
 @pytest.mark.gpu
@@ -127,13 +160,26 @@ def test_ranks_path_through_rccl_with_one_rank():
     executes on the one-GPU box"""
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", "29733"]
-    out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLOVER_BENCH_FORCE_DIST": "1", "CLOVER_BENCH_C5_ROWS": "16384"}, launcher=launcher))
+    out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLOVER_BENCH_FORCE_DIST": "1", "CLOVER_BENCH_C5_ROWS": "16384", "CLOVER_BENCH_GEMM_SIZE": "1024"}, launcher=launcher))
     cfg = out["config"]
     assert out["n_gpus"] == 1 and cfg["backend"] == "nccl" and cfg["rccl_ranks"] == 1 and cfg["gathered_result_verified"] is True
     assert cfg["mode"] == "ranks" and "nccl_fallback_reason" not in cfg and "DEBUG" not in cfg
     assert cfg["gather_us_blocking"] > 0 and len(cfg["per_rank_kernel_ms"]) == 1
     assert "degraded" not in out and "degraded" not in check_c5(out, 1) and out["c5"]["backend"] == "nccl"
     assert out["ms_per_step_cold"] > 0 and out["roofline"]["kernel_avg_ms_cold"] > 0
+    # the product's loops behind it, one shard, no communicator needed
+    op, g = check_product_loops(out, 1, rehearsal=False)
+    assert "degraded" not in op and "degraded" not in g and g["exchange"].startswith("none")
+
+
+@pytest.mark.gpu
+def test_product_loops_in_the_ranks_line_through_rccl_with_a_communicator_of_one_rank():
+    """CLV_SHARDED_RCCL_SELFTEST=1: rank 0's one-process loops take the RCCL branches -- the in-place ncclAllGather pair of the packed mvm
+    result and the ncclAllGather of the fp32 C row panel (clm4_sharded_gemm_enqueue) -- with a communicator of one rank, on the one-GPU box"""
+    out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLV_SHARDED_RCCL_SELFTEST": "1", "CLOVER_BENCH_C5_ROWS": "16384", "CLOVER_BENCH_GEMM_SIZE": "1024"}))
+    op, g = check_product_loops(out, 1, rehearsal=False)
+    assert op["rccl_ranks"] == 1 and op["backend"].startswith("rccl") and g["rccl_ranks"] == 1 and "ncclAllGather" in g["exchange"]
+    assert "degraded" not in op and "degraded" not in g
 
 
 @pytest.mark.gpu
@@ -143,7 +189,7 @@ def test_rccl_failure_falls_back_to_gloo_and_says_degraded():
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", "29735"]
     out = json_line(run_bench(["--gpus", "1", *SMALL], {"CLOVER_BENCH_FORCE_DIST": "1", "CLOVER_BENCH_FORCE_GLOO_FALLBACK": "1",
-                                                        "CLOVER_BENCH_C5_ROWS": "16384"}, launcher=launcher))
+                                                        "CLOVER_BENCH_C5_ROWS": "16384", "CLOVER_BENCH_GEMM_SIZE": "1024"}, launcher=launcher))
     cfg = out["config"]
     assert cfg["backend"] == "gloo" and "CLOVER_BENCH_FORCE_GLOO_FALLBACK" in cfg["nccl_fallback_reason"] and cfg["gathered_result_verified"] is True
     assert out["degraded"] is True and "RCCL unavailable" in out["degraded_why"] and out["value_kernel_only"] >= out["value"] * 0.5

@@ -187,6 +187,25 @@ def test_gpu_threshold_reference_order(hip, oracle, case, data):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(4096, 512), (65536, 20000)])
+def test_gpu_threshold_reference_order_with_nan_and_inf_scales(hip, oracle, case):
+    """gt_idx_t (CloverBase.h:216-218) is (a.value > b.value) || isnan(a.value): with a NaN block scale (NaN magnitudes) or an infinite one
+    (inf, and NaN over a zero nibble) among the first k elements the initial make_heap takes other turns than a plain `>` -- outside the
+    reference's data contract, but the walk is the reference's for those inputs too.  LDS heap and global-memory heap."""
+    n, k = case
+    rng = np.random.default_rng(n + k)
+    q, s = random_packed(rng, n)
+    s = s.copy()
+    s[1] = np.float32(np.nan)
+    s[3] = np.float32(np.inf)
+    s[(k // 64) + 2] = np.float32(np.nan)               # one beyond the first k elements: never enters (NaN > root is false)
+    with np.errstate(invalid="ignore"):
+        ref = oracle.v4_threshold(q, s, n, k)
+        out = hip.v4_threshold(q, s, n, k, mode=THRESHOLD_REFERENCE)
+    assert same(out, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k", [0, 1, 100])
 def test_gpu_threshold_reference_order_leaves_the_padding_alone(hip, oracle, k):
     """raw ABI input whose nibbles beyond n are NOT zero (a container never produces that): both modes touch the first n elements only,

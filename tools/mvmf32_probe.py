@@ -26,5 +26,7 @@ for t, sd in ((s1, 6), (s2, 7)):
 rng = hip.new_rng(1, 2)
 for _ in range(5):
     hip.check(lib.clv4_scale_and_add(q1.ptr, s1.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, rng.ptr, None))
+for _ in range(5):                                   # round 5: the deterministic kernel beside it
+    hip.check(lib.clv4_scale_and_add(q1.ptr, s1.ptr, q2.ptr, s2.ptr, 0.5, n, q3.ptr, s3.ptr, None, None))
 hip.sync()
 print("weak kernels probe done")
