@@ -249,11 +249,15 @@ def main() -> None:
                          "driven by rank 0 behind the ranks' timed regions)")
     ap.add_argument("--cpu-baseline-child", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--gemm-probe-child", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--product-loops-child", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.warmup is None:
         args.warmup = 80 if args.workload == "gemm" else 20
     if args.event_every <= 0:
         args.event_every = max(1, min(8, args.steps // 8))
+    if args.product_loops_child:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return product_loops_child(args, args.product_loops_child)
     if args.gemm_probe_child:
         return gemm_probe_child(args.gemm_probe_child, args.gemm_size)
     if args.workload == "gemm":
@@ -588,16 +592,9 @@ def main() -> None:
     if dist_on:
         dist.barrier()                                           # every rank is past its last kernel and collective
         dist.destroy_process_group()                             # torch's RCCL communicators are gone before the product builds its own
-    n_dev = world
     if not args.no_one_process and (world == 1 or debug_one_gpu or torch.cuda.device_count() >= world):
-        for key, fn in (("one_process", one_process_object), ("gemm_sharded", gemm_sharded_measure)):
-            try:
-                torch.cuda.empty_cache()
-                out[key] = fn(args, torch, hip, n_dev)
-            except Exception as e:                               # noqa: BLE001 -- a side measurement must never cost the headline line
-                out[key] = {"failed": f"{type(e).__name__}: {e}"[:400]}
-        hip.check(lib.clv_set_device(dev_index))
-        torch.cuda.set_device(dev_index)
+        torch.cuda.empty_cache()
+        out.update(run_product_loops(args, world))
 
     # side measurements first, while the chip is warm from the timed loop (the matrix pipe's clocks need ~50 calls to settle after an idle
     # period, and the CPU baseline below leaves the GPU idle for half a minute: round 3 measured the GEMM 5 % slower behind it)
@@ -810,6 +807,42 @@ def one_process_measure(args, torch, hip, n: int) -> dict:
         out["roofline"]["traffic"] = tr[0]
         out["roofline"]["traffic_source"] = f"profiles/{tr[1]}"
     return out
+
+
+def product_loops_child(args, n: int) -> None:
+    """`--product-loops-child N` (started by run_product_loops): both product loops over N devices in a process of their own"""
+    import torch
+
+    from clover_amd.lib_binding import CloverHip
+    hip = CloverHip(device=0)
+    res = {}
+    for key, fn in (("one_process", one_process_object), ("gemm_sharded", gemm_sharded_measure)):
+        try:
+            res[key] = fn(args, torch, hip, n)
+        except Exception as e:                                   # noqa: BLE001
+            res[key] = {"failed": f"{type(e).__name__}: {e}"[:400]}
+        torch.cuda.empty_cache()
+    print(json.dumps(res))
+
+
+def run_product_loops(args, n: int) -> dict:
+    """The product's own loops over the same N devices (`one_process`, `gemm_sharded`) in a CHILD process with a time limit: a side
+    measurement -- RCCL through dlopen, ncclCommInitAll over N devices, paths no one-GPU box can rehearse with more than one rank --
+    must never cost the headline line, whether it raises, crashes or hangs."""
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--product-loops-child", str(n), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--rows-per-gpu", str(args.rows_per_gpu), "--cols", str(args.cols), "--settle-ms", str(args.settle_ms), "--event-every", str(args.event_every),
+           "--gemm-size", str(args.gemm_size), *(["--preset", args.preset] if args.preset else []), *(["--no-c5"] if args.no_c5 else [])]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                               "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            raise RuntimeError(f"child exit code {p.returncode}: {p.stderr.strip()[-300:]}")
+        return json.loads(lines[-1])
+    except Exception as e:                                       # noqa: BLE001
+        why = {"failed": f"{type(e).__name__}: {e}"[:500]}
+        return {"one_process": why, "gemm_sharded": dict(why)}
 
 
 def one_process_object(args, torch, hip, n: int) -> dict:

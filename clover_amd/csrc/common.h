@@ -269,6 +269,35 @@ __device__ __forceinline__ void unpack8_x16(uint32_t w, float f[8])
     f[6] = sbyte3_to_f32(even); f[7] = sbyte3_to_f32(odd);
 }
 
+// The same 8 nibbles as floats of ONE SIXTEENTH their value, f[e] = q_e / 16 (exact), one instruction per element and no masks:
+// v_cvt_off_f32_i4 converts the signed 4-bit integer in bits [3:0] of its source (the hardware's interpolation-offset table: 1000 ->
+// -0.5 ... 0111 -> 0.4375) and the SDWA source select hands it byte K -- the low nibble of byte K is element 2K+1, and after ONE shift
+// of the word by 4 the same select reaches the high nibbles (elements 2K): 9 VALU per word instead of 11.  The caller folds the 16
+// into its scale: (q / 16) * (16 s) is the same real number as q * s and 16 s is exact unless it overflows (times16_is_finite), so the
+// product rounds identically -- also for denormal scales, where the s / 16 form above has to take the plain path.
+#define CLV_LOWNIB_16TH(K)                                                                                                       \
+    __device__ __forceinline__ float lownib##K##_16th(uint32_t w)                                                                \
+    {                                                                                                                           \
+        float f;                                                                                                                \
+        asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #K : "=v"(f) : "v"(w));          \
+        return f;                                                                                                               \
+    }
+CLV_LOWNIB_16TH(0)
+CLV_LOWNIB_16TH(1)
+CLV_LOWNIB_16TH(2)
+CLV_LOWNIB_16TH(3)
+#undef CLV_LOWNIB_16TH
+
+__device__ __forceinline__ void unpack8_16th(uint32_t w, float f[8])
+{
+    const uint32_t hi = w >> 4;
+    f[0] = lownib0_16th(hi); f[1] = lownib0_16th(w);
+    f[2] = lownib1_16th(hi); f[3] = lownib1_16th(w);
+    f[4] = lownib2_16th(hi); f[5] = lownib2_16th(w);
+    f[6] = lownib3_16th(hi); f[7] = lownib3_16th(w);
+}
+__device__ __forceinline__ bool times16_is_finite(float s) { return __builtin_fabsf(s * 16.0f) < __builtin_inff(); }
+
 // s / 16 is exact unless it falls into the denormals: true when (16 q) * (s / 16) rounds exactly like q * s
 __device__ __forceinline__ bool sixteenth_is_exact(float s)
 {

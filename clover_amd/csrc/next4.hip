@@ -88,6 +88,111 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const
     }
 }
 
+// Large vectors (round 5): the same arithmetic with the PER-BLOCK work done once per block instead of once per lane.  Counters of the
+// kernel above at n = 2^30 (profiles/r05_weak_kernels_pmc.txt): 8.4 VALU instructions per element = 87 % of the VALU issue slots at
+// 1.84 GHz -- it is bound by its instruction count, not by HBM -- and ~1.2 of the 8.4 are block scalars (two div7, the 1/16 scaling, the
+// exactness test, fix_zero, the division 7 / max, the overflow guard) that both lanes of a block compute for themselves.  Here a wave
+// takes 64 blocks = two steps of 64 half-block lanes:
+//   A  lane = BLOCK: the 64 scale pairs are one coalesced load each; su7, sv7 and their 16-fold (see unpack8_16th) once per block;
+//      ds_bpermute hands lane (step, half-block) its block's two factors (the LDS crossbar, not the VALU);
+//   B  lane = half a block, as above: nibbles as q / 16 (9 instead of 11 VALU per word), value = fma(qv/16, 16 sv7, qu/16 * 16 su7),
+//      |max| of the 32 values, pair maximum by DPP;
+//   C  lane = BLOCK again: maxima gathered by two ds_bpermute, 0 -> 1.0, k = 7 / max (k = 0 where the reference's cvttps overflow
+//      makes every nibble 0, see quant_pack8), ONE coalesced store of the 64 scales, k back out by ds_bpermute;
+//   D  quantise and store.
+// All loads of a wave's chunk precede its stores lane by lane, so r may alias qu or qv as before.
+__device__ __forceinline__ uint32_t quant_pack8_k(const float v[8], float k)      // quant_pack8 without its overflow guard (folded into k)
+{
+    uint32_t even = cvt_i32_byte0_first(v[0] * k), odd = cvt_i32_byte0_first(v[1] * k);
+    cvt_i32_into_byte1(even, v[2] * k);
+    cvt_i32_into_byte1(odd, v[3] * k);
+    cvt_i32_into_byte2(even, v[4] * k);
+    cvt_i32_into_byte2(odd, v[5] * k);
+    cvt_i32_into_byte3(even, v[6] * k);
+    cvt_i32_into_byte3(odd, v[7] * k);
+    return nibbles_from_bytes(even, odd);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void k_v4_scale_and_add_blk(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
+                                                              const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nblocks)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4, nquads = 2 * nblocks;
+    for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c * 64 < nblocks; c += nwaves) {
+        const uint64_t b0 = c * 64, bl = b0 + lane, blc = bl < nblocks ? bl : b0;
+        u32x4 wu[2], wv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint64_t h = 2 * b0 + 64 * u + lane, hc = h < nquads ? h : 2 * b0;
+            wu[u] = NT ? __builtin_nontemporal_load(qu + hc) : qu[hc];
+            wv[u] = NT ? __builtin_nontemporal_load(qv + hc) : qv[hc];
+        }
+        const float fsu = su[blc], fsv = sv[blc];
+        asm volatile("" ::: "memory");
+        // A: lane = block
+        const float su7 = div7(fsu), sv7 = div7(fsv * a);
+        const bool fast = __all(times16_is_finite(su7) && times16_is_finite(sv7));      // wave-uniform: a real branch below
+        const float fa = fast ? su7 * 16.0f : su7, fb = fast ? sv7 * 16.0f : sv7;
+        float cu[2], cv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int src = 4 * (32 * u + (lane >> 1));
+            cu[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(fa)));
+            cv[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(fb)));
+        }
+        // B: lane = half a block
+        float v[2][4][8], mb[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t xu[4] = {wu[u].x, wu[u].y, wu[u].z, wu[u].w}, xv[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+            if (fast) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float fu[8], fv[8];
+                    unpack8_16th(xu[q], fu);
+                    unpack8_16th(xv[q], fv);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[u][q][e] = __builtin_fmaf(fv[e], cv[u], fu[e] * cu[u]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[u][q][e] = __builtin_fmaf((float)unpack1(xv[q], e), cv[u], (float)unpack1(xu[q], e) * cu[u]);
+            }
+            float m = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[u][q][e]));
+            mb[u] = fmaxf(m, __shfl_xor(m, 1));
+        }
+        // C: lane = block (lanes 0..31: the blocks of step 0, lanes 32..63: step 1); the block's maximum sits in lanes 2 b', 2 b' + 1
+        const int from = 4 * (2 * (lane & 31));
+        const float m0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[0])));
+        const float m1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[1])));
+        const float m = fix_zero_max(lane < 32 ? m0 : m1);
+        float k = 7.0f / m;                                   // IEEE-correct fp32 division (CloverVector4.h:1390)
+        k = k < __builtin_inff() ? k : 0.0f;                  // 7 / max overflows: every nibble of the block is 0 (quant_pack8's guard)
+        if (bl < nblocks) sr[bl] = m;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const float kk = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (32 * u + (lane >> 1)), __float_as_int(k)));
+            // D
+            u32x4 o;
+            o.x = quant_pack8_k(v[u][0], kk);
+            o.y = quant_pack8_k(v[u][1], kk);
+            o.z = quant_pack8_k(v[u][2], kk);
+            o.w = quant_pack8_k(v[u][3], kk);
+            const uint64_t h = 2 * b0 + 64 * u + lane;
+            if (h < nquads) {
+                if (NT) __builtin_nontemporal_store(o, r + h); else r[h] = o;
+            }
+        }
+    }
+}
+
 // stochastic variant: same segment walk as k_v4_quantize_st (rng4.hip); the nibbles are unpacked by bit
 // position there, so noise group g of AVX lane j meets element 8j + (g ^ 1) (CloverVector4.h:1236-1243).
 template <int S, bool NT = false>
@@ -214,6 +319,10 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
     }
 }
 
+#ifndef SAA_BLK_MIN_BLOCKS
+#define SAA_BLK_MIN_BLOCKS 4096u      // n >= 2^18: the block-scalar kernel; below that the launch-bound sizes of the IHT / GD loops keep the plain one
+#endif
+
 extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
                                   int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream)
 {
@@ -222,6 +331,17 @@ extern "C" int clv4_scale_and_add(const int8_t *qu, const float *su, const int8_
     if (!n_pad) return CLV_OK;
     hipStream_t st = as_stream(stream);
     const uint64_t nwords = n_pad / 8, nb = n_pad / 64;
+    if (!rng_state_dev && nb >= SAA_BLK_MIN_BLOCKS) {
+        // one wave per 64 blocks, at most 8 workgroups per CU (grid-stride over the chunks)
+        const uint64_t want = (nb + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+        const dim3 grid((unsigned)(want < cap ? want : cap));
+        if (3 * (n_pad / 2) > (256ull << 20))
+            hipLaunchKernelGGL(k_v4_scale_and_add_blk<true>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a, (u32x4 *)r, sr, nb);
+        else
+            hipLaunchKernelGGL(k_v4_scale_and_add_blk<false>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a, (u32x4 *)r, sr, nb);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
     if (!rng_state_dev) {
         const uint64_t nquads = nwords / 4;
         const uint64_t want = (nquads + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;

@@ -434,7 +434,10 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
     if (rc) return rc;
     const uint64_t nvec = n_pad / 32, per_thread = (nvec + (uint64_t)grid * DOT_FAST_THREADS - 1) / ((uint64_t)grid * DOT_FAST_THREADS);
     static const int force_u = [] { const char *e = getenv("CLV_DOT_FAST_U"); return e ? atoi(e) : 0; }();      // A/B switch
-    const int u = force_u ? force_u : per_thread >= 4 ? 4 : 2;
+    // loads in flight per thread, measured on one box (profiles/r05_dot_fast_ab.jsonl, us at n = 2^24 / 2^26 / 2^29 / 2^30): U = 1: 4.19 / 11.6 /
+    // 88.7 / 174.0, U = 2: 4.02 / 12.2 / 92.5 / 189.3, U = 4: 5.05 / 12.3 / 120.0 / 217.1 (two launches: 6.38 / 14.7 / 91.0 / 181.7) -- deeper
+    // only pays where a thread has two steps in all (one round trip instead of two); long vectors want the plain loop
+    const int u = force_u ? force_u : per_thread <= 2 ? 2 : 1;
 #define DOT1_LAUNCH(U)                                                                                                                      \
     hipLaunchKernelGGL(k_v4_dot_fast1<U>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec, \
                        (unsigned long long *)slots, out_dev)

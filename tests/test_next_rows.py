@@ -80,7 +80,7 @@ def test_oracle_threshold_matches_std_make_heap(oracle, tmp_path):
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [128, 256, 2048 + 128, 1 << 16, (1 << 20) + 128])
+@pytest.mark.parametrize("n", [128, 256, 2048 + 128, 1 << 16, (1 << 18) - 128, 1 << 18, (1 << 18) + 128, (1 << 18) + 64 * 63 + 64, (1 << 20) + 128])
 def test_gpu_scale_and_add_bit_exact(hip, oracle, n):
     rng = np.random.default_rng(n)
     (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
@@ -93,6 +93,35 @@ def test_gpu_scale_and_add_bit_exact(hip, oracle, n):
     r, sr = hip.v4_scale_and_add(qu, su, qv, sv, 0.5, in_place=True)       # x.scaleAndAdd(t, mu) of the IHT loop
     assert same(r, oracle.v4_scale_and_add(qu, su, qv, sv, 0.5)[0])
     assert sr[0] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1 << 16, 1 << 18, (1 << 19) + 640])
+def test_gpu_scale_and_add_extreme_scales(hip, oracle, n):
+    """both deterministic kernels (the plain one below 2^18 elements, the block-scalar one from there on) at the ends of the fp32 range: block
+    scales near FLT_MAX (the 16-fold scale of the nibble -> q/16 conversion would overflow: the wave takes the plain conversion), denormal
+    scales, zero blocks on either side, and scales so small that 7 / max overflows (every nibble of the block becomes 0, as in the reference)"""
+    rng = np.random.default_rng(n + 1)
+    (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
+    nb = n // 64
+    su, sv = su.copy(), sv.copy()
+    su[0::7] = np.float32(2.0e38)
+    sv[3::11] = np.float32(1.5e38)
+    su[1::13] = np.float32(1e-42)                          # denormal
+    sv[1::13] = np.float32(3e-43)
+    su[5::17] = np.float32(1e-39)
+    sv[5::17] = np.float32(1e-39)
+    qu[32 * 2:32 * 3] = 0
+    qv[32 * 4:32 * 5] = 0
+    qu[32 * 6:32 * 7] = 0
+    qv[32 * 6:32 * 7] = 0
+    for a in (1.0, -0.25, 1e-3):
+        with np.errstate(over="ignore", invalid="ignore"):
+            ro, sro = oracle.v4_scale_and_add(qu, su, qv, sv, a)
+        r, sr = hip.v4_scale_and_add(qu, su, qv, sv, a)
+        ok = np.isfinite(sro)                              # a block whose maximum overflowed to inf is outside the reference's contract
+        assert ok.sum() > nb // 2
+        assert same(sr[ok], sro[ok]) and same(r.reshape(nb, 32)[ok], ro.reshape(nb, 32)[ok])
 
 
 @pytest.mark.gpu

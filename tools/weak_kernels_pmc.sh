@@ -15,3 +15,4 @@ done
 timeout 120 python $R/tools/pmc_summary.py /tmp/wk_pmc k_m4_mvm_f32 < /dev/null
 timeout 120 python $R/tools/pmc_summary.py /tmp/wk_pmc k_v4_scale_and_add_st < /dev/null
 timeout 120 python $R/tools/pmc_summary.py /tmp/wk_pmc "k_v4_scale_and_add<" < /dev/null
+timeout 120 python $R/tools/pmc_summary.py /tmp/wk_pmc "k_v4_scale_and_add_blk" < /dev/null
