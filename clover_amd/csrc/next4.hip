@@ -11,19 +11,19 @@
 //     val = fma((float)qv, f32(f32(sv*a)/7), (float)qu * f32(su/7));  lane = 4 dwords (half a block) of u and of v.
 //     algorithmic bytes: 3 * (1/2 + 1/16) = 1.6875 per element.
 // =================================================================================================
-// su7 = f32(su / 7), sv7 = f32(f32(sv * a) / 7).  Fast form: the nibbles come as 16 q (unpack8_x16) and the scales as s / 16 --
-// bit-identical as long as s / 16 is exact (sixteenth_is_exact); blocks whose scale sits at the bottom of the fp32 range take the
-// plain form.
+// su7 = f32(su / 7), sv7 = f32(f32(sv * a) / 7).  Fast form: the nibbles come as q / 16 (unpack8_16th: one conversion per element, no
+// masks) and the scales as 16 s -- bit-identical as long as 16 s does not overflow (times16_is_finite); blocks whose scale sits at the
+// very top of the fp32 range take the plain form.
 __device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, float sv7, float v[8])
 {
-    const float su16 = su7 * 0.0625f, sv16 = sv7 * 0.0625f;
+    const float su16 = su7 * 16.0f, sv16 = sv7 * 16.0f;
     float fu[8], fv[8];
-    unpack8_x16(wu, fu);
-    unpack8_x16(wv, fv);
+    unpack8_16th(wu, fu);
+    unpack8_16th(wv, fv);
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = __builtin_fmaf(fv[e], sv16, fu[e] * su16);
     // a WAVE-uniform branch around the plain form: hipcc would otherwise if-convert a per-lane one and run both forms everywhere
-    if (!__all(sixteenth_is_exact(su7) && sixteenth_is_exact(sv7))) {
+    if (!__all(times16_is_finite(su7) && times16_is_finite(sv7))) {
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const float du = (float)unpack1(wu, e) * su7;
@@ -118,17 +118,28 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_blk(const u32x4 *qu, c
                                                               const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nblocks)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4, nquads = 2 * nblocks;
-    for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c * 64 < nblocks; c += nwaves) {
-        const uint64_t b0 = c * 64, bl = b0 + lane, blc = bl < nblocks ? bl : b0;
+    // the chunk index is wave-uniform: told to the compiler (readfirstlane), so that the chunk's base addresses and the full / ragged
+    // decision live in scalar registers and a lane adds only its own 32-bit offset (the 64-bit per-lane index arithmetic and the clamps
+    // were 10 % of the kernel's instructions)
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t c = (uint64_t)blockIdx.x * 4 + wave_in_wg; c * 64 < nblocks; c += nwaves) {
+        const uint64_t b0 = c * 64;
+        const uint32_t left = (uint32_t)(nblocks - b0 < 64 ? nblocks - b0 : 64);      // blocks of this chunk: 64 except in the last one
+        const u32x4 *pu = qu + 2 * b0, *pv = qv + 2 * b0;
+        u32x4 *pr = r + 2 * b0;
+        const float *psu = su + b0, *psv = sv + b0;
+        float *psr = sr + b0;
+        const bool full = left == 64;
         u32x4 wu[2], wv[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const uint64_t h = 2 * b0 + 64 * u + lane, hc = h < nquads ? h : 2 * b0;
-            wu[u] = NT ? __builtin_nontemporal_load(qu + hc) : qu[hc];
-            wv[u] = NT ? __builtin_nontemporal_load(qv + hc) : qv[hc];
+            const uint32_t h = 64 * u + lane, hc = full || h < 2 * left ? h : 0;
+            wu[u] = NT ? __builtin_nontemporal_load(pu + hc) : pu[hc];
+            wv[u] = NT ? __builtin_nontemporal_load(pv + hc) : pv[hc];
         }
-        const float fsu = su[blc], fsv = sv[blc];
+        const uint32_t blc = full || (uint32_t)lane < left ? lane : 0;
+        const float fsu = psu[blc], fsv = psv[blc];
         asm volatile("" ::: "memory");
         // A: lane = block
         const float su7 = div7(fsu), sv7 = div7(fsv * a);
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_blk(const u32x4 *qu, c
         const float m = fix_zero_max(lane < 32 ? m0 : m1);
         float k = 7.0f / m;                                   // IEEE-correct fp32 division (CloverVector4.h:1390)
         k = k < __builtin_inff() ? k : 0.0f;                  // 7 / max overflows: every nibble of the block is 0 (quant_pack8's guard)
-        if (bl < nblocks) sr[bl] = m;
+        if (full || (uint32_t)lane < left) psr[lane] = m;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const float kk = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (32 * u + (lane >> 1)), __float_as_int(k)));
@@ -185,9 +196,9 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_blk(const u32x4 *qu, c
             o.y = quant_pack8_k(v[u][1], kk);
             o.z = quant_pack8_k(v[u][2], kk);
             o.w = quant_pack8_k(v[u][3], kk);
-            const uint64_t h = 2 * b0 + 64 * u + lane;
-            if (h < nquads) {
-                if (NT) __builtin_nontemporal_store(o, r + h); else r[h] = o;
+            const uint32_t h = 64 * u + lane;
+            if (full || h < 2 * left) {
+                if (NT) __builtin_nontemporal_store(o, pr + h); else pr[h] = o;
             }
         }
     }
@@ -255,6 +266,88 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu,
                 if (blk < nblocks) {
                     r[blk * 8 + rho] = packed;
                     if (rho == 0) sr[blk] = m;
+                }
+            }
+        } else if constexpr (Sh::NBR == 64) {
+            // 64 blocks per round = two steps of half-block lanes, the per-block work once per BLOCK (phases A..D of
+            // k_v4_scale_and_add_blk; lane L of the block phases <-> local block L of the round)
+            const int half = lane & 1;
+            u32x4 wu[2], wv[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint64_t blk = Sh::block(blk0, rr, 32 * u + (lane >> 1));
+                const uint64_t b = blk < nblocks ? blk : 0;
+                const u32x4 *pu = reinterpret_cast<const u32x4 *>(qu) + (b * 2 + half), *pv = reinterpret_cast<const u32x4 *>(qv) + (b * 2 + half);
+                wu[u] = NT ? __builtin_nontemporal_load(pu) : *pu;
+                wv[u] = NT ? __builtin_nontemporal_load(pv) : *pv;
+            }
+            const uint64_t blkL = Sh::block(blk0, rr, lane), bL = blkL < nblocks ? blkL : 0;
+            const float fsu = su[bL], fsv = sv[bL];
+            asm volatile("" ::: "memory");                        // every load of the round precedes its stores (r may alias qu)
+            const float su7 = div7(fsu), sv7 = div7(fsv * a);
+            const bool fast = __all(times16_is_finite(su7) && times16_is_finite(sv7));
+            const float fa = fast ? su7 * 16.0f : su7, fb = fast ? sv7 * 16.0f : sv7;
+            float v[2][4][8], mb[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int src = 4 * (32 * u + (lane >> 1));
+                const float cu = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(fa)));
+                const float cv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(fb)));
+                const uint32_t xu[4] = {wu[u].x, wu[u].y, wu[u].z, wu[u].w}, xv[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+                if (fast) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        float gu[8], gv[8];
+                        unpack8_16th(xu[q4], gu);
+                        unpack8_16th(xv[q4], gv);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[u][q4][e] = __builtin_fmaf(gv[e], cv, gu[e] * cu);
+                    }
+                } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[u][q4][e] = __builtin_fmaf((float)unpack1(xv[q4], e), cv, (float)unpack1(xu[q4], e) * cu);
+                }
+                float m = 0.0f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) m = fmaxf(m, __builtin_fabsf(v[u][q4][e]));
+                mb[u] = fmaxf(m, __shfl_xor(m, 1));
+            }
+            const int from = 4 * (2 * (lane & 31));
+            const float m0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[0])));
+            const float m1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[1])));
+            const float mL = fix_zero_max(lane < 32 ? m0 : m1);
+            float kL = 7.0f / mL;
+            kL = kL < __builtin_inff() ? kL : 0.0f;               // 7 / max overflows: fma(v, 0, noise) truncates to 0 -- every nibble 0, as quant_pack8's guard
+            if (blkL < nblocks) sr[blkL] = mL;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int bl = 32 * u + (lane >> 1);
+                const uint64_t blk = Sh::block(blk0, rr, bl);
+                const float kq = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * bl, __float_as_int(kL)));
+                // W[j] of draw 0 and draw 1 for this lane's words j = 4 half .. 4 half + 3
+                const u32x4 *W4 = reinterpret_cast<const u32x4 *>(raw + (size_t)(bl * 2) * 4);
+                const u32x4 Wa = W4[half], Wb = W4[2 + half];
+                const uint32_t W0[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, W1[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    float n0[4], n1[4], nz[8];
+                    noise4_of(W0[q4], n0);
+                    noise4_of(W1[q4], n1);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int g = e ^ 1;
+                        nz[e] = (g >> 2) ? n1[g & 3] : n0[g & 3];
+                    }
+                    o[q4] = quant_pack8(v[u][q4], kq, nz);
+                }
+                if (blk < nblocks) {
+                    u32x4 *pr = reinterpret_cast<u32x4 *>(r) + (blk * 2 + half);
+                    if (NT) __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, pr); else *pr = u32x4{o[0], o[1], o[2], o[3]};
                 }
             }
         } else {
@@ -1806,15 +1899,15 @@ __global__ __launch_bounds__(256, MVF_WAVES) void k_m4_mvm_f32(const u32x4 *__re
 #pragma unroll
             for (int k = 0; k < NX; k++) { const uint32_t i = tid + 256 * k; if (i < nx) reinterpret_cast<f32x4 *>(mvf_x)[i] = xr[k]; }
             if ((uint32_t)tid < nb) s7[tid] = div7(sv);
-            fast = (uint32_t)tid >= nb || sixteenth_is_exact(div7(sv));
+            fast = (uint32_t)tid >= nb || times16_is_finite(div7(sv));
         }
-        // the barrier the staging needs anyway also tells whether every block factor c of the chunk survives a division by 16
-        // exactly: then the nibbles are taken as 16 q (one SDWA conversion each, common.h) and (16 q) * (c / 16) rounds like q * c
+        // the barrier the staging needs anyway also tells whether every block factor c of the chunk survives a multiplication by 16
+        // (no overflow): then the nibbles are taken as q / 16 (one v_cvt_off_f32_i4 each, common.h) and (q / 16) * (16 c) rounds like q * c
         fast = __builtin_amdgcn_readfirstlane(__syncthreads_and(fast));      // scalar: a real branch, not two predicated bodies
         const u32x4 *Ap = Arow + c0 / 32;
         const uint32_t ngroups = cw / 128;                                // 16 words = 128 columns per quad and step
         constexpr int U = MVF_U;
-        // FAST: every block factor c of the chunk survives c / 16 exactly (see the barrier above)
+        // FAST: every block factor c of the chunk survives 16 c (see the barrier above)
         auto chunk = [&](auto fast_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
             auto group = [&](const u32x4 av, uint32_t g) {
@@ -1828,9 +1921,9 @@ __global__ __launch_bounds__(256, MVF_WAVES) void k_m4_mvm_f32(const u32x4 *__re
                     const f32x4 xh = reinterpret_cast<const f32x4 *>(mvf_x)[2 * wi + 1];
                     const float xv[8] = {xl.x, xl.y, xl.z, xl.w, xh.x, xh.y, xh.z, xh.w};
                     if constexpr (FAST) {
-                        const float sc16 = sc * 0.0625f;
+                        const float sc16 = sc * 16.0f;
                         float f16[8];
-                        unpack8_x16(w[i], f16);
+                        unpack8_16th(w[i], f16);                                  // q / 16 (r5: 9 VALU per word instead of 11)
 #pragma unroll
                         for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(xv[j], f16[j] * sc16, acc[j]);     // rounded product first
                     } else {

@@ -329,8 +329,8 @@ def test_gpu_mixed_mvm_f32_bit_exact(hip, oracle, shape):
 
 @pytest.mark.gpu
 def test_gpu_mixed_mvm_f32_tiny_and_huge_scales(hip, oracle):
-    """scales at both ends of the fp32 range: the kernel's 16 q / (c / 16) form must step aside where c / 16 would be a denormal
-    (a whole 16384-column chunk then takes the plain form), and the result must not change"""
+    """scales at both ends of the fp32 range: the kernel's (q / 16) * (16 c) form must step aside where 16 c would overflow (a whole
+    16384-column chunk then takes the plain form) and is exact for tiny and denormal c; the result must not change either way"""
     M, N = 128, 16384 + 256
     rng = np.random.default_rng(77)
     qA, _ = random_packed(rng, M * N)
@@ -340,7 +340,14 @@ def test_gpu_mixed_mvm_f32_tiny_and_huge_scales(hip, oracle):
     sA[N // 64 - 1] = np.float32(1e37)   # second chunk (plain scales around it)
     x = rng.normal(size=N).astype(np.float32)
     x[200:260] *= np.float32(1e30)       # the tiny blocks' products are visible in the sum
-    assert same(hip.m4_mvm_f32(qA, sA, M, N, x), oracle.m4_mvm_f32(qA, sA, M, N, x))
+    sA[9] = np.float32(3e38)             # f32(s / 7) * 16 overflows: first chunk, first row group takes the plain form
+    sA[2 * (N // 64) - 2] = np.float32(2.9e38)      # second chunk, second row group
+    x[9 * 64:10 * 64] *= np.float32(1e-30)
+    x[N - 128:N - 64] *= np.float32(1e-30)
+    sA[11] = np.float32(1e-42)           # a denormal scale: the fast form is exact for it
+    out = hip.m4_mvm_f32(qA, sA, M, N, x)
+    assert np.isfinite(out).all()
+    assert same(out, oracle.m4_mvm_f32(qA, sA, M, N, x))
 
 
 @pytest.mark.gpu
