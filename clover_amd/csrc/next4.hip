@@ -1615,6 +1615,11 @@ struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global 
 // scale that is NaN, or infinite over a zero nibble) sits in the initial heap -- kept so that the walk is the reference's for every input
 #define THR_GT(a, b) ((THR_VAL(a) > THR_VAL(b)) || THR_VAL(a) != THR_VAL(a))
 
+// wave-uniform truth of a per-lane condition that is the same in every lane: the ballot is a scalar, so the branches on it are scalar
+// branches (s_cbranch_scc) instead of exec-mask loops -- the values the heap walk compares come from LDS / global loads, which the compiler
+// must assume to differ per lane
+__device__ __forceinline__ bool thr_uniform(bool c) { return __ballot(c) != 0ull; }
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ vals, uint32_t n, uint32_t k, uint2 *__restrict__ gheap,
                                                      uint32_t *__restrict__ keep)
@@ -1630,7 +1635,7 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
     }
     __syncthreads();
     // std::make_heap(min_heap, min_heap + k, gt_idx_t) (:1944): libstdc++ __make_heap = __adjust_heap(first, parent, len, value) for
-    // parent = (len - 2) / 2 ... 0, comp(a, b) = a.value > b.value
+    // parent = (len - 2) / 2 ... 0, comp = gt_idx_t.  Every index below is wave-uniform (kept scalar through thr_uniform)
     if (k >= 2) {
         for (uint32_t parent = (k - 2) / 2 + 1; parent-- > 0;) {
             const uint2 v = ThrHeap::ld<IN_LDS>(h, parent);
@@ -1638,10 +1643,14 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
             uint32_t hole = parent, child = parent;
             while (child < (k - 1) / 2) {
                 child = 2 * (child + 1);
-                uint2 a = ThrHeap::ld<IN_LDS>(h, child);
+                const uint2 a = ThrHeap::ld<IN_LDS>(h, child);
                 const uint2 b = ThrHeap::ld<IN_LDS>(h, child - 1);
-                if (THR_GT(a, b)) { child--; a = b; }                      // comp(first + child, first + (child - 1))
-                ThrHeap::st<IN_LDS>(h, hole, a);
+                if (thr_uniform(THR_GT(a, b))) {                           // comp(first + child, first + (child - 1))
+                    child--;
+                    ThrHeap::st<IN_LDS>(h, hole, b);
+                } else {
+                    ThrHeap::st<IN_LDS>(h, hole, a);
+                }
                 hole = child;
             }
             if ((k & 1) == 0 && child == (k - 2) / 2) {
@@ -1652,7 +1661,7 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
             while (hole > top) {                                           // __push_heap
                 const uint32_t par = (hole - 1) / 2;
                 const uint2 pe = ThrHeap::ld<IN_LDS>(h, par);
-                if (!THR_GT(pe, v)) break;                                 // comp(first + parent, value)
+                if (!thr_uniform(THR_GT(pe, v))) break;                    // comp(first + parent, value)
                 ThrHeap::st<IN_LDS>(h, hole, pe);
                 hole = par;
             }
@@ -1662,6 +1671,7 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
     // the walk over elements k ... n-1 (:1952-1962): strictly larger than the root -> replace the root, min_heapify(0)
     float root = THR_VAL(ThrHeap::ld<IN_LDS>(h, 0));
     float vnext = (k + lane < n) ? vals[k + lane] : -1.0f;
+    const uint32_t last = k - 1;
     for (uint32_t base = k; base < n; base += 64) {
         const float v = vnext;
         const uint32_t nb = base + 64 + lane;
@@ -1669,25 +1679,42 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
         unsigned long long mask = __ballot(v > root);
         while (mask) {
             const int j = __builtin_ctzll(mask);
-            const uint2 m = make_uint2(__float_as_uint(__shfl(v, j)), base + (uint32_t)j);
-            // min_heapify(heap, 0, k) with heap[0] = m (CloverBase.h:226-249): the smaller child moves up while it is smaller than m,
-            // the LEFT child on equal children
+            const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), j), base + (uint32_t)j);
+            const float mv = THR_VAL(m);
+            // min_heapify(heap, 0, k) with heap[0] = m (CloverBase.h:226-249): the smaller child moves up while it is smaller than m, the
+            // LEFT child on equal children.  TWO levels per LDS round trip (r5): the two children of `pos` and its four grandchildren
+            // (entries 4 pos + 3 ... 4 pos + 6, untouched by the move at `pos`) are requested together; round 4 took two dependent
+            // round trips PER level (values, then -- inside the lane-0 branch -- the indices) and ran 3.4 ms at N = 8192, K = 1024.
+            // pick: 0 = m stays here, 1 = the left child moves up, 2 = the right one
+            auto pick = [&](const uint2 a, const uint2 b, bool has_b) {
+                int c = 0;
+                float sv = mv;
+                if (thr_uniform(THR_VAL(a) < sv)) { c = 1; sv = THR_VAL(a); }
+                if (has_b && thr_uniform(THR_VAL(b) < sv)) c = 2;
+                return c;
+            };
             uint32_t pos = 0;
-            float new_root = THR_VAL(m);
+            float new_root = mv;
             for (;;) {
-                const uint32_t l = 2 * pos + 1, r = l + 1;
+                const uint32_t l = 2 * pos + 1;
                 if (l >= k) break;
-                const uint2 cl = ThrHeap::ld<IN_LDS>(h, l);
-                const uint2 cr = ThrHeap::ld<IN_LDS>(h, r < k ? r : l);
-                uint32_t smallest = pos;
-                float sv = THR_VAL(m);
-                uint2 ce = cl;
-                if (THR_VAL(cl) < sv) { smallest = l; sv = THR_VAL(cl); }
-                if (r < k && THR_VAL(cr) < sv) { smallest = r; ce = cr; }
-                if (smallest == pos) break;
-                ThrHeap::st<IN_LDS>(h, pos, ce);
-                if (pos == 0) new_root = THR_VAL(ce);
-                pos = smallest;
+                const uint32_t g0 = 2 * l + 1;
+                const uint2 cl = ThrHeap::ld<IN_LDS>(h, l), cr = ThrHeap::ld<IN_LDS>(h, l + 1 < k ? l + 1 : l);
+                const uint2 ga = ThrHeap::ld<IN_LDS>(h, g0 < k ? g0 : last), gb = ThrHeap::ld<IN_LDS>(h, g0 + 1 < k ? g0 + 1 : last);
+                const uint2 gc = ThrHeap::ld<IN_LDS>(h, g0 + 2 < k ? g0 + 2 : last), gd = ThrHeap::ld<IN_LDS>(h, g0 + 3 < k ? g0 + 3 : last);
+                const int c1 = pick(cl, cr, l + 1 < k);
+                if (c1 == 0) break;
+                const uint2 up1 = c1 == 1 ? cl : cr;
+                ThrHeap::st<IN_LDS>(h, pos, up1);
+                if (pos == 0) new_root = THR_VAL(up1);
+                pos = c1 == 1 ? l : l + 1;
+                const uint32_t l2 = 2 * pos + 1;                           // = g0 (left) or g0 + 2 (right)
+                if (l2 >= k) break;
+                const uint2 x = c1 == 1 ? ga : gc, y = c1 == 1 ? gb : gd;
+                const int c2 = pick(x, y, l2 + 1 < k);
+                if (c2 == 0) break;
+                ThrHeap::st<IN_LDS>(h, pos, c2 == 1 ? x : y);
+                pos = c2 == 1 ? l2 : l2 + 1;
             }
             ThrHeap::st<IN_LDS>(h, pos, m);
             root = new_root;
