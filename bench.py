@@ -835,7 +835,7 @@ def run_product_loops(args, n: int) -> dict:
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS")}
     try:
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)      # ~15 s of work at N = 8; a hang must not eat the run
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not lines:
             raise RuntimeError(f"child exit code {p.returncode}: {p.stderr.strip()[-300:]}")
