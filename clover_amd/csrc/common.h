@@ -177,12 +177,26 @@ __device__ __forceinline__ uint32_t nibbles_from_bytes(uint32_t even, uint32_t o
     return ((even << 4) & 0xF0F0F0F0u) | (odd & 0x0F0F0F0Fu);      // v_lshlrev_b32 + v_bfi_b32
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // quantise + pack 8 consecutive elements (one output dword); noise == nullptr <=> rounding disabled
 __device__ __forceinline__ uint32_t quant_pack8(const float v[8], float k, const float *noise)
 {
     float t[8];
+    if (noise) {
+        // the stochastic products as four v_pk_fma_f32 (hipcc packs the deterministic multiplies itself, but not the fmas whose addend
+        // comes out of the v_bitop3 asm): the same fused, singly rounded fma per lane, half the issue slots
 #pragma unroll
-    for (int e = 0; e < 8; e++) t[e] = noise ? __builtin_fmaf(v[e], k, sign_onto_nonneg(noise[e], v[e])) : v[e] * k;      // quant1_st / quant1_det
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 r = __builtin_elementwise_fma(f32x2{v[e], v[e + 1]}, f32x2{k, k},
+                                                      f32x2{sign_onto_nonneg(noise[e], v[e]), sign_onto_nonneg(noise[e + 1], v[e + 1])});
+            t[e] = r.x;
+            t[e + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) t[e] = v[e] * k;                                                                      // quant1_det
+    }
     uint32_t even = cvt_i32_byte0_first(t[0]), odd = cvt_i32_byte0_first(t[1]);
     cvt_i32_into_byte1(even, t[2]);
     cvt_i32_into_byte1(odd, t[3]);

@@ -74,6 +74,45 @@ def test_self_launch_builds_the_drivers_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_product_loops_child_failure_costs_two_objects_not_the_line(monkeypatch):
+    """rank 0 runs the product's own multi-GPU loops in a child process with a time limit (bench.run_product_loops): whatever the child does
+    -- exit code, no JSON, hang -- the caller gets two objects that say `failed`, and the environment the child sees carries none of the
+    launcher's rank variables"""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    class A:
+        steps, warmup, rows_per_gpu, cols, settle_ms, event_every, gemm_size, preset, no_c5 = 20, 5, 65536, 65536, 60.0, 2, 8192, None, False
+    seen = {}
+
+    class Bad:
+        returncode, stdout, stderr = 1, "", "boom"
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"], seen["timeout"] = cmd, env, kw.get("timeout")
+        return Bad()
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    out = bench.run_product_loops(A, 8)
+    assert set(out) == {"one_process", "gemm_sharded"} and all("failed" in v and "exit code 1" in v["failed"] for v in out.values())
+    assert "--product-loops-child" in seen["cmd"] and seen["cmd"][seen["cmd"].index("--product-loops-child") + 1] == "8"
+    assert not {"RANK", "WORLD_SIZE", "LOCAL_RANK"} & set(seen["env"]) and seen["timeout"] and seen["timeout"] <= 600
+
+    def hang(cmd, env=None, **kw):
+        raise bench.subprocess.TimeoutExpired(cmd, kw.get("timeout"))
+    monkeypatch.setattr(bench.subprocess, "run", hang)
+    out = bench.run_product_loops(A, 8)
+    assert all("TimeoutExpired" in v["failed"] for v in out.values())
+
+    class Good:
+        returncode, stderr = 0, ""
+        stdout = "[noise]\n" + json.dumps({"one_process": {"ms_per_step": 1.0}, "gemm_sharded": {"value": 2.0}}) + "\n"
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, env=None, **kw: Good())
+    assert bench.run_product_loops(A, 8) == {"one_process": {"ms_per_step": 1.0}, "gemm_sharded": {"value": 2.0}}
+
+
 REHEARSAL = {"CLOVER_BENCH_DEBUG_ONE_GPU": "1", "CLOVER_BENCH_C5_ROWS": "16384", "CLOVER_BENCH_GEMM_SIZE": "1024"}
 
 
