@@ -592,9 +592,13 @@ def main() -> None:
     if dist_on:
         dist.barrier()                                           # every rank is past its last kernel and collective
         dist.destroy_process_group()                             # torch's RCCL communicators are gone before the product builds its own
-    if not args.no_one_process and (world == 1 or debug_one_gpu or torch.cuda.device_count() >= world):
-        torch.cuda.empty_cache()
-        out.update(run_product_loops(args, world))
+    if not args.no_one_process:
+        if world == 1 or debug_one_gpu or torch.cuda.device_count() >= world:
+            torch.cuda.empty_cache()
+            out.update(run_product_loops(args, world))
+        else:                                                    # a launcher that shows every rank its own device only
+            why = {"skipped": f"rank 0 sees {torch.cuda.device_count()} device(s), the one-process loops need all {world}"}
+            out.update({"one_process": why, "gemm_sharded": dict(why)})
 
     # side measurements first, while the chip is warm from the timed loop (the matrix pipe's clocks need ~50 calls to settle after an idle
     # period, and the CPU baseline below leaves the GPU idle for half a minute: round 3 measured the GEMM 5 % slower behind it)
