@@ -335,6 +335,10 @@ def test_stochastic_vector_ops_every_kernel_shape(hip, oracle, segments):
     n += (-n) % 128
     rng = np.random.default_rng(segments)
     x = (rng.normal(size=n) * 3).astype(np.float32)
+    x[64 * 3:64 * 4] = 0.0                                   # an all-zero block: scale 1.0
+    x[64 * 5:64 * 6] = np.float32(1e-39)                     # a block whose maximum makes 7 / max overflow: every nibble 0 (cvttps overflow)
+    x[64 * 9:64 * 9 + 5] = 0.0
+    x[n - 64:] = -0.0
     (qu, su), (qv, sv) = random_packed(rng, n), random_packed(rng, n)
     assert hip.lib.clv_rng_set_segments(segments) == 0
     try:
