@@ -186,15 +186,24 @@ def run_cpu_baseline(hip, A, sA, x, sx, r, sr, rows_total: int, cols: int, sampl
     if inside:
         tq = min(inside, key=lambda t: bt[t]["ms"])
         within = {"threads": tq, **bt[tq], "note": "best team no wider than the cgroup cpu quota" if quota_cpus else "no quota: same as value"}
+    # `value`: under a cgroup cpu quota the SUSTAINED figure -- the best team no wider than the quota (stable to 1 % over the rounds: 97-98 GB/s with
+    # 16 threads) -- because a wider team only runs in bursts until the quota throttles it: its median moved 136 -> 462 -> 297 -> 169 -> 279 GB/s
+    # from run to run.  The best burst stays beside it (`burst_best`); without a quota the two are the same team.
+    best_any = {"value": round(nbytes / res["seconds"] / 1e9, 3), "threads": res["threads"], "ms": round(res["seconds"] * 1e3, 3),
+                "ms_min": round(res["min_s"] * 1e3, 3), "ms_max": round(res["max_s"] * 1e3, 3),
+                "note": "best median over all team sizes; wider than the quota = short bursts, not sustainable"}
+    head = within if (within and quota_cpus) else None
     return {
-        "value": round(nbytes / res["seconds"] / 1e9, 3), "unit": "GB/s", "cores": res["threads"], "kind": "port",
+        "value": head["GB/s"] if head else best_any["value"], "unit": "GB/s", "cores": head["threads"] if head else res["threads"], "kind": "port",
+        "value_is": ("best team within the cgroup cpu quota (sustained)" if head else "best team (no cpu quota)"), "burst_best": best_any,
         "within_quota": within, "quota_cpus": quota_cpus, "by_threads": {str(k): v for k, v in sorted(bt.items())},
         "sample": f"mvm of {'ALL' if sample_rows == rows_total else 'the first'} {sample_rows} rows x {cols} cols of the same matrix ({nbytes} B), median of <=15 runs, "
                   f"AVX2+OpenMP restatement with the reference's vpmaddubsw instruction mix (oracle/clover4_fast.c, bound threads, NUMA "
-                  f"first-touch placement, best of 1/16/64/half/all threads) on {cpu_model}, {os.cpu_count()} cpus, "
+                  f"first-touch placement, teams of 1/16/64/half/all threads) on {cpu_model}, {os.cpu_count()} cpus, "
                   f"{res.get('runnable_cpus')} runnable by this process, {quota}",
-        "ms": round(res["seconds"] * 1e3, 3), "ms_min": round(res["min_s"] * 1e3, 3), "ms_max": round(res["max_s"] * 1e3, 3), "runs": res["runs"],
-        "threads_used": res["threads"], "runnable_cpus": res.get("runnable_cpus"), "cgroup": quota,
+        "ms": head["ms"] if head else round(res["seconds"] * 1e3, 3), "ms_min": head["ms_min"] if head else round(res["min_s"] * 1e3, 3),
+        "ms_max": head["ms_max"] if head else round(res["max_s"] * 1e3, 3), "runs": head["runs"] if head else res["runs"],
+        "threads_used": head["threads"] if head else res["threads"], "runnable_cpus": res.get("runnable_cpus"), "cgroup": quota,
         "median_ms_by_threads": res.get("median_ms_by_threads"), "gpu_result_matches_cpu": res["gpu_result_matches_cpu"],
         **({"dot": {"value": round(1.125 * res["dot"]["n"] / res["dot"]["seconds"] / 1e9, 3), "unit": "GB/s", "cores": 1,
                     "sample": f"CloverVector4::dot order (sequential, as the reference's dot), n = {res['dot']['n']}, median"}}

@@ -40,7 +40,10 @@ def test_mvm_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "GB/s" and cb["gpu_result_matches_cpu"] is True
     assert cb["ms_min"] <= cb["ms"] <= cb["ms_max"] and cb["runnable_cpus"] >= 1 and cb["threads_used"] == cb["cores"]
-    assert cb["within_quota"]["GB/s"] > 0 and str(cb["within_quota"]["threads"]) in cb["by_threads"] and cb["value"] >= cb["within_quota"]["GB/s"] * 0.999
+    assert cb["within_quota"]["GB/s"] > 0 and str(cb["within_quota"]["threads"]) in cb["by_threads"]
+    # round 5: under a cgroup cpu quota `value` is the SUSTAINED team (within the quota); the best burst stays beside it
+    assert cb["burst_best"]["value"] >= cb["value"] * 0.999 and cb["cores"] == cb["threads_used"]
+    assert cb["value"] == (cb["within_quota"]["GB/s"] if cb["quota_cpus"] else cb["burst_best"]["value"])
     assert d["ms_per_step_cold"] > 0 and d["config"]["settle_launches"] >= 8
     # the second roofline-bearing object: BASELINE configs[3], normalised to the pipe the kernel runs on
     g = d["gemm"]
