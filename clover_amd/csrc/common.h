@@ -45,6 +45,10 @@ int clv_cu_count();
 // grow-only per-device scratch buffer used when the caller passes workspace == NULL
 int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream);      // grow-only scratch per (device, stream)
 void clv_internal_workspace_forget(hipStream_t stream);
+// the exact-order chain kernel of vector4.hip for other sources (mixed8.hip: CloverVector8::dot): see there for the layout of X
+uint64_t clv_internal_dot_chain_blocks_padded(uint64_t steps);
+uint64_t clv_internal_dot_chain_bytes(uint64_t steps);
+int clv_internal_dot_chain(const void *X, uint64_t blocks_padded, float *out_dev, hipStream_t st);
 // zero-initialised hand-over slots per (device, stream), <= 64 KiB; every user leaves them zero again (runtime.hip)
 int clv_internal_sync_slots(void **ptr, uint64_t bytes, hipStream_t stream);
 

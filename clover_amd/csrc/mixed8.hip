@@ -456,6 +456,127 @@ __global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ 
 }
 
 // =================================================================================================
+// CloverVector8::dot (CloverVector8.h:911-977; round 5 -- the one arithmetic method of the class that was still missing here).
+//   Per 64-element block: I[w] = the 8 byte products that fall into 32-bit lane w of the block's two 32-byte halves (exact; |q| <= 127, so
+//   the reference's maddubs never saturates), scale = f32(f32(su / 127*) f32(sv / 127*)) with 127* = the constant 1.0f / 127.0f, and ONE
+//   accumulator register: acc[w] = fma(scale, (float)I[w], acc[w]) block after block -- 8 sequential chains of n / 64 steps -- then the
+//   _mm256_haddf32_ps tree (CloverBase.h:149-157).
+//   EXACT: that order, bit for bit, on the chain kernel of CloverVector4::dot (vector4.hip: one wave, 16 chain lanes, operands in a register
+//          ring, generated asm): its lanes l = 8 a + w keep two accumulators a = 0, 1 per AVX lane w and its tree starts with
+//          acc[0][w] + acc[1][w].  Here one fma step = ONE block, accumulator 0 carries the chain and accumulator 1 is fed zeros --
+//          fma(0, 0, +0) = +0 and acc + 0 = acc exactly -- after which that kernel's tree IS _mm256_haddf32_ps over the 8 chains.
+//          k_v8_dot_prep (all CUs) writes the operands in that kernel's layout.  Latency-bound by the definition: n / 64 dependent fmas
+//          per chain, twice CloverVector4::dot's n / 128.
+//   FAST:  exact block integers, per-block scale, fp32 partials by a fixed tree (dot_common.h): the memory-bound order, one launch --
+//          what dot_parallel() means (the reference's own dot_parallel sums its threads' partials in unspecified order, :979-1060).
+// =================================================================================================
+#include "dot_common.h"
+
+#define CLV_RCP127 (1.0f / 127.0f)      // clover_mm256_rcp_127_ps (CloverBase.h:87)
+__device__ __forceinline__ int v8_word_isum(const uint32_t *__restrict__ qu, const uint32_t *__restrict__ qv, uint64_t blk, int w)
+{
+    // lane w of both halves: words w and 8 + w of the block's 16
+    int I = __builtin_amdgcn_sdot4((int)qu[16 * blk + w], (int)qv[16 * blk + w], 0, false);
+    return __builtin_amdgcn_sdot4((int)qu[16 * blk + 8 + w], (int)qv[16 * blk + 8 + w], I, false);
+}
+
+// The chain kernel's operand layout (k_v4_dot_prep2): thread = (block Q of 16 steps, chain lane l, piece 0..4); pieces 0..3 = f of steps
+// 4 piece .. 4 piece + 3, piece 4 = c of steps 4 i + (l & 3), i = 0..3 (each lane of a quad keeps a quarter of the 16 factors).  Step p =
+// CloverVector8 block p for the lanes of accumulator 0; accumulator 1 (l >= 8) and steps past the end hold zeros.
+__global__ __launch_bounds__(256) void k_v8_dot_prep(const uint32_t *__restrict__ qu, const float *__restrict__ su, const uint32_t *__restrict__ qv,
+                                                     const float *__restrict__ sv, uint64_t nblocks, uint64_t qblocks_padded, f32x4 *__restrict__ X)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < qblocks_padded * 80; t += stride) {
+        const uint64_t Q = t / 80;
+        const int r = (int)(t - Q * 80), l = r / 5, piece = r - 5 * l, w = l & 7;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t p = piece < 4 ? 16 * Q + 4 * piece + i : 16 * Q + 4 * i + (l & 3);
+            v[i] = 0.0f;
+            if (l < 8 && p < nblocks) v[i] = piece < 4 ? (float)v8_word_isum(qu, qv, p, w) : (su[p] * CLV_RCP127) * (sv[p] * CLV_RCP127);
+        }
+        X[t] = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+// FAST: lane = 16 bytes of each operand (a quarter block); the four lanes of a block add their integer sums, lane 0 of the quad folds
+template <int U>
+__global__ __launch_bounds__(DOT_FAST_THREADS) void k_v8_dot_fast1(const u32x4 *__restrict__ qu, const float *__restrict__ su, const u32x4 *__restrict__ qv,
+                                                                   const float *__restrict__ sv, uint64_t nvec, unsigned long long *slots,
+                                                                   float *__restrict__ out)
+{
+    __shared__ float sh[4];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    float acc = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += U * stride) {
+        u32x4 a[U], b[U];
+        float cu[U], cv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t j = i + u * stride, jc = j < nvec ? j : i;          // nvec, i - lane and stride are multiples of 4: quads stay whole
+            a[u] = __builtin_nontemporal_load(&qu[jc]);
+            b[u] = __builtin_nontemporal_load(&qv[jc]);
+            cu[u] = su[jc >> 2];
+            cv[u] = sv[jc >> 2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int I = __builtin_amdgcn_sdot4((int)a[u].x, (int)b[u].x, 0, false);
+            I = __builtin_amdgcn_sdot4((int)a[u].y, (int)b[u].y, I, false);
+            I = __builtin_amdgcn_sdot4((int)a[u].z, (int)b[u].z, I, false);
+            I = __builtin_amdgcn_sdot4((int)a[u].w, (int)b[u].w, I, false);
+            I += __shfl_xor(I, 1);
+            I += __shfl_xor(I, 2);
+            const uint64_t j = i + u * stride;
+            const float c = ((j & 3) == 0 && j < nvec) ? (cu[u] * CLV_RCP127) * (cv[u] * CLV_RCP127) : 0.0f;      // branch-free, see k_v4_dot_fast1
+            acc = __builtin_fmaf(c, (float)I, acc);
+        }
+    }
+    dot_hand_over_and_collect(block_sum_256(acc, sh), slots, out, sh);
+}
+
+extern "C" uint64_t clv8_dot_workspace_bytes(uint64_t n_pad) { return clv_internal_dot_chain_bytes(n_pad / 64); }
+
+extern "C" int clv8_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad, int mode, float *out_dev,
+                        void *workspace, void *stream)
+{
+    CLV_REQUIRE(qu && su && qv && sv && out_dev, "clv8_dot: null pointer");
+    CLV_REQUIRE(n_pad % 128 == 0, "clv8_dot: n_pad=%llu is not a multiple of 128", (unsigned long long)n_pad);
+    CLV_REQUIRE(mode == CLV_DOT_EXACT || mode == CLV_DOT_FAST, "clv8_dot: unknown mode %d", mode);
+    hipStream_t st = as_stream(stream);
+    if (!n_pad) { CLV_HIP(hipMemsetAsync(out_dev, 0, sizeof(float), st)); return CLV_OK; }
+    if (mode == CLV_DOT_EXACT) {
+        if (!workspace) {
+            int rc = clv_internal_workspace(&workspace, clv8_dot_workspace_bytes(n_pad), st);
+            if (rc) return rc;
+        }
+        const uint64_t qpad = clv_internal_dot_chain_blocks_padded(n_pad / 64);
+        const uint64_t want = (qpad * 80 + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+        hipLaunchKernelGGL(k_v8_dot_prep, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const uint32_t *)qu, su, (const uint32_t *)qv, sv,
+                           n_pad / 64, qpad, (f32x4 *)workspace);
+        CLV_LAUNCH_CHECK();
+        return clv_internal_dot_chain(workspace, qpad, out_dev, st);
+    }
+    const uint64_t nvec = n_pad / 16;
+    const uint64_t want = (nvec + DOT_FAST_THREADS - 1) / DOT_FAST_THREADS, cap = (uint64_t)clv_cu_count() * 4;
+    const int grid = (int)(want < cap ? want : cap);
+    void *slots = nullptr;
+    int rc = clv_internal_sync_slots(&slots, (uint64_t)grid * 8, st);
+    if (rc) return rc;
+    const uint64_t per_thread = (nvec + (uint64_t)grid * DOT_FAST_THREADS - 1) / ((uint64_t)grid * DOT_FAST_THREADS);
+    if (per_thread <= 2)
+        hipLaunchKernelGGL(k_v8_dot_fast1<2>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec,
+                           (unsigned long long *)slots, out_dev);
+    else
+        hipLaunchKernelGGL(k_v8_dot_fast1<1>, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, nvec,
+                           (unsigned long long *)slots, out_dev);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
+}
+
+// =================================================================================================
 // C ABI
 // =================================================================================================
 extern "C" int clv8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t *rng_state_dev, void *stream)

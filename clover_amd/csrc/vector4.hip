@@ -187,17 +187,7 @@ __global__ __launch_bounds__(64) void k_v4_dot_chain2(const f32x4 *__restrict__ 
 //   block contributes exactly c[b] * I[b] like the reference; only the fp32 summation ORDER differs.
 //   algorithmic bytes: 1.125 per element.
 // ------------------------------------------------------------------------------------------------
-#define DOT_FAST_THREADS 256
-
-__device__ __forceinline__ float block_sum_256(float v, float *sh)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) sh[wave] = v;
-    __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
+#include "dot_common.h"      // DOT_FAST_THREADS, block_sum_256, dot_hand_over_and_collect
 
 __global__ __launch_bounds__(DOT_FAST_THREADS) void k_v4_dot_partial(const u32x4 *__restrict__ qu, const float *__restrict__ su,
                                                                      const u32x4 *__restrict__ qv, const float *__restrict__ sv,
@@ -271,43 +261,7 @@ __global__ __launch_bounds__(DOT_FAST_THREADS) void k_v4_dot_fast1(const u32x4 *
             acc = __builtin_fmaf(c, (float)I, acc);
         }
     }
-    const float t = block_sum_256(acc, sh);
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&slots[blockIdx.x], (1ull << 32) | __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x != gridDim.x - 1) return;
-    // collector: every round requests all of this thread's outstanding slots at once
-    constexpr int MAXS = 8;                                                    // grid <= 256 * MAXS (dot_fast_grid: 4 per CU)
-    const int count = (int)gridDim.x;
-    float part[MAXS];
-    uint32_t need = 0;
-#pragma unroll
-    for (int k = 0; k < MAXS; k++) {
-        part[k] = 0.0f;
-        if ((int)threadIdx.x + DOT_FAST_THREADS * k < count) need |= 1u << k;
-    }
-    while (need) {
-        unsigned long long v[MAXS];
-#pragma unroll
-        for (int k = 0; k < MAXS; k++)
-            if (need & (1u << k)) v[k] = __hip_atomic_load(&slots[threadIdx.x + DOT_FAST_THREADS * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < MAXS; k++)
-            if ((need & (1u << k)) && (v[k] >> 32)) {
-                part[k] = __uint_as_float((uint32_t)v[k]);
-                need &= ~(1u << k);
-            }
-        if (need) __builtin_amdgcn_s_sleep(1);
-    }
-    float acc2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < MAXS; k++) {
-        acc2 += part[k];                                                       // slots beyond `count` contribute +0.0f: acc2 + 0 == acc2 bit for bit
-        // zero again for the next launch: plain stores (nobody reads the slots any more in this launch; the end of the kernel writes them back)
-        if ((int)threadIdx.x + DOT_FAST_THREADS * k < count) slots[threadIdx.x + DOT_FAST_THREADS * k] = 0ull;
-    }
-    __syncthreads();                                                           // sh is reused
-    const float r = block_sum_256(acc2, sh);
-    if (threadIdx.x == 0) *out = r;
+    dot_hand_over_and_collect(block_sum_256(acc, sh), slots, out, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,6 +340,22 @@ static inline uint64_t dot_exact_blocks(uint64_t n_pad) { return (n_pad / 128 + 
 static inline uint64_t dot_exact_blocks_padded(uint64_t n_pad)
 {
     return (dot_exact_blocks(n_pad) + DOTX_D - 1) / DOTX_D * DOTX_D;
+}
+
+// The chain kernel for other callers in the library (CloverVector8::dot, mixed8.hip): X holds `steps` fma steps in k_v4_dot_prep2's layout
+// (per block of 16 steps and chain lane l: 80 bytes = 16 f + one float4 of c in quad layout; zeros past the end)
+uint64_t clv_internal_dot_chain_blocks_padded(uint64_t steps)
+{
+    const uint64_t blocks = (steps + 15) / 16;
+    return (blocks + DOTX_D - 1) / DOTX_D * DOTX_D;
+}
+uint64_t clv_internal_dot_chain_bytes(uint64_t steps) { return (clv_internal_dot_chain_blocks_padded(steps) + DOTX_D) * 1280 + 256; }
+int clv_internal_dot_chain(const void *X, uint64_t blocks_padded, float *out_dev, hipStream_t st)
+{
+    CLV_REQUIRE(blocks_padded / DOTX_D <= 0xFFFFFFFFull, "dot chain: vector too long");
+    hipLaunchKernelGGL(k_v4_dot_chain2, dim3(1), dim3(64), 0, st, (const f32x4 *)X, (uint32_t)(blocks_padded / DOTX_D), out_dev);
+    CLV_LAUNCH_CHECK();
+    return CLV_OK;
 }
 
 extern "C" uint64_t clv4_dot_workspace_bytes(uint64_t n_pad)

@@ -53,6 +53,8 @@ SIGNATURES = {
     "clv4_restore": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "clv4_dot_workspace_bytes": (_u64, [_u64]),
     "clv4_dot": (C.c_int, [_vp, _vp, _vp, _vp, _u64, C.c_int, _vp, _vp, _vp]),
+    "clv8_dot_workspace_bytes": (_u64, [_u64]),
+    "clv8_dot": (C.c_int, [_vp, _vp, _vp, _vp, _u64, C.c_int, _vp, _vp, _vp]),
     "clv4_word_isums": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "clm4_quantize": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "clm4_restore": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
@@ -314,6 +316,13 @@ class CloverHip:
         dr, dsr = (b[0], b[1]) if in_place else (self.alloc(max(n, 1)), self.alloc(max(n // 16, 4)))
         self.check(self.lib.clv8_scale_and_add(b[0].ptr, b[1].ptr, b[2].ptr, b[3].ptr, a, n, dr.ptr, dsr.ptr, rng.ptr if rng else None, None))
         return dr.download(np.int8, n), dsr.download(np.float32, n // 64)
+
+    def v8_dot(self, qu, su, qv, sv, mode: int = DOT_EXACT) -> np.float32:
+        n = qu.size
+        bufs = [self.to_device(a) for a in (qu, su, qv, sv)]
+        out = self.alloc(4)
+        self.check(self.lib.clv8_dot(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, n, mode, out.ptr, None, None))
+        return out.download(np.float32, 1)[0]
 
     def v8_threshold(self, q, s, n: int, k: int, mode: int = THRESHOLD_FAST) -> np.ndarray:
         dq, ds = self.to_device(q), self.to_device(s)

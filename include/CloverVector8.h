@@ -10,11 +10,12 @@
  *   restore / restore_scalar                        -> clv8_restore   (:835-909, :255-266)
  *
  *   scaleAndAdd / _parallel / _scalar               -> clv8_scale_and_add (:1063-1358, :1360-1678, :311-391)
- *   threshold / threshold_parallel                  -> clv8_threshold     (:1680-1740; lowest-index tie rule, see clover_hip.h)
+ *   threshold / threshold_parallel                  -> clv8_threshold_mode (:1680-1740; tie rule by the exactness switch, clover_device.h)
+ *   dot / dot_parallel / dot_scalar                 -> clv8_dot EXACT / FAST   (:911-977, :979-1061, :268-310; round 5)
  *
  * on the device: what Q_IHT / Q_GD need when they run with a CloverMatrix4 and CloverVector8 vectors, the configuration the
- * reference publishes as "4-bit" (test/performance/02_bit04.cpp:140).  The 8-bit dot (:911-1061) and CloverMatrix8 belong to
- * the 8-bit containers' own path and are not part of this backend.
+ * reference publishes as "4-bit" (test/performance/02_bit04.cpp:140), and with round 5 every method of the reference's class.
+ * CloverMatrix8 belongs to the 8-bit containers' own path and is not part of this backend.
  */
 #ifndef CLOVER_VECTOR8_H
 #define CLOVER_VECTOR8_H
@@ -91,6 +92,18 @@ public:
 
     /* CloverVector8.h:137-140 */
     float get(uint64_t i) const { return values_ro()[i] * scales_ro()[i >> 6] / 127.0f; }
+    /* :141-147 */
+    float getAbs(uint64_t i) const
+    {
+        const float v = get(i);
+        return v < 0 ? -v : (v == 0 ? 0.0f : v);            /* the sign bit cleared (-0 -> +0) */
+    }
+    /* :149-153 */
+    void set(uint64_t i, float v) const
+    {
+        const float rcp_scale = 127.0f / scales_ro()[i >> 6];
+        values_rw()[i] = (int8_t)roundf(rcp_scale * v);
+    }
     int8_t getBits(uint64_t i) const { return values_ro()[i]; }
     void setBits(uint64_t i, int8_t bits) { values_rw()[i] = bits; }
     void clear()
@@ -183,6 +196,30 @@ public:
     }
 
     /* keep the k largest magnitudes, zero the rest (CloverVector8.h:1680-1740) */
+    /* dot(): by default the reference's order, bit for bit -- 8 sequential fma chains of n / 64 steps (CloverVector8.h:911-977): latency-bound
+     * by that definition.  Under -DCLOVER_FAST / clover_hip::set_exactness(FAST) the fast order (exact block integers, fp32 tree, one launch,
+     * memory-bound).  dot_parallel(): always the fast order (the reference's own is "any order", :979-1061); dot_exact(): always the
+     * reference's.  The switch: clover_device.h. */
+    float dot(const CloverVector8 &other) const { return dot_mode(other, clover_hip::dot_mode()); }
+    float dot_exact(const CloverVector8 &other) const { return dot_mode(other, CLV_DOT_EXACT); }
+    float dot_parallel(const CloverVector8 &other) const { return dot_mode(other, CLV_DOT_FAST); }
+    float dot_fast(const CloverVector8 &other) const { return dot_mode(other, CLV_DOT_FAST); }
+    /* :268-310, on the host: the validation partner of dot */
+    float dot_scalar(const CloverVector8 &other) const
+    {
+        same_size(other);
+        const int8_t *u = values_ro(), *v = other.values_ro();
+        const float *su = scales_ro(), *sv = other.scales_ro();
+        float result = 0;
+        for (uint64_t b = 0; b < length_pad / 64; b++) {
+            const float scale = (su[b] / 127.0f) * (sv[b] / 127.0f);
+            int32_t block = 0;
+            for (uint64_t i = 64 * b; i < 64 * b + 64; i++) block += (int32_t)u[i] * (int32_t)v[i];
+            result += block * scale;
+        }
+        return result;
+    }
+
     void threshold(uint64_t k)
     {
         clover_hip::check(clv8_threshold_mode(dev_values_rw(), dev_scales_ro(), length, length_pad, k, clover_hip::threshold_mode(), nullptr, nullptr), "CloverVector8::threshold");
@@ -218,6 +255,14 @@ public:
     }
 
 private:
+    float dot_mode(const CloverVector8 &other, int mode) const
+    {
+        same_size(other);
+        clover_hip::ResultSlot &slot = clover_hip::result_slot();          /* per-thread device word + pinned host word */
+        clover_hip::check(clv8_dot(dev_values_ro(), dev_scales_ro(), other.dev_values_ro(), other.dev_scales_ro(), length_pad, mode,
+                                   slot.device(), nullptr, nullptr), "CloverVector8::dot");
+        return slot.fetch();
+    }
     void same_size(const CloverVector8 &other) const
     {
         if (other.length_pad != length_pad) {

@@ -198,6 +198,13 @@ int  clv8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, voi
  * test/performance/02_bit04.cpp:140).  Same contracts as clv4_scale_and_add / clv4_threshold. */
 int  clv8_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad,
                         int8_t *r, float *sr, uint64_t *rng_state_dev, void *stream);
+/* clv8_dot = CloverVector8::dot (CloverVector8.h:911-977): per block the 64 byte products summed exactly per 32-bit lane of the block's two
+ * halves, scale = f32(f32(su * 1/127) * f32(sv * 1/127)), 8 fma chains over ALL blocks, then the _mm256_haddf32_ps tree.  CLV_DOT_EXACT: that
+ * order, bit for bit (n/64 dependent fmas per chain: latency-bound by definition); CLV_DOT_FAST (= dot_parallel, :979-1061): the same exact
+ * block integers, fp32 tree order, one launch, memory-bound.  workspace: clv8_dot_workspace_bytes() bytes or NULL (internal; EXACT only). */
+uint64_t clv8_dot_workspace_bytes(uint64_t n_pad);
+int  clv8_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad, int mode, float *out_dev,
+              void *workspace, void *stream);
 uint64_t clv8_threshold_workspace_bytes(uint64_t n_pad);
 int  clv8_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream);
 int  clv8_threshold_mode(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, int mode, void *workspace, void *stream);

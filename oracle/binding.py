@@ -40,6 +40,9 @@ class Oracle:
         L.orc_v4_dot.restype = C.c_float
         L.orc_v4_dot_scalar.restype = C.c_float
         L.orc_v4_dot_f64.restype = C.c_double
+        L.orc_v8_dot.restype = C.c_float
+        L.orc_v8_dot_scalar.restype = C.c_float
+        L.orc_v8_dot_f64.restype = C.c_double
         L.orc_v4_get.restype = C.c_float
         L.orc_m4_get.restype = C.c_float
         self.L = L
@@ -177,6 +180,18 @@ class Oracle:
         self.L.orc_v8_scale_and_add(_p(qu, i8), _p(su, _fp), _p(qv, i8), _p(sv, _fp), C.c_float(a), _u64(n), _p(r, i8), _p(sr, _fp),
                                     C.byref(rng) if rng is not None else None)
         return r, sr
+
+    def v8_dot(self, qu, su, qv, sv) -> np.float32:
+        i8 = C.POINTER(C.c_int8)
+        return np.float32(self.L.orc_v8_dot(_p(qu, i8), _p(su, _fp), _p(qv, i8), _p(sv, _fp), _u64(qu.size)))
+
+    def v8_dot_scalar(self, qu, su, qv, sv) -> np.float32:
+        i8 = C.POINTER(C.c_int8)
+        return np.float32(self.L.orc_v8_dot_scalar(_p(qu, i8), _p(su, _fp), _p(qv, i8), _p(sv, _fp), _u64(qu.size)))
+
+    def v8_dot_f64(self, qu, su, qv, sv) -> float:
+        i8 = C.POINTER(C.c_int8)
+        return float(self.L.orc_v8_dot_f64(_p(qu, i8), _p(su, _fp), _p(qv, i8), _p(sv, _fp), _u64(qu.size)))
 
     def v8_threshold(self, q, s, n: int, k: int) -> np.ndarray:
         out = np.array(q, dtype=np.int8, copy=True)

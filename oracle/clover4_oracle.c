@@ -566,6 +566,54 @@ void orc_v8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, orc_rn
     }
 }
 
+/* CloverVector8::dot (CloverVector8.h:911-977): per block the 64 byte products are summed per 32-bit lane of the two 32-byte halves
+ * (sign / maddubs / madd / add_epi32: exact, |q| <= 127 so maddubs never saturates), scale = f32(f32(su * 1/127) * f32(sv * 1/127)), ONE
+ * accumulator register: acc[w] = fma(scale, (float)I[w], acc[w]) for every block in order -- 8 sequential chains -- then the
+ * _mm256_haddf32_ps tree (CloverBase.h:149-157). */
+static const float RCP127 = 1.0f / 127.0f;
+float orc_v8_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad)
+{
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t b = 0; b < n_pad / 64; b++) {
+        const float scale = (su[b] * RCP127) * (sv[b] * RCP127);
+        for (int w = 0; w < 8; w++) {
+            int32_t I = 0;
+            for (int i = 0; i < 4; i++)
+                I += (int32_t)qu[64 * b + 4 * w + i] * qv[64 * b + 4 * w + i] + (int32_t)qu[64 * b + 32 + 4 * w + i] * qv[64 * b + 32 + 4 * w + i];
+            acc[w] = fmaf(scale, (float)I, acc[w]);
+        }
+    }
+    float x[4];
+    for (int j = 0; j < 4; j++) x[j] = acc[j + 4] + acc[j];
+    const float y0 = x[0] + x[2];
+    const float y1 = x[1] + x[3];
+    return y0 + y1;
+}
+/* CloverVector8::dot_scalar (CloverVector8.h:268-310): the reference's tolerance partner */
+float orc_v8_dot_scalar(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad)
+{
+    float result = 0.0f;
+    for (uint64_t b = 0; b < n_pad / 64; b++) {
+        const float scale = (su[b] / 127.0f) * (sv[b] / 127.0f);
+        int32_t I = 0;
+        for (int i = 0; i < 64; i++) I += (int32_t)qu[64 * b + i] * qv[64 * b + i];
+        const float term = (float)I * scale;                  /* separate multiply, then add */
+        result = result + term;
+    }
+    return result;
+}
+double orc_v8_dot_f64(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad)
+{
+    double r = 0.0;
+    for (uint64_t b = 0; b < n_pad / 64; b++) {
+        const float scale = (su[b] * RCP127) * (sv[b] * RCP127);
+        int64_t I = 0;
+        for (int i = 0; i < 64; i++) I += (int32_t)qu[64 * b + i] * qv[64 * b + i];
+        r += (double)scale * (double)I;
+    }
+    return r;
+}
+
 void orc_v8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x)
 {
     for (uint64_t i = 0; i < n_pad; i++) x[i] = (float)q[i] * (s[i >> 6] / 127.0f);

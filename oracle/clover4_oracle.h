@@ -104,6 +104,10 @@ void     orc_m4_mvm_f32(const uint8_t *A, const float *sA, uint64_t rows, uint64
 void     orc_v8_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, orc_rng *rng);
 /* CloverVector8::restore (CloverVector8.h:835-909): x = (float)q * (scale / 127.0f) */
 void     orc_v8_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x);
+/* CloverVector8::dot (CloverVector8.h:911-977: 8 sequential fma chains), dot_scalar (:268-310), and the order-free fp64 value */
+float    orc_v8_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad);
+float    orc_v8_dot_scalar(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad);
+double   orc_v8_dot_f64(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad);
 /* fp32 row dots of CloverMatrix4::mvm(const CloverVector8 &, CloverVector8 &) (CloverMatrix4.h:1093-1243) in SIMD order:
  * 8 fp32 fma chains per row (chain L = elements 4L..4L+3 and 32+4L..32+4L+3 of every 64-block),
  * c_b = f32(f32(sA*1/7) * f32(sx*1/127)), chain += c_b * (float)I exactly-summed, then ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)) */

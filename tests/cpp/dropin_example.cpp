@@ -104,6 +104,8 @@ int main()
         hexdump("mixed_x8", x8.getData(), 64);
         hexdump("mixed_r8", r8.getData(), 128);
         printf("mixed_scales=0x%08x,0x%08x bytes8=%llu\n", bits(r8.getScales()[0]), bits(r8.getScales()[1]), (unsigned long long)x8.getBytes());
+        CloverVector8 y8v(x);
+        printf("mixed_dot8=0x%08x dot8_parallel=%.9g getabs=%.9g\n", bits(x8.dot(y8v)), x8.dot_parallel(y8v), x8.getAbs(1));
         x8.restore(back);
         printf("mixed_restore=0x%08x,0x%08x get=0x%08x\n", bits(back.get(1)), bits(back.get(255)), bits(x8.get(1)));
     }

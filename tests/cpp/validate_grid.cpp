@@ -108,6 +108,11 @@ static void vectors()
         e.scaleAndAdd(f, 0.5f, e1);
         e.scaleAndAdd_scalar(f, 0.5f, e2);
         for (uint64_t i = 0; i < n; i++) expect(e1.getBits(i) == e2.getBits(i), "8-bit scaleAndAdd vs scalar", n, i);
+        {   // CloverVector8::dot against its scalar twin, the reference's 0.02 (02_vector.cpp:258-339 for the 8-bit container), both orders
+            const float d8s = e.dot_scalar(f);
+            expect(std::fabs(e.dot(f) - d8s) <= 0.02f, "8-bit dot vs dot_scalar", n, 0);
+            expect(std::fabs(e.dot_parallel(f) - d8s) <= 0.02f, "8-bit dot_parallel vs dot_scalar", n, 0);
+        }
         threshold_relation<CloverVector8>(w, n, "8-bit threshold: sorted magnitudes");
     }
 }

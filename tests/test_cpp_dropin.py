@@ -74,6 +74,15 @@ def test_dropin_example_matches_reference_answers(tmp_path, oracle, exactness):
     assert [int(v, 16) for v in kv["mixed_scales"].split(",")] == [int(bits(sr8[0])), int(bits(sr8[1]))] and kv["bytes8"] == str(256 + 4 * 4)
     back = oracle.v8_restore(qx8, sx8)
     assert [int(v, 16) for v in kv["mixed_restore"].split(",")] == [int(bits(back[1])), int(bits(back[255]))]
+    # CloverVector8::dot through the header (round 5): x8 . x8
+    d8 = oracle.v8_dot(qx8, sx8, qx8, sx8)
+    if exactness == "fast":
+        got8 = float(np.array([int(kv["mixed_dot8"], 16)], np.uint32).view(np.float32)[0])
+        assert abs(got8 - float(d8)) <= 1e-5 * abs(float(d8))
+    else:
+        assert int(kv["mixed_dot8"], 16) == int(bits(d8))
+    assert abs(float(kv["dot8_parallel"]) - float(d8)) <= 1e-5 * abs(float(d8))
+    assert abs(float(kv["getabs"]) - abs(float(back[1]))) <= 1e-7 * max(1.0, abs(float(back[1])))
     assert int(kv["get"], 16) == int(bits(np.float32(np.float32(np.float32(qx8[1]) * sx8[0]) / np.float32(127.0))))
     # the IHT-style iteration built from the "next" rows
     assert kv["iht_transpose_ok"] == "1" and 0 < int(kv["iht_nonzeros"]) <= 32

@@ -302,3 +302,65 @@ def test_gpu_mixed_iht_loop_matches_oracle_loop(hip, oracle, mode):
     assert same(bufs[6].download(np.int8, n), t3[0]) and same(bufs[4].download(np.int8, m), t2[0])
     if st:
         assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
+
+
+# ---------------------------------------------------------------- CloverVector8::dot (round 5)
+def _v8_pair(rng, n, kind):
+    """two quantized 8-bit vectors; kind: normal data, integers (the reference's dot test data, 02_vector.cpp:258-295), extremes (+-127
+    everywhere: the largest block integers, 64 x 127^2), zero blocks"""
+    if kind == "ints":
+        x, y = rng.integers(-10, 11, size=n).astype(np.float32), rng.integers(-10, 11, size=n).astype(np.float32)
+    else:
+        x, y = (rng.normal(size=n) * 3).astype(np.float32), (rng.normal(size=n) * 0.01).astype(np.float32)
+    if kind == "extreme":
+        x = np.where(rng.random(n) < 0.5, -5.0, 5.0).astype(np.float32)
+        y = np.where(rng.random(n) < 0.5, -0.25, 0.25).astype(np.float32)
+    if kind == "zeros":
+        x[64:192] = 0.0
+        y[n - 64:] = 0.0
+    return x, y
+
+
+@pytest.mark.parametrize("n", [128, 1024, 64 * 33 + 64])
+def test_oracle_v8_dot_orders_agree(oracle, n):
+    """the reference's own check for dot is SIMD vs scalar within 0.02 (test/validate/02_vector.cpp); the README-style known answer
+    (a = 1, b = 2 -> 2 n) holds in the 8-bit format too"""
+    rng = np.random.default_rng(n)
+    x, y = _v8_pair(rng, n, "ints")
+    qx, sx = oracle.v8_quantize(x)
+    qy, sy = oracle.v8_quantize(y)
+    d, ds, d64 = oracle.v8_dot(qx, sx, qy, sy), oracle.v8_dot_scalar(qx, sx, qy, sy), oracle.v8_dot_f64(qx, sx, qy, sy)
+    assert abs(float(d) - float(ds)) <= 0.02 * max(1.0, abs(d64) * 1e-3) and abs(float(d) - d64) <= 1e-5 * max(abs(d64), 1.0) * (n // 64)
+    a, b = oracle.v8_quantize(np.ones(n, np.float32)), oracle.v8_quantize(2 * np.ones(n, np.float32))
+    assert float(oracle.v8_dot(*a, *b)) == 2.0 * n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 256, 1024 + 128, 64 * 16 * 7, (1 << 16) + 128, (1 << 20) + 384])
+@pytest.mark.parametrize("kind", ["normal", "ints", "extreme", "zeros"])
+def test_gpu_v8_dot_exact_and_fast(hip, oracle, n, kind):
+    """clv8_dot EXACT == the reference's order (8 fma chains over all blocks + the hadd tree), bit for bit; FAST within the fast order's bound"""
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST
+    rng = np.random.default_rng(n + len(kind))
+    x, y = _v8_pair(rng, n, kind)
+    qx, sx = oracle.v8_quantize(x)
+    qy, sy = oracle.v8_quantize(y)
+    want = oracle.v8_dot(qx, sx, qy, sy)
+    got = hip.v8_dot(qx, sx, qy, sy, mode=DOT_EXACT)
+    assert np.float32(got).tobytes() == np.float32(want).tobytes(), (got, want)
+    d64 = oracle.v8_dot_f64(qx, sx, qy, sy)
+    terms = np.abs(np.repeat(sx * sy, 64).astype(np.float64) * qx.astype(np.float64) * qy.astype(np.float64)).sum() / (127.0 * 127.0)
+    fast = hip.v8_dot(qx, sx, qy, sy, mode=DOT_FAST)
+    assert abs(float(fast) - d64) <= 2e-6 * terms + 1e-6
+    assert abs(float(got) - float(oracle.v8_dot_scalar(qx, sx, qy, sy))) <= 0.02 + 1e-5 * abs(d64)
+
+
+@pytest.mark.gpu
+def test_gpu_v8_dot_empty_and_bad_arguments(hip):
+    lib = hip.lib
+    out, buf = hip.alloc(8), hip.alloc(1024)
+    assert lib.clv8_dot(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 0, 0, out.ptr, None, None) == 0
+    assert out.download(np.float32, 1)[0] == 0.0
+    assert lib.clv8_dot(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 192, 0, out.ptr, None, None) != 0            # not a multiple of 128
+    assert lib.clv8_dot(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 128, 7, out.ptr, None, None) != 0            # unknown mode
+    assert lib.clv8_dot(None, buf.ptr, buf.ptr, buf.ptr, 128, 0, out.ptr, None, None) != 0

@@ -79,6 +79,13 @@ for logn in (24, 30):
         rec(f"threshold_k25pct_n2^{logn}", 0.5625 * n * 5, lambda: hip.check(lib.clv4_threshold(q3.ptr, s.ptr, n, n, k, None, None)), reps=3,
             extra={"note": "5 passes over nibbles+scales (3 histogram, tie count, apply) + 4 tiny kernels"})
         rec(f"dot_exact_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2)
+    q8b = hip.alloc(n)
+    hip.check(lib.clv8_quantize(x.ptr, n, q8.ptr, s3.ptr, None, None))
+    hip.check(lib.clv8_quantize(x.ptr, n, q8b.ptr, s2.ptr, None, None))
+    rec(f"v8_dot_fast_n2^{logn}", 2.125 * n, lambda: hip.check(lib.clv8_dot(q8.ptr, s3.ptr, q8b.ptr, s2.ptr, n, DOT_FAST, out.ptr, None, None)))
+    if logn == 24:
+        rec(f"v8_dot_exact_n2^{logn}", 2.125 * n, lambda: hip.check(lib.clv8_dot(q8.ptr, s3.ptr, q8b.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2)
+    del q8b
     rec(f"v8_restore_n2^{logn}", 5.0625 * n, lambda: hip.check(lib.clv8_restore(q8.ptr, s3.ptr, n, x.ptr, None)))
     del x, q, s, q2, s2, q3, s3, q8
 
