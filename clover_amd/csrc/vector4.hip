@@ -374,7 +374,10 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
     CLV_REQUIRE(mode == CLV_DOT_EXACT || mode == CLV_DOT_FAST, "clv4_dot: unknown mode %d", mode);
     hipStream_t st = as_stream(stream);
     if (!n_pad) { CLV_HIP(hipMemsetAsync(out_dev, 0, sizeof(float), st)); return CLV_OK; }
-    if (!workspace) {
+    const int grid = dot_fast_grid(n_pad);
+    static const bool two_launches = getenv("CLV_DOT_FAST_TWO_LAUNCHES") != nullptr;      // A/B switch: the round-1..4 form (same bits)
+    const bool needs_scratch = mode == CLV_DOT_EXACT || two_launches || grid > DOT_FAST_THREADS * DOT_MAX_SLOTS_PER_THREAD;
+    if (!workspace && needs_scratch) {
         int rc = clv_internal_workspace(&workspace, clv4_dot_workspace_bytes(n_pad), as_stream(stream));
         if (rc) return rc;
     }
@@ -389,9 +392,7 @@ extern "C" int clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, con
         CLV_LAUNCH_CHECK();
         return CLV_OK;
     }
-    const int grid = dot_fast_grid(n_pad);
-    static const bool two_launches = getenv("CLV_DOT_FAST_TWO_LAUNCHES") != nullptr;      // A/B switch: the round-1..4 form (same bits)
-    if (two_launches || grid > 256 * 8) {
+    if (two_launches || grid > DOT_FAST_THREADS * DOT_MAX_SLOTS_PER_THREAD) {
         hipLaunchKernelGGL(k_v4_dot_partial, dim3(grid), dim3(DOT_FAST_THREADS), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv,
                            n_pad / 32, (float *)workspace);
         CLV_LAUNCH_CHECK();

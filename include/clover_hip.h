@@ -36,7 +36,10 @@
  *      (3) a state belongs to the process that initialised it (re-key with clv_rng_set after sharing the buffer across processes).
  *  - asynchrony: every call only enqueues work on `stream`; results are valid after clv_stream_sync / an event.
  *    clv4_dot, the threshold functions (when `workspace` is NULL) and clm4_gemm use grow-only scratch owned by the library, one
- *    buffer per (device, stream): calls on different streams never share scratch and may overlap.
+ *    buffer per (device, stream): calls on different streams never share scratch and may overlap.  clv4_dot / clv8_dot in CLV_DOT_FAST
+ *    mode are ONE launch whose workgroups hand their partials over through 64 KiB of zero-initialised slots, also per (device, stream),
+ *    allocated (hipMalloc + a memset on the stream) by the first such call there: make one ordinary call on a stream before capturing
+ *    it into a hipGraph (tests/test_graph_capture.py); the kernel leaves the slots zero, so replays need nothing else.
  */
 #ifndef CLOVER_HIP_H
 #define CLOVER_HIP_H
@@ -118,7 +121,8 @@ int  clv4_quantize(const float *x, uint64_t n_pad, int8_t *q, float *s, uint64_t
 int  clv4_restore(const int8_t *q, const float *s, uint64_t n_pad, float *x, void *stream);
 /* CloverVector4::dot (CloverVector4.h:1095-1192).  *out_dev receives one float.  CLV_DOT_EXACT is
  * bit-identical to the reference; CLV_DOT_FAST differs only in fp32 summation order (the per-block
- * integer sums are exact either way).  workspace: clv4_dot_workspace_bytes() bytes or NULL (internal). */
+ * integer sums are exact either way; one launch, deterministic: a fixed tree whatever order the workgroups finish in).
+ * workspace: clv4_dot_workspace_bytes() bytes or NULL (internal); only CLV_DOT_EXACT uses it. */
 uint64_t clv4_dot_workspace_bytes(uint64_t n_pad);
 int  clv4_dot(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, uint64_t n_pad,
               int mode, float *out_dev, void *workspace, void *stream);
