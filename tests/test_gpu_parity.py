@@ -477,3 +477,35 @@ def test_gemm_both_workgroup_tiles_bit_exact(tile):
     env = dict(os.environ, CLV_GEMM_TILE=tile)
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_dot_fast_one_launch_gives_the_two_launch_bits(hip):
+    """round 5: clv4_dot FAST is one launch (slots + collector workgroup); the round-1..4 form (k_v4_dot_partial + k_v4_dot_final), kept behind
+    CLV_DOT_FAST_TWO_LAUNCHES (read once per process: a child process), must give the same bits -- same per-thread order, same final tree"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, json, numpy as np\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "from clover_amd.lib_binding import CloverHip, DOT_FAST\n"
+        "hip = CloverHip(device=0); lib = hip.lib; out = hip.alloc(8); res = {}\n"
+        "for n in (128, 8192, (1 << 16) + 384, 1 << 20, (1 << 24) + 128, 1 << 26):\n"
+        "    q, s, q2, s2 = hip.alloc(n // 2), hip.alloc(n // 16), hip.alloc(n // 2), hip.alloc(n // 16)\n"
+        "    hip.check(lib.clv_fill_random_nibbles(q.ptr, q.nbytes, 1, 0, None)); hip.check(lib.clv_fill_random_nibbles(q2.ptr, q2.nbytes, 2, 0, None))\n"
+        "    hip.check(lib.clv_fill_random_scales(s.ptr, s.nbytes // 4, 3, 0, None)); hip.check(lib.clv_fill_random_scales(s2.ptr, s2.nbytes // 4, 4, 0, None))\n"
+        "    for _ in range(3):\n"
+        "        hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_FAST, out.ptr, None, None))\n"
+        "    res[str(n)] = int(out.download(np.uint32)[0])\n"
+        "print(json.dumps(res))\n")
+    outs = []
+    for extra in ({}, {"CLV_DOT_FAST_TWO_LAUNCHES": "1"}):
+        env = dict(os.environ, **extra)
+        env.pop("CLV_DOT_FAST_TWO_LAUNCHES", None) if not extra else None
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1], outs
