@@ -315,3 +315,26 @@ def test_sharded_loop_calls_equal_the_unsharded_mvm(hip, parts, rows, selftest, 
         assert lib.clm4_sharded_step_timing(ctx, 0, 9, C.byref(km), C.byref(gm)) != 0
     finally:
         hip.check(lib.clm4_sharded_destroy(ctx))
+
+
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_scale_and_add_2p28_streaming_kernels_whole_result(hip, oracle, stochastic):
+    """n = 2^28 (three 128 MiB vectors: beyond the Infinity Cache): the streaming (non-temporal) instances of the round-5 scaleAndAdd kernels --
+    k_v4_scale_and_add_blk<true> and k_v4_scale_and_add_st<64, true> with its block-scalar phases -- which no smaller test reaches.  The
+    WHOLE result, every nibble and scale, against the scalar oracle (device-generated operands, two calls: the second continues the stream)."""
+    lib = hip.lib
+    n = 1 << 28
+    qu, su, qv, sv = hip.alloc(n // 2), hip.alloc(n // 16), hip.alloc(n // 2), hip.alloc(n // 16)
+    r, sr = hip.alloc(n // 2), hip.alloc(n // 16)
+    hip.check(lib.clv_fill_random_nibbles(qu.ptr, qu.nbytes, 81, 0, None))
+    hip.check(lib.clv_fill_random_nibbles(qv.ptr, qv.nbytes, 82, 0, None))
+    hip.check(lib.clv_fill_random_scales(su.ptr, su.nbytes // 4, 83, 0, None))
+    hip.check(lib.clv_fill_random_scales(sv.ptr, sv.nbytes // 4, 84, 0, None))
+    hqu, hsu, hqv, hsv = qu.download(np.uint8), su.download(np.float32), qv.download(np.uint8), sv.download(np.float32)
+    st, o = (hip.new_rng(2028, 5), oracle.rng(2028, 5)) if stochastic else (None, None)
+    for a in (0.5, -1.25):
+        hip.check(lib.clv4_scale_and_add(qu.ptr, su.ptr, qv.ptr, sv.ptr, a, n, r.ptr, sr.ptr, st.ptr if st else None, None))
+        ro, sro = oracle.v4_scale_and_add(hqu, hsu, hqv, hsv, a, o)
+        assert same(r.download(np.uint8), ro) and same(sr.download(np.float32), sro), a
+    if stochastic:
+        assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
