@@ -338,3 +338,18 @@ def test_scale_and_add_2p28_streaming_kernels_whole_result(hip, oracle, stochast
         assert same(r.download(np.uint8), ro) and same(sr.download(np.float32), sro), a
     if stochastic:
         assert np.array_equal(hip.rng_get(st)[1], oracle.rng_keys(o)[1])
+
+
+def test_mvm_f32_streaming_kernel_whole_result(hip, oracle):
+    """clm4_mvm_f32 on a matrix beyond the Infinity Cache (8320 x 65664 nibbles = 273 MB): the non-temporal instance of the kernel with its
+    round-5 q / 16 conversion, five x chunks incl. a ragged one -- every row dot against the scalar oracle, bit for bit"""
+    lib = hip.lib
+    M, N = 8320, 65536 + 128
+    A, sA = hip.alloc(M * N // 2), hip.alloc((M // 64) * (N // 64) * 4)
+    hip.check(lib.clv_fill_random_nibbles(A.ptr, A.nbytes, 91, 0, None))
+    hip.check(lib.clv_fill_random_scales(sA.ptr, sA.nbytes // 4, 92, 0, None))
+    x = (np.random.default_rng(93).normal(size=N) * 2).astype(np.float32)
+    hA, hsA = A.download(np.uint8), sA.download(np.float32)
+    xd, rd = hip.to_device(x), hip.alloc(4 * M)
+    hip.check(lib.clm4_mvm_f32(A.ptr, sA.ptr, M, N, xd.ptr, rd.ptr, None))
+    assert same(rd.download(np.float32), oracle.m4_mvm_f32(hA, hsA, M, N, x))
