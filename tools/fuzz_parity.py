@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """One-off extended fuzz on the GPU box: the randomised parity sweeps of tests/test_gpu_random_shapes.py (GPU == oracle, bit for bit) over many
 more seeds than the suite runs, plus random (n, a) scaleAndAdd / dot cases around the kernel-switch sizes of round 5.  Prints a summary line;
-exit code 1 on the first mismatch (with the seed).     python tools/fuzz_parity.py [first_seed] [count]"""
+exit code 1 on the first mismatch (with the seed).     python tools/fuzz_parity.py [first_seed] [count] [a|b]
+Body `b` (the rows the random-shape tests do not draw): threshold in both modes, 4- and 8-bit (FAST == the lowest-index restatement, REFERENCE ==
+the oracle's heap walk, nibble for nibble) with random (n, K) and tie-heavy data; CloverVector8 scaleAndAdd in both rounding modes; the fused
+mvm + scaleAndAdd; stochastic vector ops with every segment shape forced (1 / 4 / 16 / 64) at sizes that are not multiples of the shape."""
 import sys
 import time
 from pathlib import Path
@@ -12,15 +15,101 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import test_gpu_random_shapes as T  # noqa: E402
-from clover_amd.lib_binding import DOT_EXACT, DOT_FAST, CloverHip  # noqa: E402
+import test_next_rows as NR  # noqa: E402
+from clover_amd.lib_binding import DOT_EXACT, DOT_FAST, THRESHOLD_REFERENCE, CloverHip  # noqa: E402
 from conftest import random_packed  # noqa: E402
 from oracle.binding import Oracle  # noqa: E402
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 150)
+body = sys.argv[3] if len(sys.argv) > 3 else "a"
 hip, orc = CloverHip(device=0), Oracle()
 t0, done = time.time(), 0
+same = NR.same
+
+
+def body_b(seed):
+    rng = np.random.default_rng(50000 + seed)
+    # ---- threshold, 4-bit: n ragged inside its padding, K anywhere in [0, n]; data kinds as tests/test_next_rows.py
+    n = int(rng.integers(1, 40000)) if seed % 5 else int(rng.integers(131072 - 300, 131072 + 4000))
+    npad = (n + 127) // 128 * 128
+    k = int(rng.integers(0, n + 1)) if seed % 3 else int(rng.integers(0, min(n, 64) + 1))
+    x = np.zeros(npad, np.float32)
+    kind = seed % 4
+    if kind == 0:
+        x[:n] = rng.integers(-40, 41, size=n)
+    elif kind == 1:
+        x[:n] = rng.choice(np.array([-7, -3, 0, 3, 7], np.float32), size=n)
+    elif kind == 2:
+        x[:n] = rng.normal(size=n) * np.repeat(rng.uniform(0.1, 10, size=npad // 64), 64)[:n]
+    else:
+        x[:n] = T._data(rng, npad, 3)[:n]
+    q, s = orc.v4_quantize(x)
+    ref = orc.v4_threshold(q, s, n, k)
+    assert same(hip.v4_threshold(q, s, n, k, mode=THRESHOLD_REFERENCE), ref), f"v4 threshold REFERENCE n={n} k={k} kind={kind}"
+    assert same(hip.v4_threshold(q, s, n, k), NR._threshold_lowest_index(orc, q, s, n, k)), f"v4 threshold FAST n={n} k={k} kind={kind}"
+    # ---- threshold, 8-bit
+    n8 = int(rng.integers(1, 30000))
+    npad8 = (n8 + 127) // 128 * 128
+    k8 = int(rng.integers(0, n8 + 1))
+    x8 = np.zeros(npad8, np.float32)
+    x8[:n8] = rng.integers(-40, 41, size=n8) if seed % 2 else rng.normal(size=n8)
+    q8, s8 = orc.v8_quantize(x8)
+    ref8 = orc.v8_threshold(q8, s8, n8, k8)
+    assert same(hip.v8_threshold(q8, s8, n8, k8, mode=THRESHOLD_REFERENCE), ref8), f"v8 threshold REFERENCE n={n8} k={k8}"
+    mags = np.abs((q8.astype(np.float32) * np.repeat(s8, 64)) / np.float32(127.0))[:n8]
+    fast8 = hip.v8_threshold(q8, s8, n8, k8)
+    assert np.array_equal(np.sort(mags[fast8[:n8] != 0]), np.sort(mags[ref8[:n8] != 0])) and same(fast8[n8:], q8[n8:]), f"v8 threshold FAST n={n8} k={k8}"
+    # ---- CloverVector8 scaleAndAdd, both rounding modes, one shared stream
+    m = 128 * int(rng.integers(1, 600))
+    u, v = T._data(rng, m, seed % 4), T._data(rng, m, (seed + 3) % 4)
+    (qu, su), (qv, sv) = orc.v8_quantize(u), orc.v8_quantize(v)
+    a = float(rng.uniform(-2, 2))
+    r, sr = hip.v8_scale_and_add(qu, su, qv, sv, a)
+    ro, sro = orc.v8_scale_and_add(qu, su, qv, sv, a)
+    assert same(r, ro) and same(sr, sro), f"v8 scaleAndAdd m={m}"
+    g, o = hip.new_rng(3 + seed, 11), orc.rng(3 + seed, 11)
+    r, sr = hip.v8_scale_and_add(qu, su, qv, sv, a, rng=g)
+    ro, sro = orc.v8_scale_and_add(qu, su, qv, sv, a, o)
+    assert same(r, ro) and same(sr, sro), f"v8 scaleAndAdd stochastic m={m}"
+    # ---- fused mvm + scaleAndAdd == the two calls on the oracle, both rounding modes
+    M, N = 128 * int(rng.integers(1, 5)), 128 * int(rng.integers(1, 10))
+    qA, sA = random_packed(rng, M * N)[0], rng.uniform(0.5, 2.0, size=(M // 64) * (N // 64)).astype(np.float32)
+    (qx, sx), (qy, sy) = random_packed(rng, N), random_packed(rng, M)
+    for st in (False, True):
+        gg, oo = (hip.new_rng(9 + seed, 5), orc.rng(9 + seed, 5)) if st else (None, None)
+        t_, st_, r, sr = hip.m4_mvm_scale_and_add(qA, sA, M, N, qx, sx, qy, sy, a, rng=gg)
+        to, sto = orc.m4_mvm(qA, sA, M, N, qx, sx, oo)
+        ro, sro = orc.v4_scale_and_add(qy, sy, to, sto, a, oo)
+        assert same(t_, to) and same(st_, sto) and same(r, ro) and same(sr, sro), f"fused mvm+scaleAndAdd {M}x{N} stochastic={st}"
+    # ---- stochastic vector ops with a forced segment shape, size not a multiple of the shape
+    seg = (1, 4, 16, 64)[seed % 4]
+    nb = int(rng.integers(1, 3 * 32 * seg + 40))
+    nv = 128 * ((nb + 1) // 2)
+    xv, yv = T._data(rng, nv, (seed + 1) % 4), T._data(rng, nv, (seed + 2) % 4)
+    (qa, sa), (qb, sb) = orc.v4_quantize(xv), orc.v4_quantize(yv)
+    assert hip.lib.clv_rng_set_segments(seg) == 0
+    try:
+        g, o = hip.new_rng(77 + seed, 3), orc.rng(77 + seed, 3)
+        qs, ss = hip.v4_quantize(xv, rng=g)
+        qso, sso = orc.v4_quantize(xv, o)
+        assert same(qs, qso) and same(ss, sso), f"quantize stochastic seg={seg} n={nv}"
+        r, sr = hip.v4_scale_and_add(qa, sa, qb, sb, a, rng=g)
+        ro, sro = orc.v4_scale_and_add(qa, sa, qb, sb, a, o)
+        assert same(r, ro) and same(sr, sro), f"scaleAndAdd stochastic seg={seg} n={nv}"
+        q8s, s8s = hip.v8_quantize(xv, rng=g)
+        q8o, s8o = orc.v8_quantize(xv, o)
+        assert same(q8s, q8o) and same(s8s, s8o), f"v8 quantize stochastic seg={seg} n={nv}"
+        assert np.array_equal(hip.rng_get(g)[1], orc.rng_keys(o)[1]), f"stream position seg={seg}"
+    finally:
+        hip.lib.clv_rng_set_segments(0)
+
+
 for seed in range(first, first + count):
     try:
+        if body == "b":
+            body_b(seed)
+            done += 1
+            continue
         T.test_vector_ops_random(hip, orc, seed)
         T.test_matrix_ops_random(hip, orc, seed)
         if seed % 4 == 0:
