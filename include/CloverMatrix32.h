@@ -2,12 +2,14 @@
  * CloverMatrix32.h -- fp32 row-major matrix container: the input of CloverMatrix4::quantize and the
  * output of CloverMatrix4::gemm.  Mirrors the storage part of the reference's include/CloverMatrix32.h
  * (:43-73; rows and cols padded to multiples of 128 by CloverMatrix.h:48-53, contents uninitialised).
- * The reference's fp32 mvm (MKL sgemv) and transpose (IPP) are out of scope.
+ * The class's own fp32 arithmetic -- mvm (MKL sgemv there), transpose (IPP / MKL there), quantize = copy -- is provided on the
+ * HOST (clover_fp32.h): the baseline the 4-bit results are compared with, not part of the GPU path.
  */
 #ifndef CLOVER_MATRIX32_H
 #define CLOVER_MATRIX32_H
 
 #include <iomanip>
+#include <iostream>
 #include <sstream>
 #include <string>
 
@@ -42,6 +44,21 @@ public:
     void set(uint64_t i, uint64_t j, float v) { reinterpret_cast<float *>(mem.host_rw())[i * cols + j] = v; }
     void clear() { memset(mem.host_rw(), 0, rows * cols * sizeof(float)); }
 
+    /* ---- fp32 arithmetic on the host (clover_fp32.h; CloverMatrix32.h:90-215) ---- */
+    /* result = A * productVector; shape mismatch: message + exit(1) as the reference (:109-113) */
+    void mvm(const CloverVector32 &productVector, CloverVector32 &result) const { mvm_host(productVector, result, false); }
+    void mvm_parallel(const CloverVector32 &productVector, CloverVector32 &result) const { mvm_host(productVector, result, true); }
+    void mvm_scalar(const CloverVector32 &productVector, CloverVector32 &result) const { mvm_host(productVector, result, false); }
+    void quantize(const CloverMatrix32 &other) { memcpy(mem.host_rw(), other.mem.host_ro(), rows * cols * sizeof(float)); }
+    /* other (cols x rows) = this transposed */
+    void transpose(CloverMatrix32 &other) const { clover_fp32::transpose(host_ro(), rows, cols, other.host_rw(), false); }
+    void transpose_parallel(CloverMatrix32 &other) const { clover_fp32::transpose(host_ro(), rows, cols, other.host_rw(), true); }
+    void transpose_scalar(CloverMatrix32 &other) const { clover_fp32::transpose(host_ro(), rows, cols, other.host_rw(), false); }
+    void setRandomFloats(float min_value, float max_value, uint64_t seed = 0x9E3779B97F4A7C15ull)
+    {
+        clover_fp32::fill_uniform(reinterpret_cast<float *>(mem.host_rw()), rows * cols, min_value, max_value, seed);
+    }
+
     void setRandomInteger(float max_value, uint64_t seed = 0x9E3779B97F4A7C15ull)
     {
         CloverVector32 view(rows * cols, reinterpret_cast<float *>(mem.host_rw()));      /* non-owning view over the same buffer */
@@ -63,6 +80,17 @@ public:
     float *host_rw() { return reinterpret_cast<float *>(mem.host_rw()); }
     const float *device_ro() const { return reinterpret_cast<const float *>(mem.dev_ro()); }
     float *device_wo() { return reinterpret_cast<float *>(mem.dev_wo()); }
+
+private:
+    void mvm_host(const CloverVector32 &x, CloverVector32 &result, bool team) const
+    {
+        if (x.size() != cols) {
+            std::cout << "Can't perform MVM: " << rows << " x " << cols << " Matrix times a " << x.size() << " vector to update a "
+                      << result.size() << " vector. Exiting..." << std::endl;
+            exit(1);
+        }
+        clover_fp32::mvm_rows(host_ro(), rows, cols, x.host_ro(), result.host_rw(), team);
+    }
 };
 
 #endif
