@@ -509,3 +509,54 @@ def test_dot_fast_one_launch_gives_the_two_launch_bits(hip):
         assert p.returncode == 0, p.stderr[-1500:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1], outs
+
+
+def test_internal_workspaces_belong_to_their_stream(hip):
+    """dot (FAST: the hand-over slots of the one-launch reduction; EXACT: the chain operands), threshold (the multi-kernel large-vector path
+    and the REFERENCE heap walk) keep their scratch per (device, stream): the same calls enqueued alternately on two streams, different data
+    on each, nothing synchronised in between, give what each gives alone on the default stream."""
+    import ctypes as C
+
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST, THRESHOLD_FAST, THRESHOLD_REFERENCE
+    lib = hip.lib
+    rng = np.random.default_rng(4242)
+    n_dot, n_thr, n_ref = 1 << 22, (1 << 20) + 128, 65536
+    sets = []
+    for _ in range(2):
+        sets.append({"u": random_packed(rng, n_dot), "v": random_packed(rng, n_dot), "t": random_packed(rng, n_thr), "r": random_packed(rng, n_ref)})
+    want = []
+    for d in sets:                                                   # alone, default stream
+        want.append({"fast": hip.v4_dot(*d["u"], *d["v"], mode=DOT_FAST), "exact": hip.v4_dot(*d["u"], *d["v"], mode=DOT_EXACT),
+                     "thr": hip.v4_threshold(*d["t"], n_thr - 77, n_thr // 4, mode=THRESHOLD_FAST),
+                     "ref": hip.v4_threshold(*d["r"], n_ref, n_ref // 8, mode=THRESHOLD_REFERENCE)})
+    streams = [C.c_void_p(), C.c_void_p()]
+    for st in streams:
+        hip.check(lib.clv_stream_create(C.byref(st)))
+    try:
+        dev = [{k: [hip.to_device(a) for a in v] for k, v in d.items()} for d in sets]
+        out = [{"fast": hip.alloc(4), "exact": hip.alloc(4)} for _ in sets]
+        hip.sync()
+        for rep in range(3):
+            for k in (0, 1):
+                b, st = dev[k], streams[k]
+                hip.check(lib.clv4_dot(b["u"][0].ptr, b["u"][1].ptr, b["v"][0].ptr, b["v"][1].ptr, n_dot, DOT_FAST, out[k]["fast"].ptr, None, st))
+            for k in (0, 1):
+                b, st = dev[k], streams[k]
+                hip.check(lib.clv4_dot(b["u"][0].ptr, b["u"][1].ptr, b["v"][0].ptr, b["v"][1].ptr, n_dot, DOT_EXACT, out[k]["exact"].ptr, None, st))
+            if rep == 0:                                             # threshold works in place: once
+                for k in (0, 1):
+                    b, st = dev[k], streams[k]
+                    hip.check(lib.clv4_threshold_mode(b["t"][0].ptr, b["t"][1].ptr, n_thr - 77, n_thr, n_thr // 4, THRESHOLD_FAST, None, st))
+                for k in (0, 1):
+                    b, st = dev[k], streams[k]
+                    hip.check(lib.clv4_threshold_mode(b["r"][0].ptr, b["r"][1].ptr, n_ref, n_ref, n_ref // 8, THRESHOLD_REFERENCE, None, st))
+        for st in streams:
+            hip.check(lib.clv_stream_sync(st))
+        for k in (0, 1):
+            assert np.float32(out[k]["fast"].download(np.float32, 1)[0]).tobytes() == np.float32(want[k]["fast"]).tobytes()
+            assert np.float32(out[k]["exact"].download(np.float32, 1)[0]).tobytes() == np.float32(want[k]["exact"]).tobytes()
+            assert same(dev[k]["t"][0].download(np.uint8, n_thr // 2), want[k]["thr"])
+            assert same(dev[k]["r"][0].download(np.uint8, n_ref // 2), want[k]["ref"])
+    finally:
+        for st in streams:
+            hip.check(lib.clv_stream_destroy(st))
