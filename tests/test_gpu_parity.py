@@ -560,3 +560,50 @@ def test_internal_workspaces_belong_to_their_stream(hip):
     finally:
         for st in streams:
             hip.check(lib.clv_stream_destroy(st))
+
+
+def test_abi_from_several_host_threads(hip):
+    """four host threads, a stream each, the same mix of calls at once (ctypes drops the GIL inside a call): the registries behind the ABI --
+    workspaces and hand-over slots per (device, stream), the error string per thread -- serve them without mixing anything up"""
+    import ctypes as C
+    import threading
+
+    from clover_amd.lib_binding import DOT_EXACT, DOT_FAST
+    lib = hip.lib
+    n = 1 << 20
+    rng = np.random.default_rng(7)
+    data = [(random_packed(rng, n), random_packed(rng, n), rng.normal(size=n).astype(np.float32)) for _ in range(4)]
+    want = [(hip.v4_dot(*u, *v, mode=DOT_FAST), hip.v4_dot(*u, *v, mode=DOT_EXACT), hip.v4_quantize(x)) for u, v, x in data]
+    dev = [([hip.to_device(a) for a in u], [hip.to_device(a) for a in v], hip.to_device(x), hip.alloc(n // 2), hip.alloc(n // 16), hip.alloc(4), hip.alloc(4))
+           for u, v, x in data]
+    hip.sync()
+    errors = []
+
+    def work(k):
+        try:
+            st = C.c_void_p()
+            hip.check(lib.clv_set_device(0))
+            hip.check(lib.clv_stream_create(C.byref(st)))
+            u, v, x, q, s, of, oe = dev[k]
+            for _ in range(40):
+                hip.check(lib.clv4_dot(u[0].ptr, u[1].ptr, v[0].ptr, v[1].ptr, n, DOT_FAST, of.ptr, None, st))
+                hip.check(lib.clv4_quantize(x.ptr, n, q.ptr, s.ptr, None, st))
+                hip.check(lib.clv4_dot(u[0].ptr, u[1].ptr, v[0].ptr, v[1].ptr, n, DOT_EXACT, oe.ptr, None, st))
+            assert lib.clv4_dot(None, None, None, None, n, DOT_FAST, None, None, st) != 0        # an error of this thread's own
+            hip.check(lib.clv_stream_sync(st))
+            hip.check(lib.clv_stream_destroy(st))
+        except Exception as e:                                       # noqa: BLE001
+            errors.append(f"thread {k}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    hip.sync()
+    for k in range(4):
+        _, _, _, q, s, of, oe = dev[k]
+        assert np.float32(of.download(np.float32, 1)[0]).tobytes() == np.float32(want[k][0]).tobytes()
+        assert np.float32(oe.download(np.float32, 1)[0]).tobytes() == np.float32(want[k][1]).tobytes()
+        assert same(q.download(np.uint8, n // 2), want[k][2][0]) and same(s.download(np.float32, n // 64), want[k][2][1])
