@@ -1588,13 +1588,13 @@ __global__ __launch_bounds__(256) void k_thr_ref_keys(const uint32_t *__restrict
 }
 
 struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global memory read past the vector L1 (lane 0 writes, every lane reads)
-    template <bool IN_LDS> __device__ static __forceinline__ uint2 ld(const uint2 *h, uint32_t i)
+    template <bool IN_LDS> __device__ static __forceinline__ uint2 ld(const uint2 *h, unsigned long long i)
     {
         if (IN_LDS) return h[i];
         const unsigned long long v = __hip_atomic_load((const unsigned long long *)(h + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     }
-    template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *h, uint32_t i, uint2 v)
+    template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *h, unsigned long long i, uint2 v)
     {
         if (threadIdx.x == 0) {
             if (IN_LDS) h[i] = v;
@@ -1609,6 +1609,31 @@ struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    // every lane with `on` stores its own entry at its own index (the moves of one sift step)
+    template <bool IN_LDS> __device__ static __forceinline__ void st_lanes(uint2 *h, bool on, unsigned long long i, uint2 v)
+    {
+        if (on) {
+            if (IN_LDS) h[i] = v;
+            else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!IN_LDS) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    // this lane's own store (make_heap: a lane works inside its own subtree; level_done() orders the levels)
+    template <bool IN_LDS> __device__ static __forceinline__ void st1(uint2 *h, unsigned long long i, uint2 v)
+    {
+        if (IN_LDS) h[i] = v;
+        else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    template <bool IN_LDS> __device__ static __forceinline__ void level_done()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 };
 #define THR_VAL(e) __uint_as_float((e).x)
 // gt_idx_t (CloverBase.h:216-218): (a.value > b.value) || isnan(a.value).  The NaN clause decides only where a NaN magnitude (a block
@@ -1620,58 +1645,92 @@ struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global 
 // must assume to differ per lane
 __device__ __forceinline__ bool thr_uniform(bool c) { return __ballot(c) != 0ull; }
 
+// bit `lane` and the bits of its ancestors inside a 62-node subtree laid out as lane = 2^depth - 2 + offset (depth 1 .. 5): the lanes
+// that must ALL have been chosen for `lane` to lie on the sift path
+__device__ __forceinline__ unsigned long long thr_ancestors(uint32_t lane)
+{
+    if (lane >= 62) return ~0ull;                                       // never satisfied: only bits 0 .. 61 are ever set
+    unsigned long long anc = 0;
+    for (uint32_t l = lane;; l = (l - 2) >> 1) {
+        anc |= 1ull << l;
+        if (l < 2) break;
+    }
+    return anc;
+}
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ vals, uint32_t n, uint32_t k, uint2 *__restrict__ gheap,
                                                      uint32_t *__restrict__ keep)
 {
+    // heap indices: 32 bits while the heap fits LDS (k <= 16384: (pos + 1) << 5 stays small), 64 for the global-memory heap
+    typedef typename std::conditional<IN_LDS, uint32_t, unsigned long long>::type hidx_t;
     extern __shared__ __attribute__((aligned(16))) uint2 thr_lheap[];
     uint2 *h = IN_LDS ? thr_lheap : gheap;
     const uint32_t lane = threadIdx.x;
-    // "Copy the first K-elements" (CloverVector4.h:1933-1940)
-    for (uint32_t i = lane; i < k; i += 64) {
-        const uint2 e = make_uint2(__float_as_uint(vals[i]), i);
+    // "Copy the first K-elements" (CloverVector4.h:1933-1940); entry k is a sentinel (+inf: never smaller than anything) that every
+    // fetch beyond the heap is clamped to
+    for (uint32_t i = lane; i <= k; i += 64) {
+        const uint2 e = i < k ? make_uint2(__float_as_uint(vals[i]), i) : make_uint2(0x7F800000u, 0xFFFFFFFFu);
         if (IN_LDS) h[i] = e;
         else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)e.x | ((unsigned long long)e.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     // std::make_heap(min_heap, min_heap + k, gt_idx_t) (:1944): libstdc++ __make_heap = __adjust_heap(first, parent, len, value) for
-    // parent = (len - 2) / 2 ... 0, comp = gt_idx_t.  Every index below is wave-uniform (kept scalar through thr_uniform)
+    // parent = (len - 2) / 2 ... 0, comp = gt_idx_t.  An adjust touches the subtree under its parent only, and the parents of ONE level have
+    // disjoint subtrees: their adjusts commute, so a level is done by all lanes at once (lane = parent, the scalar algorithm per lane) and
+    // the levels follow each other bottom-up -- the same heap as the sequential order, entry for entry (r5; one parent at a time before:
+    // 0.4 ms at k = 1024).
     if (k >= 2) {
-        for (uint32_t parent = (k - 2) / 2 + 1; parent-- > 0;) {
-            const uint2 v = ThrHeap::ld<IN_LDS>(h, parent);
-            const uint32_t top = parent;
-            uint32_t hole = parent, child = parent;
-            while (child < (k - 1) / 2) {
-                child = 2 * (child + 1);
-                const uint2 a = ThrHeap::ld<IN_LDS>(h, child);
-                const uint2 b = ThrHeap::ld<IN_LDS>(h, child - 1);
-                if (thr_uniform(THR_GT(a, b))) {                           // comp(first + child, first + (child - 1))
-                    child--;
-                    ThrHeap::st<IN_LDS>(h, hole, b);
-                } else {
-                    ThrHeap::st<IN_LDS>(h, hole, a);
+        const uint32_t last_parent = (k - 2) / 2;
+        for (int level = 31 - __builtin_clz(last_parent + 1); level >= 0; level--) {
+            const uint32_t lo = (1u << level) - 1u, hi = (2u << level) - 2u < last_parent ? (2u << level) - 2u : last_parent;
+            for (uint32_t parent = lo + lane; parent <= hi; parent += 64) {
+                const uint2 v = ThrHeap::ld<IN_LDS>(h, parent);
+                const uint32_t top = parent;
+                uint32_t hole = parent, child = parent;
+                while (child < (k - 1) / 2) {
+                    child = 2 * (child + 1);
+                    const uint2 a = ThrHeap::ld<IN_LDS>(h, child);
+                    const uint2 b = ThrHeap::ld<IN_LDS>(h, child - 1);
+                    if (THR_GT(a, b)) {                                        // comp(first + child, first + (child - 1))
+                        child--;
+                        ThrHeap::st1<IN_LDS>(h, hole, b);
+                    } else {
+                        ThrHeap::st1<IN_LDS>(h, hole, a);
+                    }
+                    hole = child;
                 }
-                hole = child;
+                if ((k & 1) == 0 && child == (k - 2) / 2) {
+                    child = 2 * (child + 1);
+                    ThrHeap::st1<IN_LDS>(h, hole, ThrHeap::ld<IN_LDS>(h, child - 1));
+                    hole = child - 1;
+                }
+                while (hole > top) {                                           // __push_heap
+                    const uint32_t par = (hole - 1) / 2;
+                    const uint2 pe = ThrHeap::ld<IN_LDS>(h, par);
+                    if (!THR_GT(pe, v)) break;                                 // comp(first + parent, value)
+                    ThrHeap::st1<IN_LDS>(h, hole, pe);
+                    hole = par;
+                }
+                ThrHeap::st1<IN_LDS>(h, hole, v);
             }
-            if ((k & 1) == 0 && child == (k - 2) / 2) {
-                child = 2 * (child + 1);
-                ThrHeap::st<IN_LDS>(h, hole, ThrHeap::ld<IN_LDS>(h, child - 1));
-                hole = child - 1;
-            }
-            while (hole > top) {                                           // __push_heap
-                const uint32_t par = (hole - 1) / 2;
-                const uint2 pe = ThrHeap::ld<IN_LDS>(h, par);
-                if (!thr_uniform(THR_GT(pe, v))) break;                    // comp(first + parent, value)
-                ThrHeap::st<IN_LDS>(h, hole, pe);
-                hole = par;
-            }
-            ThrHeap::st<IN_LDS>(h, hole, v);
+            ThrHeap::level_done<IN_LDS>();                                     // the next level reads what other lanes wrote in this one
         }
     }
     // the walk over elements k ... n-1 (:1952-1962): strictly larger than the root -> replace the root, min_heapify(0)
     float root = THR_VAL(ThrHeap::ld<IN_LDS>(h, 0));
     float vnext = (k + lane < n) ? vals[k + lane] : -1.0f;
-    const uint32_t last = k - 1;
+    // min_heapify(heap, 0, k) with heap[0] = m (CloverBase.h:226-249): the smaller child moves up while it is smaller than m, the LEFT
+    // child on equal children.  FIVE levels per memory round trip (r5; one pair of dependent round trips PER level in round 4): the 62
+    // descendants of `pos` down to depth 5 are fetched by 62 lanes at once -- lane = 2^depth - 2 + offset, so a left child sits on an even
+    // lane with its right sibling beside it; indices beyond the heap are clamped to the +inf sentinel.  What a sibling pair decides depends
+    // on the pair and on m only (a < m, b < a, b < m), never on the path: three compares in all lanes give every pair's verdict, a
+    // handful of mask operations the set S of chosen children, and a lane lies on the sift path iff it and all its ancestors are in S
+    // (one masked compare against a per-lane constant).  The entries on the path move up one level in ONE masked store.  A wave issues
+    // one instruction per ~4 cycles whatever it is, so the instruction count of this loop IS its time: ~45 per round.
+    const uint32_t ld2 = lane + 2, dep = lane < 62 ? 31u - (uint32_t)__builtin_clz(ld2) : 0u, off = lane < 62 ? ld2 - (1u << dep) : 0u;
+    const unsigned long long anc = thr_ancestors(lane);
+    const unsigned long long LEFT = 0x1555555555555555ull;                 // even lanes 0 .. 60: the left children
     for (uint32_t base = k; base < n; base += 64) {
         const float v = vnext;
         const uint32_t nb = base + 64 + lane;
@@ -1681,40 +1740,26 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
             const int j = __builtin_ctzll(mask);
             const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), j), base + (uint32_t)j);
             const float mv = THR_VAL(m);
-            // min_heapify(heap, 0, k) with heap[0] = m (CloverBase.h:226-249): the smaller child moves up while it is smaller than m, the
-            // LEFT child on equal children.  TWO levels per LDS round trip (r5): the two children of `pos` and its four grandchildren
-            // (entries 4 pos + 3 ... 4 pos + 6, untouched by the move at `pos`) are requested together; round 4 took two dependent
-            // round trips PER level (values, then -- inside the lane-0 branch -- the indices) and ran 3.4 ms at N = 8192, K = 1024.
-            // pick: 0 = m stays here, 1 = the left child moves up, 2 = the right one
-            auto pick = [&](const uint2 a, const uint2 b, bool has_b) {
-                int c = 0;
-                float sv = mv;
-                if (thr_uniform(THR_VAL(a) < sv)) { c = 1; sv = THR_VAL(a); }
-                if (has_b && thr_uniform(THR_VAL(b) < sv)) c = 2;
-                return c;
-            };
-            uint32_t pos = 0;
+            hidx_t pos = 0;
             float new_root = mv;
             for (;;) {
-                const uint32_t l = 2 * pos + 1;
-                if (l >= k) break;
-                const uint32_t g0 = 2 * l + 1;
-                const uint2 cl = ThrHeap::ld<IN_LDS>(h, l), cr = ThrHeap::ld<IN_LDS>(h, l + 1 < k ? l + 1 : l);
-                const uint2 ga = ThrHeap::ld<IN_LDS>(h, g0 < k ? g0 : last), gb = ThrHeap::ld<IN_LDS>(h, g0 + 1 < k ? g0 + 1 : last);
-                const uint2 gc = ThrHeap::ld<IN_LDS>(h, g0 + 2 < k ? g0 + 2 : last), gd = ThrHeap::ld<IN_LDS>(h, g0 + 3 < k ? g0 + 3 : last);
-                const int c1 = pick(cl, cr, l + 1 < k);
-                if (c1 == 0) break;
-                const uint2 up1 = c1 == 1 ? cl : cr;
-                ThrHeap::st<IN_LDS>(h, pos, up1);
-                if (pos == 0) new_root = THR_VAL(up1);
-                pos = c1 == 1 ? l : l + 1;
-                const uint32_t l2 = 2 * pos + 1;                           // = g0 (left) or g0 + 2 (right)
-                if (l2 >= k) break;
-                const uint2 x = c1 == 1 ? ga : gc, y = c1 == 1 ? gb : gd;
-                const int c2 = pick(x, y, l2 + 1 < k);
-                if (c2 == 0) break;
-                ThrHeap::st<IN_LDS>(h, pos, c2 == 1 ? x : y);
-                pos = c2 == 1 ? l2 : l2 + 1;
+                hidx_t mine = ((pos + 1) << dep) - 1 + off;              // lanes 62, 63 fetch `pos` itself: harmless, never on a path
+                mine = mine < (hidx_t)k ? mine : (hidx_t)k;
+                const uint2 e = ThrHeap::ld<IN_LDS>(h, mine);
+                const float a = THR_VAL(e);
+                const float b = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e.x, 0xB1, 0xF, 0xF, false));     // lane ^ 1
+                const unsigned long long alm = __ballot(a < mv), bla = __ballot(b < a), blm = __ballot(b < mv);
+                const unsigned long long r = LEFT & ((alm & bla) | (~alm & blm));      // pairs whose RIGHT child moves up
+                const unsigned long long S = (LEFT & alm & ~r) | (r << 1);             // the chosen child of every pair that has one
+                const unsigned long long path = __ballot((S & anc) == anc);
+                if (path == 0) break;
+                const int last = 63 - __builtin_clzll(path);
+                if (pos == 0) new_root = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)e.x, __builtin_ctzll(path)));
+                ThrHeap::st_lanes<IN_LDS>(h, ((path >> lane) & 1ull) != 0, (mine - 1) >> 1, e);
+                if (IN_LDS) pos = (hidx_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, last);
+                else pos = (hidx_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)mine >> 32), last) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, last));
+                if (last < 30) break;                                        // the path ended above depth 5: m stops at `pos`
             }
             ThrHeap::st<IN_LDS>(h, pos, m);
             root = new_root;
@@ -1772,7 +1817,7 @@ static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t
         // nothing survives (the oracle's reading of k = 0): the bitmap the keys pass has just cleared goes to the apply pass as it is,
         // which clears the first n elements and leaves the padding alone
     } else if (k <= THR_LDS_ENTRIES) {
-        const size_t lds = (size_t)k * sizeof(uint2);
+        const size_t lds = ((size_t)k + 1) * sizeof(uint2);                                  // + the sentinel entry
         if (lds > 64 * 1024) CLV_HIP(hipFuncSetAttribute((const void *)k_thr_ref_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_thr_ref_walk<true>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
     } else {
