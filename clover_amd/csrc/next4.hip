@@ -1562,12 +1562,12 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
 //      __adjust_heap; min_heapify with left-first ties) reproduced step by step.  Which of several EQUAL magnitudes survive is decided by
 //      where they sit in the heap when a larger value arrives, i.e. by the whole history: the walk is sequential by definition, like the
 //      16 fma chains of dot EXACT.  One wavefront runs it: the heap lives in LDS (k <= 16384 entries of {value, index}; beyond that in
-//      global memory), lane 0 writes, all lanes read (same-address broadcast); the stream of the n - k later elements is taken 64 at a
-//      time and a ballot against the current root skips every chunk -- or chunk remainder -- that cannot enter the heap (the root only
-//      grows), so only the inserts cost a sift (one LDS round trip per level).  Around it: a parallel pass that writes |value| per element
+//      global memory); the stream of the n - k later elements is taken 64 at a time and a ballot against the current root skips every
+//      chunk -- or chunk remainder -- that cannot enter the heap (the root only grows), so only the inserts cost a sift (five heap
+//      levels per LDS round trip, see k_thr_ref_walk).  Around it: a parallel pass that writes |value| per element
 //      (the same expression as CloverVector4::get / CloverVector8::get) and a parallel pass that clears every nibble / byte whose index
-//      is not in the final heap.  Cost: ~1 us per insert (log2 k dependent LDS reads): N = 8192, K = 1024 about 1 ms -- an opt-in
-//      exactness mode, the radix select above stays the default.
+//      is not in the final heap.  Cost: ~0.4 us per insert: N = 8192, K = 1024 0.85 ms (round 4: 3.4).  The C ABI's default is the radix
+//      select above; the C++ containers default to this mode (clover_device.h: the exactness switch).
 // =================================================================================================
 #define THR_LDS_ENTRIES 16384u
 
@@ -1751,11 +1751,12 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
                 const unsigned long long alm = __ballot(a < mv), bla = __ballot(b < a), blm = __ballot(b < mv);
                 const unsigned long long r = LEFT & ((alm & bla) | (~alm & blm));      // pairs whose RIGHT child moves up
                 const unsigned long long S = (LEFT & alm & ~r) | (r << 1);             // the chosen child of every pair that has one
-                const unsigned long long path = __ballot((S & anc) == anc);
+                const bool on_path = (S & anc) == anc;
+                const unsigned long long path = __ballot(on_path);
                 if (path == 0) break;
                 const int last = 63 - __builtin_clzll(path);
                 if (pos == 0) new_root = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)e.x, __builtin_ctzll(path)));
-                ThrHeap::st_lanes<IN_LDS>(h, ((path >> lane) & 1ull) != 0, (mine - 1) >> 1, e);
+                ThrHeap::st_lanes<IN_LDS>(h, on_path, (mine - 1) >> 1, e);
                 if (IN_LDS) pos = (hidx_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, last);
                 else pos = (hidx_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)mine >> 32), last) << 32) |
                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, last));

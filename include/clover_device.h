@@ -111,12 +111,12 @@ inline uint64_t round_up(uint64_t v, uint64_t m) { return v % m ? v + m - (v % m
  *                              (n/128 dependent fmas: 0.38 ms at n = 2^24, what one host    within 2e-6 * sum|terms| (the reference's own
  *                              core takes for the same order)                               dot_parallel is "any order" too); memory-bound
  *   threshold()                CLV_THRESHOLD_REFERENCE: the reference's K-entry min-heap   CLV_THRESHOLD_FAST: radix select; the same MULTISET of
- *                              walk, survivors index for index (one wavefront, about 1.3 us  magnitudes survives, ties at the K-th value go to
- *                              per heap insert: 2.8 ms at N = 8192, K = 1024)               the lowest indices (5 us at N = 8192)
+ *                              walk, survivors index for index (one wavefront, about 0.4 us  magnitudes survives, ties at the K-th value go to
+ *                              per heap insert: 0.85 ms at N = 8192, K = 1024)              the lowest indices (5 us at N = 8192)
  *
  *   -DCLOVER_REFERENCE_BITS   both methods return the reference's bits.  THE DEFAULT when neither macro is given: a drop-in first of all
  *                             reproduces what it replaces (a Q_IHT through CloverIHT.h then follows the reference's trajectory tie for tie);
- *   -DCLOVER_FAST             both take the fast form (a quantized IHT iteration at N = 8192: 20 us instead of 2.8 ms).
+ *   -DCLOVER_FAST             both take the fast form (a quantized IHT iteration at N = 8192: 20 us instead of 0.83 ms).
  * At run time: clover_hip::set_exactness(clover_hip::REFERENCE_BITS | clover_hip::FAST) switches both; CLV_EXACTNESS=fast|reference in the
  * environment picks the start value of a build without either macro.  Finer: set_dot_mode() / set_threshold_mode(), and the older
  * single-method macros -DCLOVER_DOT_FAST, -DCLOVER_THRESHOLD_REFERENCE / -DCLOVER_THRESHOLD_FAST and CLV_THRESHOLD_REFERENCE=0|1 still

@@ -241,8 +241,8 @@ int  clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint6
  *   CLV_THRESHOLD_REFERENCE  the reference's survivor SET, index for index: its K-entry min-heap walk (CloverVector4.h:1927-1972,
  *                            std::make_heap under gt_idx_t + min_heapify, CloverBase.h:208-249) is reproduced step by step by one
  *                            wavefront with the heap in LDS.  Sequential by definition (which of several equal magnitudes survive
- *                            depends on the whole insertion history): about 1 us per heap insert -- N = 8192, K = 1024 roughly
- *                            1 ms -- so it is opt-in, for runs that must follow the reference's Q_IHT trajectory exactly.
+ *                            depends on the whole insertion history): about 0.4 us per heap insert -- N = 8192, K = 1024: 0.85 ms.
+ *                            The C++ containers take this mode by default (clover_device.h: the exactness switch); here it is a mode.
  * `workspace` (NULL = library scratch of the stream) needs clv_threshold_reference_workspace_bytes(n_pad) in REFERENCE mode.
  * clm4_iht / clm4_iht_v8 take threshold = 2 for this mode (1 = FAST, 0 = no threshold: Q_GD). */
 #define CLV_THRESHOLD_FAST 0
