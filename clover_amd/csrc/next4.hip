@@ -1587,63 +1587,43 @@ __global__ __launch_bounds__(256) void k_thr_ref_keys(const uint32_t *__restrict
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < keep_words; i += stride) keep[i] = 0;
 }
 
-struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global memory read past the vector L1 (lane 0 writes, every lane reads)
+struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global memory read past the vector L1
+    // global-memory heap: a lane's store and ANOTHER lane's later load of the same entry are ordered by the memory model, not by the in-order
+    // issue of one wavefront: release / acquire at wavefront scope (no instruction on gfx950 beyond a wait for the store; the
+    // LDS heap is ordered by the wave's own lgkmcnt waits)
+    template <bool IN_LDS> __device__ static __forceinline__ void wave_fence()
+    {
+        if (!IN_LDS) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
     template <bool IN_LDS> __device__ static __forceinline__ uint2 ld(const uint2 *h, unsigned long long i)
     {
         if (IN_LDS) return h[i];
         const unsigned long long v = __hip_atomic_load((const unsigned long long *)(h + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     }
-    template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *h, unsigned long long i, uint2 v)
-    {
-        if (threadIdx.x == 0) {
-            if (IN_LDS) h[i] = v;
-            else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // global-memory heap: lane 0's store and the other lanes' later loads of the same entry are ordered by the memory model, not by
-        // the in-order issue of one wavefront: release / acquire at wavefront scope (no instruction on gfx950 beyond a wait
-        // for the store; the LDS heap is ordered by the wave's own lgkmcnt waits)
-        if (!IN_LDS) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-    // every lane with `on` stores its own entry at its own index (the moves of one sift step)
-    template <bool IN_LDS> __device__ static __forceinline__ void st_lanes(uint2 *h, bool on, unsigned long long i, uint2 v)
-    {
-        if (on) {
-            if (IN_LDS) h[i] = v;
-            else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!IN_LDS) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-    // this lane's own store (make_heap: a lane works inside its own subtree; level_done() orders the levels)
+    // this lane's own store, no fence (make_heap: a lane works inside its own subtree; wave_fence() separates the levels)
     template <bool IN_LDS> __device__ static __forceinline__ void st1(uint2 *h, unsigned long long i, uint2 v)
     {
         if (IN_LDS) h[i] = v;
         else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    template <bool IN_LDS> __device__ static __forceinline__ void level_done()
+    // every lane with `on` stores its own entry at its own index (the moves of one sift step); then every lane may read them
+    template <bool IN_LDS> __device__ static __forceinline__ void st_lanes(uint2 *h, bool on, unsigned long long i, uint2 v)
     {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (on) st1<IN_LDS>(h, i, v);
+        wave_fence<IN_LDS>();
     }
+    // one wave-uniform entry, written by lane 0
+    template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *h, unsigned long long i, uint2 v) { st_lanes<IN_LDS>(h, threadIdx.x == 0, i, v); }
 };
 #define THR_VAL(e) __uint_as_float((e).x)
 // gt_idx_t (CloverBase.h:216-218): (a.value > b.value) || isnan(a.value).  The NaN clause decides only where a NaN magnitude (a block
 // scale that is NaN, or infinite over a zero nibble) sits in the initial heap -- kept so that the walk is the reference's for every input
 #define THR_GT(a, b) ((THR_VAL(a) > THR_VAL(b)) || THR_VAL(a) != THR_VAL(a))
-
-// wave-uniform truth of a per-lane condition that is the same in every lane: the ballot is a scalar, so the branches on it are scalar
-// branches (s_cbranch_scc) instead of exec-mask loops -- the values the heap walk compares come from LDS / global loads, which the compiler
-// must assume to differ per lane
-__device__ __forceinline__ bool thr_uniform(bool c) { return __ballot(c) != 0ull; }
 
 // bit `lane` and the bits of its ancestors inside a 62-node subtree laid out as lane = 2^depth - 2 + offset (depth 1 .. 5): the lanes
 // that must ALL have been chosen for `lane` to lie on the sift path
@@ -1714,7 +1694,7 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
                 }
                 ThrHeap::st1<IN_LDS>(h, hole, v);
             }
-            ThrHeap::level_done<IN_LDS>();                                     // the next level reads what other lanes wrote in this one
+            ThrHeap::wave_fence<IN_LDS>();                                     // the next level reads what other lanes wrote in this one
         }
     }
     // the walk over elements k ... n-1 (:1952-1962): strictly larger than the root -> replace the root, min_heapify(0)
