@@ -1561,16 +1561,14 @@ extern "C" int clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_
 //      CloverVector8.h:1680-1740 with the heap helpers of CloverBase.h:208-249 (std::make_heap under gt_idx_t = libstdc++'s bottom-up
 //      __adjust_heap; min_heapify with left-first ties) reproduced step by step.  Which of several EQUAL magnitudes survive is decided by
 //      where they sit in the heap when a larger value arrives, i.e. by the whole history: the walk is sequential by definition, like the
-//      16 fma chains of dot EXACT.  One wavefront runs it: the heap lives in LDS (k <= 16384 entries of {value, index}; beyond that in
-//      global memory); the stream of the n - k later elements is taken 64 at a time and a ballot against the current root skips every
+//      16 fma chains of dot EXACT.  One wavefront runs it: the heap lives in LDS (k <= 20000 entries of {value, index}; beyond that its top
+//      14 levels, the deeper entries in global memory); the stream of the n - k later elements is taken 64 at a time and a ballot against the current root skips every
 //      chunk -- or chunk remainder -- that cannot enter the heap (the root only grows), so only the inserts cost a sift (five heap
 //      levels per LDS round trip, see k_thr_ref_walk).  Around it: a parallel pass that writes |value| per element
 //      (the same expression as CloverVector4::get / CloverVector8::get) and a parallel pass that clears every nibble / byte whose index
 //      is not in the final heap.  Cost: ~0.4 us per insert: N = 8192, K = 1024 0.85 ms (round 4: 3.4).  The C ABI's default is the radix
 //      select above; the C++ containers default to this mode (clover_device.h: the exactness switch).
 // =================================================================================================
-#define THR_LDS_ENTRIES 16384u
-
 template <int BITS>
 __global__ __launch_bounds__(256) void k_thr_ref_keys(const uint32_t *__restrict__ q, const float *__restrict__ s, uint64_t n, float *__restrict__ vals,
                                                       uint32_t *__restrict__ keep, uint64_t keep_words)
@@ -1587,10 +1585,16 @@ __global__ __launch_bounds__(256) void k_thr_ref_keys(const uint32_t *__restrict
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < keep_words; i += stride) keep[i] = 0;
 }
 
-struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global memory read past the vector L1
-    // global-memory heap: a lane's store and ANOTHER lane's later load of the same entry are ordered by the memory model, not by the in-order
-    // issue of one wavefront: release / acquire at wavefront scope (no instruction on gfx950 beyond a wait for the store; the
-    // LDS heap is ordered by the wave's own lgkmcnt waits)
+#define THR_LDS_ENTRIES 16384u      // the LDS part of a heap that does not fit: the top 14 levels
+#define THR_LDS_WHOLE_MAX 20000u    // largest k whose heap (+ sentinel) lives in LDS whole: 160 008 of the CU's 160 KiB
+// the heap's LDS part: the whole heap + its sentinel when k <= THR_LDS_WHOLE_MAX (IN_LDS), else entries 0 .. THR_LDS_ENTRIES - 1 -- the top 14
+// levels, where every sift spends two of its rounds -- with the deeper entries in global memory (r5: all of it was global before, 2.3 x slower)
+extern __shared__ __attribute__((aligned(16))) uint2 thr_lheap[];
+
+struct ThrHeap {            // heap storage: LDS (ds_read / ds_write), beyond its capacity global memory read past the vector L1
+    // global-memory entries: a lane's store and ANOTHER lane's later load of the same entry are ordered by the memory model, not by the
+    // in-order issue of one wavefront: release / acquire at wavefront scope (no instruction on gfx950 beyond a wait for the
+    // store; the LDS part is ordered by the wave's own lgkmcnt waits)
     template <bool IN_LDS> __device__ static __forceinline__ void wave_fence()
     {
         if (!IN_LDS) {
@@ -1599,26 +1603,26 @@ struct ThrHeap {            // heap storage: LDS (ds_read / ds_write) or global 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    template <bool IN_LDS> __device__ static __forceinline__ uint2 ld(const uint2 *h, unsigned long long i)
+    template <bool IN_LDS> __device__ static __forceinline__ uint2 ld(const uint2 *g, unsigned long long i)
     {
-        if (IN_LDS) return h[i];
-        const unsigned long long v = __hip_atomic_load((const unsigned long long *)(h + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (IN_LDS || i < THR_LDS_ENTRIES) return thr_lheap[i];
+        const unsigned long long v = __hip_atomic_load((const unsigned long long *)(g + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     }
     // this lane's own store, no fence (make_heap: a lane works inside its own subtree; wave_fence() separates the levels)
-    template <bool IN_LDS> __device__ static __forceinline__ void st1(uint2 *h, unsigned long long i, uint2 v)
+    template <bool IN_LDS> __device__ static __forceinline__ void st1(uint2 *g, unsigned long long i, uint2 v)
     {
-        if (IN_LDS) h[i] = v;
-        else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (IN_LDS || i < THR_LDS_ENTRIES) thr_lheap[i] = v;
+        else __hip_atomic_store((unsigned long long *)(g + i), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // every lane with `on` stores its own entry at its own index (the moves of one sift step); then every lane may read them
-    template <bool IN_LDS> __device__ static __forceinline__ void st_lanes(uint2 *h, bool on, unsigned long long i, uint2 v)
+    template <bool IN_LDS> __device__ static __forceinline__ void st_lanes(uint2 *g, bool on, unsigned long long i, uint2 v)
     {
-        if (on) st1<IN_LDS>(h, i, v);
+        if (on) st1<IN_LDS>(g, i, v);
         wave_fence<IN_LDS>();
     }
     // one wave-uniform entry, written by lane 0
-    template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *h, unsigned long long i, uint2 v) { st_lanes<IN_LDS>(h, threadIdx.x == 0, i, v); }
+    template <bool IN_LDS> __device__ static __forceinline__ void st(uint2 *g, unsigned long long i, uint2 v) { st_lanes<IN_LDS>(g, threadIdx.x == 0, i, v); }
 };
 #define THR_VAL(e) __uint_as_float((e).x)
 // gt_idx_t (CloverBase.h:216-218): (a.value > b.value) || isnan(a.value).  The NaN clause decides only where a NaN magnitude (a block
@@ -1642,18 +1646,16 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ vals, uint32_t n, uint32_t k, uint2 *__restrict__ gheap,
                                                      uint32_t *__restrict__ keep)
 {
-    // heap indices: 32 bits while the heap fits LDS (k <= 16384: (pos + 1) << 5 stays small), 64 for the global-memory heap
+    // heap indices: 32 bits while the heap fits LDS (k <= 20000: (pos + 1) << 5 stays small), 64 when part of it is in global memory
     typedef typename std::conditional<IN_LDS, uint32_t, unsigned long long>::type hidx_t;
-    extern __shared__ __attribute__((aligned(16))) uint2 thr_lheap[];
-    uint2 *h = IN_LDS ? thr_lheap : gheap;
+    uint2 *h = gheap;                                                   // the global part (unused when the heap fits LDS)
     const uint32_t lane = threadIdx.x;
     // "Copy the first K-elements" (CloverVector4.h:1933-1940); entry k is a sentinel (+inf: never smaller than anything) that every
     // fetch beyond the heap is clamped to
     for (uint32_t i = lane; i <= k; i += 64) {
-        const uint2 e = i < k ? make_uint2(__float_as_uint(vals[i]), i) : make_uint2(0x7F800000u, 0xFFFFFFFFu);
-        if (IN_LDS) h[i] = e;
-        else __hip_atomic_store((unsigned long long *)(h + i), (unsigned long long)e.x | ((unsigned long long)e.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ThrHeap::st1<IN_LDS>(h, i, i < k ? make_uint2(__float_as_uint(vals[i]), i) : make_uint2(0x7F800000u, 0xFFFFFFFFu));
     }
+    ThrHeap::wave_fence<IN_LDS>();
     __syncthreads();
     // std::make_heap(min_heap, min_heap + k, gt_idx_t) (:1944): libstdc++ __make_heap = __adjust_heap(first, parent, len, value) for
     // parent = (len - 2) / 2 ... 0, comp = gt_idx_t.  An adjust touches the subtree under its parent only, and the parents of ONE level have
@@ -1773,7 +1775,7 @@ __global__ __launch_bounds__(256) void k_thr_ref_apply(uint32_t *__restrict__ q,
 
 extern "C" uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad)
 {
-    // [|value| per element: 4 n][survivor bitmap: n / 8][heap when k > 16384: 8 n] + alignment slack
+    // [|value| per element: 4 n][survivor bitmap: n / 8][heap entries beyond LDS when k > 20000: 8 n] + alignment slack
     return n_pad * 4 + ((n_pad / 8 + 255) & ~255ull) + n_pad * 8 + 512;
 }
 
@@ -1797,12 +1799,14 @@ static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t
     if (k == 0) {
         // nothing survives (the oracle's reading of k = 0): the bitmap the keys pass has just cleared goes to the apply pass as it is,
         // which clears the first n elements and leaves the padding alone
-    } else if (k <= THR_LDS_ENTRIES) {
+    } else if (k <= THR_LDS_WHOLE_MAX) {
         const size_t lds = ((size_t)k + 1) * sizeof(uint2);                                  // + the sentinel entry
         if (lds > 64 * 1024) CLV_HIP(hipFuncSetAttribute((const void *)k_thr_ref_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_thr_ref_walk<true>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
     } else {
-        hipLaunchKernelGGL(k_thr_ref_walk<false>, dim3(1), dim3(64), 0, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
+        const size_t lds = (size_t)THR_LDS_ENTRIES * sizeof(uint2);                          // the top 14 levels; the rest in the workspace
+        CLV_HIP(hipFuncSetAttribute((const void *)k_thr_ref_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_thr_ref_walk<false>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
     }
     hipLaunchKernelGGL(k_thr_ref_apply<BITS>, grid, dim3(256), 0, st, q, n, keep);
     CLV_LAUNCH_CHECK();

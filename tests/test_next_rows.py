@@ -193,11 +193,11 @@ def test_gpu_threshold_top_k(hip, oracle, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(128, 128, 1), (128, 128, 127), (130, 256, 64), (1000, 1024, 250), (8192, 8192, 1024), (8192, 8192, 2048),
                                   (16384, 16384, 2048), (65536, 65536, 8192), (131072, 131072, 16384), (40000, 40064, 16385),
-                                  (65536, 65536, 40000), (5000, 5120, 4999), (777, 896, 2), (4096, 4096, 4095)])
+                                  (65536, 65536, 40000), (5000, 5120, 4999), (777, 896, 2), (4096, 4096, 4095), (30000, 30080, 20000), (30000, 30080, 20001)])
 @pytest.mark.parametrize("data", ["ints40", "ties", "distinct"])
 def test_gpu_threshold_reference_order(hip, oracle, case, data):
     """CLV_THRESHOLD_REFERENCE: index-identical to the reference's min-heap walk (make_heap over the first k, strict > against the
-    root, min_heapify with left-first ties) -- LDS heap for k <= 16384, global-memory heap beyond.  `ties`: three magnitudes only
+    root, min_heapify with left-first ties) -- the heap whole in LDS for k <= 20000, its top 14 levels in LDS and the rest in global memory beyond.  `ties`: three magnitudes only
     (almost everything ties at tau); `distinct`: per-block scales make nearly all magnitudes different."""
     n, npad, k = case
     rng = np.random.default_rng(7 * n + k + len(data))

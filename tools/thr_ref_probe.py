@@ -15,7 +15,9 @@ lib = hip.lib
 vp = C.c_void_p
 res = {}
 rng = np.random.default_rng(1)
-for n, k in ((8192, 1024), (1152, 1024), (8192, 64), (8192, 4096), (65536, 8192), (8320, 8192)):
+import os
+CASES = [tuple(int(v) for v in c.split("x")) for c in os.environ["TRP_CASES"].split(",")] if os.environ.get("TRP_CASES") else ((8192, 1024), (1152, 1024), (8192, 64), (8192, 4096), (65536, 8192), (8320, 8192))
+for n, k in CASES:
     q = hip.alloc(n // 2)
     s = hip.alloc(n // 16)
     qq = hip.alloc(n // 2)
