@@ -4,7 +4,10 @@ more seeds than the suite runs, plus random (n, a) scaleAndAdd / dot cases aroun
 exit code 1 on the first mismatch (with the seed).     python tools/fuzz_parity.py [first_seed] [count] [a|b]
 Body `b` (the rows the random-shape tests do not draw): threshold in both modes, 4- and 8-bit (FAST == the lowest-index restatement, REFERENCE ==
 the oracle's heap walk, nibble for nibble) with random (n, K) and tie-heavy data; CloverVector8 scaleAndAdd in both rounding modes; the fused
-mvm + scaleAndAdd; stochastic vector ops with every segment shape forced (1 / 4 / 16 / 64) at sizes that are not multiples of the shape."""
+mvm + scaleAndAdd; stochastic vector ops with every segment shape forced (1 / 4 / 16 / 64) at sizes that are not multiples of the shape.
+Body `c`: matrices whose column count sits around the kernels' LDS chunk sizes (16384 for the fp32 vector, 32768 for the 8-bit one, 65536 for
+the 4-bit one) -- mvm in both rounding modes, mvm_v8, mvm_f32, the fused mvm + scaleAndAdd -- and transposes / stochastic matrix quantize
+on shapes that mix the 256-tile and the 64-tile kernels."""
 import sys
 import time
 from pathlib import Path
@@ -104,8 +107,51 @@ def body_b(seed):
         hip.lib.clv_rng_set_segments(0)
 
 
+def body_c(seed):
+    rng = np.random.default_rng(70000 + seed)
+    chunk = (16384, 32768, 65536)[seed % 3]
+    N = max(128, chunk * int(rng.integers(1, 3)) + 128 * int(rng.integers(-3, 4)))
+    M = 128 * int(rng.integers(1, 4))
+    qA, sA = random_packed(rng, M * N)[0], rng.uniform(0.5, 2.0, size=(M // 64) * (N // 64)).astype(np.float32)
+    sA[rng.integers(0, sA.size, 3)] = np.float32(10.0 ** rng.integers(-20, 20))
+    (qx, sx), (qy, sy) = random_packed(rng, N), random_packed(rng, M)
+    a = float(rng.uniform(-2, 2))
+    for st in (False, True):
+        g, o = (hip.new_rng(1 + seed, 2), orc.rng(1 + seed, 2)) if st else (None, None)
+        r, sr = hip.m4_mvm(qA, sA, M, N, qx, sx, rng=g)
+        ro, sro = orc.m4_mvm(qA, sA, M, N, qx, sx, o)
+        assert same(r, ro) and same(sr, sro), f"mvm {M}x{N} stochastic={st}"
+        t_, st_, r2, sr2 = hip.m4_mvm_scale_and_add(qA, sA, M, N, qx, sx, qy, sy, a, rng=g)
+        to, sto = orc.m4_mvm(qA, sA, M, N, qx, sx, o)
+        r2o, sr2o = orc.v4_scale_and_add(qy, sy, to, sto, a, o)
+        assert same(t_, to) and same(st_, sto) and same(r2, r2o) and same(sr2, sr2o), f"fused mvm+scaleAndAdd {M}x{N} stochastic={st}"
+    x32 = T._data(rng, N, seed % 4)
+    q8, s8 = orc.v8_quantize(x32)
+    r8, sr8 = hip.m4_mvm_v8(qA, sA, M, N, q8, s8)
+    r8o, sr8o = orc.m4_mvm_v8(qA, sA, M, N, q8, s8)
+    assert same(r8, r8o) and same(sr8, sr8o), f"mvm_v8 {M}x{N}"
+    assert same(hip.m4_mvm_f32(qA, sA, M, N, x32), orc.m4_mvm_f32(qA, sA, M, N, x32)), f"mvm_f32 {M}x{N}"
+    # transposes and stochastic matrix quantize: shapes that are / are not multiples of 256
+    Mt, Nt = 128 * int(rng.integers(1, 9)), 128 * int(rng.integers(1, 13))
+    qT, sT = random_packed(rng, Mt * Nt)[0], rng.uniform(0.5, 2.0, size=(Mt // 64) * (Nt // 64)).astype(np.float32)
+    qt, st2 = hip.m4_transpose(qT, sT, Mt, Nt)
+    qto, sto2 = orc.m4_transpose(qT, sT, Mt, Nt)
+    assert same(qt, qto) and same(st2, sto2), f"transpose {Mt}x{Nt}"
+    A = T._data(rng, Mt * Nt, (seed + 1) % 4).reshape(Mt, Nt)
+    g, o = hip.new_rng(21 + seed, 4), orc.rng(21 + seed, 4)
+    for _ in range(2):
+        qs, ss = hip.m4_quantize(A, rng=g)
+        qso, sso = orc.m4_quantize(A, o)
+        assert same(qs, qso) and same(ss, sso), f"matrix quantize stochastic {Mt}x{Nt}"
+    assert np.array_equal(hip.rng_get(g)[1], orc.rng_keys(o)[1]), "stream position after matrix quantize"
+
+
 for seed in range(first, first + count):
     try:
+        if body == "c":
+            body_c(seed)
+            done += 1
+            continue
         if body == "b":
             body_b(seed)
             done += 1
