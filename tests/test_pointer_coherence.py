@@ -146,3 +146,17 @@ def test_reference_validation_grid_in_the_explicit_residency_build(tmp_path):
     p = subprocess.run([str(_build_validate(tmp_path, "validate_grid", extra=("-DCLOVER_HIP_EXPLICIT_SYNC",)))], capture_output=True, text=True,
                        timeout=1500)
     assert p.returncode == 0 and "validate grid ok" in p.stdout, (p.returncode, p.stdout[-3000:], p.stderr[-1000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("build", ["tracked", "explicit"])
+def test_random_operation_sequences_against_a_host_model(tmp_path, build):
+    """tests/cpp/mirror_fuzz.cpp: device kernels, accessors, raw writes and reads through kept getData() / getScales() pointers, copies and a
+    view, in random order -- one object compared with a host-only model after every step.  Ten seeds x 400 steps per container build."""
+    exe = tmp_path / "mirror_fuzz"
+    extra = ["-DCLOVER_HIP_EXPLICIT_SYNC"] if build == "explicit" else []
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", f"-I{ROOT / 'include'}", *extra,
+                    str(CPP / "mirror_fuzz.cpp"), "-o", str(exe), *_link_flags(), "-lpthread"], check=True)
+    for seed in range(10):
+        p = subprocess.run([str(exe), str(1000 + seed), "400"], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0 and p.stdout.strip().startswith("ok"), (seed, p.stdout[-800:], p.stderr[-400:])
