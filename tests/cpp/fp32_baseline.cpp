@@ -90,6 +90,8 @@ int main(int argc, char **argv)
         CHECK(r.getData() == mine && r.get(5) == 5.0f);
         r.set(5, -1.0f);
         CHECK(mine[5] == -1.0f);
+        r.setData(nullptr);                                                       // the view lets go before the caller frees
+        std::free(mine);
     }
     // ---- threshold: distinct magnitudes
     {
