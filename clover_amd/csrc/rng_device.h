@@ -1,4 +1,4 @@
-// rng_device.h -- device-side pieces of the XORShift stream shared by rng4.hip, next4.hip and matrix4.hip.
+// rng_device.h -- device-side pieces of the XORShift stream shared by rng4.hip, scale_add4.hip, mixed8.hip and matrix4.hip.
 //
 // A draw never reads part1 (simdxorshift128plus.h:97-109 as written), so each generator lane k is one 64-bit
 // word a with  n = T(a), out = n + a, a <- n  and T linear over GF(2).  T^e is applied by square-and-multiply
