@@ -58,6 +58,44 @@ __global__ __launch_bounds__(256) void k_v8_quantize_st(const f32x4 *__restrict_
     uint64_t a = segs.starts(base);
     const int rho = lane & 7;
 
+    if constexpr (Sh::NSEG == 16) {
+        // Large vectors (r5): the mapping of k_v4_quantize_st's large-vector form (rng4.hip).  Lane = one float4; a round is 16 pieces of 4
+        // consecutive blocks (one per segment), load j reads piece j = one contiguous KiB, all 16 loads are in flight while the generator lanes
+        // step the stream; a block is a DPP row of 16 lanes (maximum by row rotations).  Element 4 c + t of a block (c = lane & 15) takes
+        // draw c >> 3, word 4 (c & 1) + t, byte (c >> 1) & 3 (CloverVector8.h:462-520 -- the element <-> noise map of the 8-lane form below,
+        // re-indexed), i.e. ONE 16-byte LDS read per lane, and the lane's four bytes are one output dword: a store instruction of the wave
+        // writes the 256 contiguous bytes of its piece.  (The 8-elements-per-lane form ran 0.66 of the HBM peak at n = 2^30.)
+        const int c = lane & 15, g = c >> 1;
+        uint32_t *q32 = reinterpret_cast<uint32_t *>(q);
+        for (int r = 0; r < Sh::ROUNDS; r++) {
+            f32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint64_t blk = blk0 + (uint64_t)j * Sh::SEGLEN + Sh::BPR * r + (lane >> 4);
+                v[j] = __builtin_nontemporal_load(&x[blk < nblocks ? blk * 16 + c : 0]);
+            }
+            if (r) __syncthreads();                          // the previous round's noise has been consumed
+            a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
+            __syncthreads();
+            const u32x4 *noise = reinterpret_cast<const u32x4 *>(raw) + (size_t)((lane >> 4) * 2 + (g >> 2)) * 2 + (c & 1);   // + 16 per piece
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint64_t blk = blk0 + (uint64_t)j * Sh::SEGLEN + Sh::BPR * r + (lane >> 4);
+                float m = fmaxf(fmaxf(__builtin_fabsf(v[j].x), __builtin_fabsf(v[j].y)), fmaxf(__builtin_fabsf(v[j].z), __builtin_fabsf(v[j].w)));
+                m = fix_zero_max(row16_max(m));
+                const float kq = 127.0f / m;
+                const u32x4 W = noise[(size_t)Sh::BPR * 4 * j];
+                uint32_t out = ((uint32_t)quant1_st(v[j].x, kq, noise_of(W.x, g & 3)) & 0xFFu) | (((uint32_t)quant1_st(v[j].y, kq, noise_of(W.y, g & 3)) & 0xFFu) << 8) |
+                               (((uint32_t)quant1_st(v[j].z, kq, noise_of(W.z, g & 3)) & 0xFFu) << 16) | ((uint32_t)quant1_st(v[j].w, kq, noise_of(W.w, g & 3)) << 24);
+                if (!(kq < __builtin_inff())) out = 0u;
+                if (blk < nblocks) {
+                    __builtin_nontemporal_store(out, &q32[blk * 16 + c]);
+                    if (c == 0) s[blk] = m;
+                }
+            }
+        }
+        return;
+    }
     for (int r = 0; r < Sh::ROUNDS; r++) {
         if (lane < 4 * Sh::NSEG) a = gen_blocks(a, Sh::BPR, raw + (size_t)(Sh::BPR * seg) * 8, k);
         __syncthreads();

@@ -93,6 +93,22 @@ def test_stochastic_vector_quantize_2p24_whole(hip, oracle):
     assert np.array_equal(k1, ok1) and np.array_equal(k2, ok2)          # 2^19 draws later: the same place in the stream
 
 
+@pytest.mark.parametrize("width", [4, 8])
+def test_stochastic_vector_quantize_large_form_whole(hip, oracle, width):
+    """beyond 2^18 blocks the stochastic vector quantizers take their large-vector form on their own (lane = one float4, 16 segments per
+    wave: k_v4_quantize_st / k_v8_quantize_st, NSEG == 16): the whole result of a ragged n just above 2^25, both element widths, and
+    the place the stream is left at"""
+    n = (1 << 25) + 128 * 3
+    x = (np.random.default_rng(70 + width).standard_normal(n) * 3).astype(np.float32)
+    st, orng = hip.new_rng(424242, 171717), oracle.rng(424242, 171717)
+    q, s = (hip.v4_quantize if width == 4 else hip.v8_quantize)(x, st)
+    qo, so = (oracle.v4_quantize if width == 4 else oracle.v8_quantize)(x, orng)
+    assert same(q, qo) and same(s, so)
+    k1, k2 = hip.rng_get(st)
+    ok1, ok2 = oracle.rng_keys(orng)
+    assert np.array_equal(k1, ok1) and np.array_equal(k2, ok2)
+
+
 def test_stochastic_matrix_quantize_and_mvm_8192_whole(hip, oracle):
     """8192 x 8192: the quantize consumes 2 draws per tile row in column-block-outer order (CloverMatrix4.h:524-525), the mvm
     2 draws per output block with the 8j+g lane map (:925-932) -- one stream through both calls"""
