@@ -85,7 +85,10 @@ for logn in (24, 30):
     rec(f"v8_dot_fast_n2^{logn}", 2.125 * n, lambda: hip.check(lib.clv8_dot(q8.ptr, s3.ptr, q8b.ptr, s2.ptr, n, DOT_FAST, out.ptr, None, None)))
     if logn == 24:
         rec(f"v8_dot_exact_n2^{logn}", 2.125 * n, lambda: hip.check(lib.clv8_dot(q8.ptr, s3.ptr, q8b.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2)
-    del q8b
+    q8c = hip.alloc(n)
+    rec(f"v8_scale_and_add_n2^{logn}", 3.1875 * n, lambda: hip.check(lib.clv8_scale_and_add(q8.ptr, s3.ptr, q8b.ptr, s2.ptr, 0.5, n, q8c.ptr, s.ptr, None, None)))
+    rec(f"v8_scale_and_add_stochastic_n2^{logn}", 3.1875 * n, lambda: hip.check(lib.clv8_scale_and_add(q8.ptr, s3.ptr, q8b.ptr, s2.ptr, 0.5, n, q8c.ptr, s.ptr, rng.ptr, None)))
+    del q8c, q8b
     rec(f"v8_restore_n2^{logn}", 5.0625 * n, lambda: hip.check(lib.clv8_restore(q8.ptr, s3.ptr, n, x.ptr, None)))
     del x, q, s, q2, s2, q3, s3, q8
 
