@@ -230,6 +230,69 @@ __global__ __launch_bounds__(256) void k_v8_scale_and_add(const u32x4 *qu, const
     }
 }
 
+// Large vectors (r5, as k_v4_scale_and_add_blk in scale_add4.hip): the plain kernel above pays three IEEE divisions (s / 127 twice, 127 / max)
+// and the quad reductions in EVERY lane of a block -- ~1.6 of its ~9 VALU instructions per element, and it is bound by their count
+// (0.63 of the HBM peak at n = 2^30).  Here a wave takes 64 blocks: four 16-byte loads per operand and lane (quarter blocks, one
+// contiguous KiB per instruction), then the per-block arithmetic ONCE per block with lane = block (phases A, C) and ds_bpermute between
+// that lane and the block's four quarter-block lanes.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_v8_scale_and_add_blk(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
+                                                              const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nblocks)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform chunk index: scalar base addresses
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t c = (uint64_t)blockIdx.x * 4 + wave_in_wg; c * 64 < nblocks; c += nwaves) {
+        const uint64_t b0 = c * 64;
+        const uint32_t left = (uint32_t)(nblocks - b0 < 64 ? nblocks - b0 : 64);
+        const bool full = left == 64;
+        const u32x4 *pu = qu + 4 * b0, *pv = qv + 4 * b0;
+        u32x4 *pr = r + 4 * b0;
+        u32x4 wu[4], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t h = 64 * u + lane, hc = full || h < 4 * left ? h : 0;
+            wu[u] = NT ? __builtin_nontemporal_load(pu + hc) : pu[hc];
+            wv[u] = NT ? __builtin_nontemporal_load(pv + hc) : pv[hc];
+        }
+        const uint32_t blc = full || (uint32_t)lane < left ? lane : 0;
+        const float fsu = su[b0 + blc], fsv = sv[b0 + blc];
+        asm volatile("" ::: "memory");                                      // every load of the chunk precedes its stores (r may alias qu)
+        // A: lane = block
+        const float fa = div127(fsu), fb = div127(fsv * a);
+        // B: lane = quarter block
+        float v[4][16], mb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int src = 4 * (16 * u + (lane >> 2));
+            const float cu = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(fa)));
+            const float cv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(fb)));
+            float m = saa8_values(wu[u], wv[u], cu, cv, v[u]);
+            m = fmaxf(m, __shfl_xor(m, 1));
+            mb[u] = fmaxf(m, __shfl_xor(m, 2));
+        }
+        // C: lane = block L: its maximum sits in the quad at lanes 4 (L & 15) of step L >> 4
+        const int from = 4 * (4 * (lane & 15));
+        const float m0 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[0])));
+        const float m1 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[1])));
+        const float m2 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[2])));
+        const float m3 = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mb[3])));
+        const float m = fix_zero_max(lane < 32 ? (lane < 16 ? m0 : m1) : (lane < 48 ? m2 : m3));
+        const float k = 127.0f / m;                                         // IEEE-correct fp32 division (CloverVector8.h:1262)
+        if (full || (uint32_t)lane < left) sr[b0 + lane] = m;
+        // D: lane = quarter block
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float kk = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (16 * u + (lane >> 2)), __float_as_int(k)));
+            const u32x4 o = saa8_pack(v[u], kk, nullptr);
+            const uint32_t h = 64 * u + lane;
+            if (full || h < 4 * left) {
+                if (NT) __builtin_nontemporal_store(o, pr + h); else pr[h] = o;
+            }
+        }
+    }
+}
+
 // stochastic: the segment walk of the other vector kernels.  Element e of a block takes draw e>>5, byte e&3 of word (e&31)>>2
 // (CloverVector8.h:1104-1126, 1193-1229): lane c (= 16 elements) reads the four words W[4 (c & 1) ..] of draw c >> 1.
 template <int S>
@@ -664,6 +727,9 @@ extern "C" int clv8_restore(const int8_t *q, const float *s, uint64_t n_pad, flo
     return CLV_OK;
 }
 
+#ifndef SAA8_BLK_MIN_BLOCKS
+#define SAA8_BLK_MIN_BLOCKS (1u << 21)      // n >= 2^27: where the operands leave the Infinity Cache; below it the plain kernel is as fast or faster (2^24: 9.6 against 10.7 us)
+#endif
 extern "C" int clv8_scale_and_add(const int8_t *qu, const float *su, const int8_t *qv, const float *sv, float a, uint64_t n_pad, int8_t *r,
                                   float *sr, uint64_t *rng_state_dev, void *stream)
 {
@@ -672,6 +738,17 @@ extern "C" int clv8_scale_and_add(const int8_t *qu, const float *su, const int8_
     if (!n_pad) return CLV_OK;
     hipStream_t st = as_stream(stream);
     const uint64_t nb = n_pad / 64;
+    static const uint64_t blk_min = [] { const char *e = getenv("CLV_SAA8_BLK_MIN_BLOCKS"); return e ? strtoull(e, nullptr, 10) : (uint64_t)SAA8_BLK_MIN_BLOCKS; }();      // A/B runs
+    if (!rng_state_dev && nb >= blk_min) {                                // once-per-block arithmetic (k_v8_scale_and_add_blk)
+        const uint64_t want = (nb + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
+        const dim3 grid((unsigned)(want < cap ? want : cap));
+        if (3 * n_pad > (256ull << 20))
+            hipLaunchKernelGGL(k_v8_scale_and_add_blk<true>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a, (u32x4 *)r, sr, nb);
+        else
+            hipLaunchKernelGGL(k_v8_scale_and_add_blk<false>, grid, dim3(256), 0, st, (const u32x4 *)qu, su, (const u32x4 *)qv, sv, a, (u32x4 *)r, sr, nb);
+        CLV_LAUNCH_CHECK();
+        return CLV_OK;
+    }
     if (!rng_state_dev) {
         const uint64_t nq16 = n_pad / 16;
         const uint64_t want = (nq16 + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;

@@ -353,3 +353,15 @@ def test_mvm_f32_streaming_kernel_whole_result(hip, oracle):
     xd, rd = hip.to_device(x), hip.alloc(4 * M)
     hip.check(lib.clm4_mvm_f32(A.ptr, sA.ptr, M, N, xd.ptr, rd.ptr, None))
     assert same(rd.download(np.float32), oracle.m4_mvm_f32(hA, hsA, M, N, x))
+
+
+def test_v8_scale_and_add_2p27_block_kernel_whole_result(hip, oracle):
+    """CloverVector8::scaleAndAdd where it takes the once-per-block kernel on its own (n >= 2^27: the operands leave the Infinity Cache):
+    the whole result of a ragged n against the oracle"""
+    n = (1 << 27) + 128 * 9
+    rng = np.random.default_rng(31)
+    qu, qv = rng.integers(-127, 128, n, dtype=np.int8), rng.integers(-127, 128, n, dtype=np.int8)
+    su, sv = rng.uniform(0.5, 2, n // 64).astype(np.float32), rng.uniform(0.5, 2, n // 64).astype(np.float32)
+    r, sr = hip.v8_scale_and_add(qu, su, qv, sv, -0.75)
+    ro, sro = oracle.v8_scale_and_add(qu, su, qv, sv, -0.75)
+    assert r.tobytes() == ro.tobytes() and sr.tobytes() == sro.tobytes()

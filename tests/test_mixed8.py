@@ -205,6 +205,55 @@ def test_gpu_v8_scale_and_add_exact(hip, oracle, n):
     assert sr[0] == 1.0
 
 
+def _saa8_cases():
+    """(qu, su, qv, sv, a, in_place) for the block-kernel test: ragged last chunks, one chunk, scales at both ends of the fp32 range"""
+    out = []
+    for n in (128, 64 * 64, 64 * 65 + 64, (1 << 18) + 128 * 37):
+        rng = np.random.default_rng(900 + n)
+        (qu, su), (qv, sv) = _rand_v8(rng, n), _rand_v8(rng, n)
+        idx = rng.integers(0, n // 64, 40)
+        su[idx[:20]] = np.float32(1e-38) * rng.uniform(0.1, 9, 20).astype(np.float32)
+        sv[idx[:20]] = np.float32(1e-39)
+        su[idx[20:]] = np.float32(1e37)
+        sv[idx[30:]] = np.float32(3e37)
+        out += [(qu, su, qv, sv, 0.5, False), (qu, su, qv, sv, -2.0, True)]
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_v8_scale_and_add_block_kernel(hip, oracle):
+    """the once-per-block kernel of large vectors (k_v8_scale_and_add_blk, taken on its own from n = 2^27: tests/test_gpu_large.py) forced on
+    small ones in a child process (CLV_SAA8_BLK_MIN_BLOCKS is read once per process): ragged last chunks, a single partial chunk, scales at
+    both ends of the fp32 range (127 / max overflowing -> the block's bytes are 0, as CloverVector8.h:1262-1290 leaves them), in place and
+    out of place -- equal to the oracle wherever the oracle's scale is finite, and to the plain kernel everywhere"""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, json, hashlib\n"
+        f"sys.path.insert(0, {str(root)!r}); sys.path.insert(0, {str(root / 'tests')!r})\n"
+        "import test_mixed8 as T\n"
+        "from clover_amd.lib_binding import CloverHip\n"
+        "hip = CloverHip(device=0); res = []\n"
+        "for qu, su, qv, sv, a, ip in T._saa8_cases():\n"
+        "    r, sr = hip.v8_scale_and_add(qu, su, qv, sv, a, in_place=ip)\n"
+        "    res.append(hashlib.sha256(r.tobytes() + sr.tobytes()).hexdigest())\n"
+        "print(json.dumps(res))\n")
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CLV_SAA8_BLK_MIN_BLOCKS="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1500:]
+    forced = json.loads(p.stdout.strip().splitlines()[-1])
+    for (qu, su, qv, sv, a, ip), h in zip(_saa8_cases(), forced):
+        r, sr = hip.v8_scale_and_add(qu, su, qv, sv, a, in_place=ip)                       # this process: the plain kernel at these sizes
+        assert hashlib.sha256(r.tobytes() + sr.tobytes()).hexdigest() == h
+        ro, sro = oracle.v8_scale_and_add(qu, su, qv, sv, a)
+        ok = np.isfinite(sro)
+        assert same(sr[ok], sro[ok]) and same(r.reshape(-1, 64)[ok], ro.reshape(-1, 64)[ok])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("segments", [1, 4, 16, 64])
 def test_gpu_v8_scale_and_add_stochastic_every_kernel_shape(hip, oracle, segments):
