@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, final check on the GPU: smoke, the whole GPU suite, the driver's command (N = 1) and the two-rank rehearsal
 cd "$(dirname "$0")/../.." || exit 1
-O=gpurun_out/r05_final4; mkdir -p $O
+O=gpurun_out/r05_final5; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 ( timeout 1800 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log )
