@@ -465,8 +465,14 @@ __device__ __forceinline__ void mvm8_epilogue(const Mvm8Tail &t, uint64_t rb, in
     }
 }
 
+#ifndef MVM8_U
+#define MVM8_U 8                  // 16-byte matrix loads in flight per lane
+#endif
+#ifndef MVM8_MIN_WAVES
+#define MVM8_MIN_WAVES 4          // waves per SIMD the register allocation must leave room for
+#endif
 template <int U, bool NT, bool ST, bool FUSE>
-__global__ __launch_bounds__(256, 4) void k_m4_mvm8(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
+__global__ __launch_bounds__(256, MVM8_MIN_WAVES) void k_m4_mvm8(const uint8_t *__restrict__ A, const float *__restrict__ sA, uint64_t cols,
                                                  const int8_t *__restrict__ x, const float *__restrict__ sx, float *__restrict__ d_out,
                                                  int8_t *r, float *sr, uint64_t *rng_state, uint64_t seq,
                                                  const uint64_t *__restrict__ pow_rows, Mvm8Fuse fuse)
@@ -795,7 +801,7 @@ static int launch_mvm8(const int8_t *A, const float *sA, uint64_t rows, uint64_t
     const bool streaming = rows * (cols / 2) > (256ull << 20);
     const Mvm8Fuse no_fuse = {nullptr, nullptr, 0.0f, nullptr, nullptr};
 #define M8_LAUNCH_F(NT, ST, FUSE)                                                                                                      \
-    hipLaunchKernelGGL((k_m4_mvm8<8, NT, ST, FUSE>), grid, block, lds, st, (const uint8_t *)A, sA, cols, x, sx, d, r, sr, rng, seq,    \
+    hipLaunchKernelGGL((k_m4_mvm8<MVM8_U, NT, ST, FUSE>), grid, block, lds, st, (const uint8_t *)A, sA, cols, x, sx, d, r, sr, rng, seq,    \
                        T.pow_rows, FUSE ? *fuse : no_fuse)
 #define M8_LAUNCH(NT, ST)                             \
     do {                                              \
