@@ -2,6 +2,7 @@
 """clv4_threshold_mode(REFERENCE) at a few (n, k): where the heap walk's time goes (make_heap vs the walk).  Wall time per call via HIP events."""
 import ctypes as C
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -10,12 +11,11 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from clover_amd.lib_binding import THRESHOLD_REFERENCE, CloverHip  # noqa: E402
 
-hip = CloverHip()
+hip = CloverHip(path=os.environ.get("CLV_LIB"))
 lib = hip.lib
 vp = C.c_void_p
 res = {}
 rng = np.random.default_rng(1)
-import os
 CASES = [tuple(int(v) for v in c.split("x")) for c in os.environ["TRP_CASES"].split(",")] if os.environ.get("TRP_CASES") else ((8192, 1024), (1152, 1024), (8192, 64), (8192, 4096), (65536, 8192), (8320, 8192))
 for n, k in CASES:
     q = hip.alloc(n // 2)
