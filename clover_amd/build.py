@@ -10,7 +10,7 @@ import shutil
 import subprocess
 from pathlib import Path
 
-HIP_SOURCES = ["runtime.hip", "vector4.hip", "matrix4.hip", "rng4.hip", "gemm4.hip", "gemm6.hip", "multi.hip", "scale_add4.hip", "transpose4.hip", "threshold4.hip", "iht4.hip", "mvm_f32.hip", "mixed8.hip"]
+HIP_SOURCES = ["runtime.hip", "vector4.hip", "matrix4.hip", "rng4.hip", "gemm4.hip", "gemm6.hip", "multi.hip", "scale_add4.hip", "transpose4.hip", "threshold4.hip", "iht4.hip", "iht_persist.hip", "mvm_f32.hip", "mixed8.hip"]
 # per-file additions.  gemm6.hip: hipcc's SLP pass pairs the fold's scalar fmas into v_pk_fma_f32, which is slower beside MFMAs
 # (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); measured here: see DESIGN.md 6
 EXTRA_FLAGS = {}

@@ -45,6 +45,7 @@ int clv_cu_count();
 // grow-only per-device scratch buffer used when the caller passes workspace == NULL
 int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream);      // grow-only scratch per (device, stream)
 void clv_internal_workspace_forget(hipStream_t stream);
+void clv_internal_persist_forget(hipStream_t stream);     // iht_persist.hip: the chain of persistent launches forgets a destroyed stream
 // the exact-order chain kernel of vector4.hip for other sources (mixed8.hip: CloverVector8::dot): see there for the layout of X
 uint64_t clv_internal_dot_chain_blocks_padded(uint64_t steps);
 uint64_t clv_internal_dot_chain_bytes(uint64_t steps);

@@ -212,6 +212,7 @@ extern "C" int clv_stream_create(void **stream)
 extern "C" int clv_stream_destroy(void *stream)
 {
     clv_internal_workspace_forget(as_stream(stream));
+    clv_internal_persist_forget(as_stream(stream));
     CLV_HIP(hipStreamDestroy(as_stream(stream)));
     return CLV_OK;
 }

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Persistent IHT kernel (iht_persist.hip) against the launch-per-step loop (iht4.hip): same inputs, every output bit for bit, then timing.
+Usage: iht_persist_probe.py [check] [time] [N ...]"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clover_amd.lib_binding import CloverHip  # noqa: E402
+
+hip = CloverHip()
+lib = hip.lib
+
+
+def problem(m, n, seed):
+    Phi, PhiT = hip.alloc(m * n // 2), hip.alloc(m * n // 2)
+    sPhi, sPhiT = hip.alloc((m // 64) * (n // 64) * 4), hip.alloc((m // 64) * (n // 64) * 4)
+    hip.check(lib.clv_fill_random_nibbles(Phi.ptr, Phi.nbytes, seed, 0, None))
+    hip.check(lib.clv_fill_random_scales(sPhi.ptr, sPhi.nbytes // 4, seed + 1, 0, None))
+    hip.check(lib.clm4_transpose(Phi.ptr, sPhi.ptr, m, n, PhiT.ptr, sPhiT.ptr, None))
+
+    def vec(k, sd):
+        q, s = hip.alloc(k // 2), hip.alloc(k // 16)
+        hip.check(lib.clv_fill_random_nibbles(q.ptr, q.nbytes, sd, 0, None))
+        hip.check(lib.clv_fill_random_scales(s.ptr, s.nbytes // 4, sd + 1, 0, None))
+        return q, s
+    return (Phi, sPhi, PhiT, sPhiT), [vec(n, seed + 2), vec(m, seed + 4), vec(m, seed + 6), vec(m, seed + 8), vec(n, seed + 10)]
+
+
+def run(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent):
+    os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
+    x, y, t1, t2, t3 = vecs
+    for v in (x, t1, t2, t3):
+        hip.check(lib.clv_memset(v[0].ptr, 0x5A, v[0].nbytes, None))
+        hip.check(lib.clv_memset(v[1].ptr, 0x3C, v[1].nbytes, None))
+    hip.check(lib.clm4_iht(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, x_len, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
+                           t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, mu, thr, None, None))
+    hip.sync()
+    return [np.concatenate([v[0].download(np.uint8, v[0].nbytes), v[1].download(np.uint8, v[1].nbytes)]) for v in (x, t1, t2, t3)]
+
+
+def check():
+    bad = 0
+    cases = [(128, 128), (256, 512), (384, 640), (640, 384), (1024, 2048), (1536, 1024), (2048, 4096), (4096, 8192), (6144, 4096), (8192, 1024), (128, 8192)]
+    for (m, n) in cases:
+        mat, vecs = problem(m, n, 100 + m + n)
+        for thr in (1, 0):
+            for (x_len, K, iters) in ((n, n // 4, 5), (n - 37, n // 8 + 3, 3), (n, 0, 2), (n, n, 2), (n, 1, 4)):
+                if thr == 0 and K != n // 4:
+                    continue
+                for mu in (1e-3, 0.05):
+                    a = run(mat, vecs, m, n, x_len, iters, K, mu, thr, True)
+                    b = run(mat, vecs, m, n, x_len, iters, K, mu, thr, False)
+                    ok = all(np.array_equal(u, v) for u, v in zip(a, b))
+                    nz = int((a[0][: n // 2] != 0).sum())
+                    if not ok:
+                        bad += 1
+                        which = [nm for nm, u, v in zip(("x", "t1", "t2", "t3"), a, b) if not np.array_equal(u, v)]
+                        print(f"MISMATCH m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu}: {which}")
+                    else:
+                        print(f"ok m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu} (nonzero x bytes {nz})")
+    print("CHECK", "FAILED" if bad else "PASSED", bad)
+    return bad
+
+
+def timing(Ns):
+    for N in Ns:
+        m, n = N // 2, N
+        mat, vecs = problem(m, n, 31)
+        x, y, t1, t2, t3 = vecs
+        for persistent in (0, 1):
+            os.environ["CLV_IHT_PERSISTENT"] = str(persistent)
+            for thr, K in ((1, n // 4), (1, m // 4), (0, 0)):
+                def call(iters):
+                    hip.check(lib.clm4_iht(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr,
+                                           t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, 1e-3, thr, None, None))
+                    hip.sync()
+                call(10)
+                res = {}
+                for iters in (1, 100, 1000):
+                    best = 1e9
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        call(iters)
+                        best = min(best, time.perf_counter() - t0)
+                    res[iters] = best
+                per = (res[1000] - res[100]) / 900 * 1e6
+                print(f"N={N} persistent={persistent} thr={thr} K={K}: 1 it {res[1]*1e6:.1f} us, 100 it {res[100]*1e6:.1f} us, 1000 it {res[1000]*1e6:.1f} us -> {per:.2f} us/iteration", flush=True)
+
+
+def stamps(N, thr=1):
+    m, n = N // 2, N
+    mat, vecs = problem(m, n, 31)
+    x, y, t1, t2, t3 = vecs
+    G = 256
+    buf = hip.alloc(G * 16 * 16 * 8)
+    hip.check(lib.clv_memset(buf.ptr, 0, buf.nbytes, None))
+    os.environ["CLV_IHT_PERSISTENT"] = "1"
+    os.environ["CLV_IHT_DEBUG_STAMPS"] = hex(buf.ptr)
+    hip.check(lib.clm4_iht(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr,
+                           t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 16, n // 4, 1e-3, thr, None, None))
+    hip.sync()
+    del os.environ["CLV_IHT_DEBUG_STAMPS"]
+    st = buf.download(np.uint64, G * 16 * 16).reshape(G, 16, 16).astype(np.int64)
+    names = ["P1", "gather1", "requant1", "barrier", "P2", "gather2", "requant2", "threshold", "tail"]
+    used = st[:, 0, 0] != 0
+    print(f"N={N} thr={thr}: {int(used.sum())} workgroups; per-phase mean / max over workgroups, iterations 4..15, in us (wave 0's view)")
+    seg = (st[used][:, 4:, 1:10] - st[used][:, 4:, 0:9]) / 100.0
+    for k, nm in enumerate(names):
+        print(f"  {nm:10s} mean {seg[:, :, k].mean():6.2f}  max {seg[:, :, k].max():6.2f}  min {seg[:, :, k].min():6.2f}")
+    tot = (st[used][:, 15, 9] - st[used][:, 4, 0]) / 100.0 / 12
+    print(f"  iteration  mean {tot.mean():6.2f}")
+    start = st[used][:, 0, 0]
+    print(f"  first stamp spread over workgroups: {(start.max() - start.min()) / 100.0:.2f} us")
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    rc = 0
+    if not args or "check" in args:
+        rc = check()
+    if "stamps" in args:
+        for N in [int(a) for a in args if a.isdigit()] or [256, 8192]:
+            stamps(N, 1)
+            stamps(N, 0)
+    if not args or "time" in args:
+        Ns = [int(a) for a in args if a.isdigit()] or [256, 1024, 2048, 4096, 8192]
+        timing(Ns)
+    sys.exit(1 if rc else 0)
