@@ -50,17 +50,28 @@ struct IhtpArgs {
     float mu;
     int threshold;                // 0: Q_GD, 1: Q_IHT with the FAST threshold
     u64 *g1, *g2;                 // granules: m and n of them, zero before the launch
+    uint32_t nap0, nap;           // s_sleep(1) units before the first poll round of a gather / between two rounds
     u64 *dbg;                     // NULL, or 16 wall-clock stamps (100 MHz) per iteration and workgroup for tools/iht_persist_probe.py
 };
-#define IHTP_STAMP(k) do { if (A.dbg && threadIdx.x == 0 && it < 16) A.dbg[((size_t)g * 16 + it) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define IHTP_STAMP(k) do { if (A.dbg && (threadIdx.x == 0 || threadIdx.x == IHTP_THREADS - 1) && it < 16) A.dbg[((size_t)g * 16 + it) * 32 + (threadIdx.x ? 16 : 0) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// ---- who owns which rows ------------------------------------------------------------------------------------------------------------
+// A consumer thread owns ONE WORD of a vector (elements 8 w .. 8 w + 7) and wants its 8 dots with coalesced loads: element e = 8 w + k
+// lives in granule slot (len / 8) * k + w.  A producer wants whole 128-byte lines of its own (16 slots: a line shared between producers
+// is invalidated under the pollers once per producer -- the first version of this kernel, natural row order: 6-9 us per gather at
+// N = 8192; this dealing: 1.5-1.9).  Both hold when a workgroup owns "units": unit u = (a = u >> 3, k = u & 7) = the 16 rows
+// 128 a + 8 j + k, j = 0..15 = slots (len / 8) k + 16 a + j.  A workgroup takes R / 16 consecutive units (R = 16, 32 or 64 rows); they
+// share `a`, so its rows lie in the two 64-row groups 2 a (j < 8) and 2 a + 1: two sets of per-block factors instead of one.
+__device__ __forceinline__ uint32_t unit_row(uint32_t u, uint32_t j) { return 128u * (u >> 3) + 8u * j + (u & 7u); }
+__device__ __forceinline__ uint32_t unit_slot(uint32_t u, uint32_t j, uint32_t len) { return (len >> 3) * (u & 7u) + 16u * (u >> 3) + j; }
 
 // ---- LDS layout (bytes; every offset a multiple of 16) -----------------------------------------------------------------------------
 // A row of Phi in LDS is re-dealt so that a chain lane reads FOUR consecutive steps with one ds_read_b128: row word wi = 16 t + j
 // (step t, chain j) sits at word (t >> 2) * 64 + j * 4 + (t & 3).  x / t2 use the same dealing; the per-block factors c[b]
-// (b = 2 t + a, a = j >> 3) sit at float (t >> 2) * 8 + a * 4 + (t & 3).
+// (b = 2 t + a, a = j >> 3) sit at float (t >> 2) * 8 + a * 4 + (t & 3), once per row-group half.
 struct IhtpLayout {
     uint32_t TG1, TG2;            // step groups (4 steps = 512 columns) of Phi's / PhiT's rows
-    uint32_t offA1, offA2, offXV, offC1, offTV, offC2, offP1, offP2, offHist, offWtot, offPub, offStage, total;
+    uint32_t offA1, offA2, offXV, offC1, offTV, offC2, offP1, offP2, offHist, offWtot, offSel, offPub, offLut, total;
 };
 
 __host__ __device__ inline IhtpLayout ihtp_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2)
@@ -72,16 +83,17 @@ __host__ __device__ inline IhtpLayout ihtp_layout(uint32_t m, uint32_t n, uint32
     L.offA1 = o; o += R1 * L.TG1 * 256;
     L.offA2 = o; o += R2 * L.TG2 * 256;
     L.offXV = o; o += L.TG1 * 256;
-    L.offC1 = o; o += L.TG1 * 32;
+    L.offC1 = o; o += 2 * L.TG1 * 32;      // two row-group halves
     L.offTV = o; o += L.TG2 * 256;
-    L.offC2 = o; o += L.TG2 * 32;
-    L.offP1 = o; o += L.TG1 * 32;          // f32(sPhi[rg][b] * 1/49), dealt like c
-    L.offP2 = o; o += L.TG2 * 32;
+    L.offC2 = o; o += 2 * L.TG2 * 32;
+    L.offP1 = o; o += 2 * L.TG1 * 32;      // f32(sPhi[rg][b] * 1/49), dealt like c
+    L.offP2 = o; o += 2 * L.TG2 * 32;
     L.offHist = o; o += 4 * 256 * 4;
     L.offWtot = o; o += 64;
-    L.offPub = o; o += 64 * 4;                                        // this workgroup's dots on their way to the publishing wave
-    L.offStage = o; o += ((m > n ? m : n) < 4096u ? (m > n ? m : n) : 4096u) * 4;      // gathered dots -> owner layout, 4096 per pass
-    L.total = o;
+    L.offSel = o; o += 64;                 // the scanning wave's (prefix, need) per radix level
+    L.offPub = o; o += 64 * 4;             // this workgroup's dots on their way to the publishing wave
+    L.offLut = o; o += 256 * 8;            // byte -> magnitude counts of its two nibbles (9 fields of 7 bits)
+    L.total = o + 1024;                    // the row-dot loop reads (never uses) up to two step groups past an array's end
     return L;
 }
 
@@ -101,22 +113,23 @@ __device__ __forceinline__ uint32_t group8_add(uint32_t v)
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
 }
 
-// copy R rows of a row-major nibble matrix (row = T * 64 bytes) into LDS in the dealt layout: work item = (row, step group, chain
-// quad jq): four 16-byte loads 64 B apart (steps 4 tg .. 4 tg + 3, chains 4 jq .. 4 jq + 3), a 4 x 4 word transposition in
-// registers, four ds_write_b128
-__device__ __forceinline__ void ihtp_load_rows(const uint8_t *__restrict__ A, uint64_t row0, uint32_t R, uint32_t T, uint32_t TG, uint32_t *lds)
+// copy this workgroup's R rows (units u0 .., 16 rows each) of a row-major nibble matrix (row = T * 64 bytes) into LDS in the dealt layout:
+// work item = (local row, step group, chain quad jq): four 16-byte loads 64 B apart (steps 4 tg .. 4 tg + 3, chains 4 jq .. 4 jq + 3),
+// a 4 x 4 word transposition in registers, four ds_write_b128
+__device__ __forceinline__ void ihtp_load_rows(const uint8_t *__restrict__ A, uint32_t u0, uint32_t R, uint32_t T, uint32_t TG, uint32_t *lds)
 {
     const uint32_t items = R * TG * 4;
     for (uint32_t it = threadIdx.x; it < items; it += IHTP_THREADS) {
-        const uint32_t jq = it & 3, tg = (it >> 2) % TG, r = (it >> 2) / TG;
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(A + (row0 + r) * (uint64_t)T * 64);
+        const uint32_t jq = it & 3, tg = (it >> 2) % TG, lr = (it >> 2) / TG;
+        const uint64_t row = unit_row(u0 + (lr >> 4), lr & 15);
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(A + row * (uint64_t)T * 64);
         u32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t t = 4 * tg + i;
             v[i] = t < T ? src[4 * t + jq] : u32x4{0u, 0u, 0u, 0u};
         }
-        u32x4 *dst = reinterpret_cast<u32x4 *>(lds + (size_t)(r * TG + tg) * 64 + jq * 16);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lds + (size_t)(lr * TG + tg) * 64 + jq * 16);
         dst[0] = u32x4{v[0].x, v[1].x, v[2].x, v[3].x};
         dst[1] = u32x4{v[0].y, v[1].y, v[2].y, v[3].y};
         dst[2] = u32x4{v[0].z, v[1].z, v[2].z, v[3].z};
@@ -135,49 +148,64 @@ __device__ __forceinline__ int sdot8z(uint32_t a, uint32_t b)
 
 struct IhtpStepRegs { u32x4 a, x; f32x4 c; };
 
-__device__ __forceinline__ float ihtp_steps4(const IhtpStepRegs &r, float acc)
+// the four exact word integers of a step group as floats (order-free work: it is interleaved with the previous group's fma chain below)
+__device__ __forceinline__ f32x4 ihtp_ints(const IhtpStepRegs &r)
 {
-    acc = __builtin_fmaf(r.c.x, (float)sdot8z(r.a.x, r.x.x), acc);
-    acc = __builtin_fmaf(r.c.y, (float)sdot8z(r.a.y, r.x.y), acc);
-    acc = __builtin_fmaf(r.c.z, (float)sdot8z(r.a.z, r.x.z), acc);
-    return __builtin_fmaf(r.c.w, (float)sdot8z(r.a.w, r.x.w), acc);
+    return f32x4{(float)sdot8z(r.a.x, r.x.x), (float)sdot8z(r.a.y, r.x.y), (float)sdot8z(r.a.z, r.x.z), (float)sdot8z(r.a.w, r.x.w)};
+}
+// acc through the four steps of group `cur` (its integers in ic) WHILE the next group's integers are formed: the fma chain is the only
+// dependent sequence of the loop, and a lone wave on its SIMD needs independent instructions between two links of it
+__device__ __forceinline__ float ihtp_chain4(float acc, const f32x4 c, const f32x4 ic, const IhtpStepRegs &nx, f32x4 &in)
+{
+    const int n0 = sdot8z(nx.a.x, nx.x.x);
+    acc = __builtin_fmaf(c.x, ic.x, acc);
+    const int n1 = sdot8z(nx.a.y, nx.x.y);
+    in.x = (float)n0;
+    acc = __builtin_fmaf(c.y, ic.y, acc);
+    const int n2 = sdot8z(nx.a.z, nx.x.z);
+    in.y = (float)n1;
+    acc = __builtin_fmaf(c.z, ic.z, acc);
+    const int n3 = sdot8z(nx.a.w, nx.x.w);
+    in.z = (float)n2;
+    acc = __builtin_fmaf(c.w, ic.w, acc);
+    in.w = (float)n3;
+    return acc;
 }
 
 // the row dot of lane (row, chain j) from LDS and the reference's add tree over the row's 16 lanes; every lane of the row returns the dot.
-// The step groups are read two ahead of their use (registers double-buffered by hand: a lone wave per SIMD has nobody to hide the LDS
-// latency behind; the first version, read-then-use, spent 1.6 us on 64 steps).
+// Step groups are read two ahead of their use (registers double-buffered by hand: a lone wave per SIMD has nobody to hide the LDS latency
+// behind; the first version, read-then-use, spent 1.6 us on 64 steps).  Reads run up to two groups past the row's end (inside LDS, unused).
 __device__ __forceinline__ float ihtp_row_dot(const uint32_t *Arow, const uint32_t *xv, const float *cf, uint32_t T, int j)
 {
     const u32x4 *Ap = reinterpret_cast<const u32x4 *>(Arow) + j;
     const u32x4 *Xp = reinterpret_cast<const u32x4 *>(xv) + j;
     const f32x4 *Cp = reinterpret_cast<const f32x4 *>(cf) + (j >> 3);
     float acc = 0.0f;
-    const uint32_t full = T >> 2, groups = (T + 3) >> 2, lastg = groups - 1;
-#define IHTP_LOAD(R, G) do { const uint32_t g_ = (G) < lastg ? (G) : lastg; R.a = Ap[g_ * 16]; R.x = Xp[g_ * 16]; R.c = Cp[g_ * 2]; } while (0)
-    IhtpStepRegs r0, r1, r2, r3;
+    const uint32_t full = T >> 2;
+#define IHTP_LOAD(R, G) do { R.a = Ap[(G) * 16]; R.x = Xp[(G) * 16]; R.c = Cp[(G) * 2]; } while (0)
+    IhtpStepRegs r0, r1;
     IHTP_LOAD(r0, 0);
     IHTP_LOAD(r1, 1);
+    f32x4 i0 = ihtp_ints(r0), i1;
     uint32_t tg = 0;
-    for (; tg + 4 <= full; tg += 4) {
-        IHTP_LOAD(r2, tg + 2);
-        IHTP_LOAD(r3, tg + 3);
-        acc = ihtp_steps4(r0, acc);
-        acc = ihtp_steps4(r1, acc);
-        IHTP_LOAD(r0, tg + 4);
-        IHTP_LOAD(r1, tg + 5);
-        acc = ihtp_steps4(r2, acc);
-        acc = ihtp_steps4(r3, acc);
+    for (; tg + 2 <= full; tg += 2) {                                   // r0 = group tg (integers in i0), r1 = group tg + 1
+        const f32x4 c0 = r0.c;
+        IHTP_LOAD(r0, tg + 2);
+        acc = ihtp_chain4(acc, c0, i0, r1, i1);
+        const f32x4 c1 = r1.c;
+        IHTP_LOAD(r1, tg + 3);
+        acc = ihtp_chain4(acc, c1, i1, r0, i0);
     }
-    for (; tg < full; tg++) {                                           // r0 = group tg, r1 = group tg + 1
-        acc = ihtp_steps4(r0, acc);
+    if (tg < full) {                                                   // one more full group: r0; the partial one, if any, is then r1
+        acc = ihtp_chain4(acc, r0.c, i0, r1, i1);
         r0 = r1;
-        IHTP_LOAD(r1, tg + 2);
+        i0 = i1;
     }
-    if (T & 3) {                                                       // the last, partial step group (cols % 512 != 0): it is r0
+    if (T & 3) {                                                       // the last, partial step group (cols % 512 != 0): it is r0 / i0
         const uint32_t rem = T & 3;
-        acc = __builtin_fmaf(r0.c.x, (float)sdot8z(r0.a.x, r0.x.x), acc);
-        if (rem > 1) acc = __builtin_fmaf(r0.c.y, (float)sdot8z(r0.a.y, r0.x.y), acc);
-        if (rem > 2) acc = __builtin_fmaf(r0.c.z, (float)sdot8z(r0.a.z, r0.x.z), acc);
+        acc = __builtin_fmaf(r0.c.x, i0.x, acc);
+        if (rem > 1) acc = __builtin_fmaf(r0.c.y, i0.y, acc);
+        if (rem > 2) acc = __builtin_fmaf(r0.c.z, i0.z, acc);
     }
 #undef IHTP_LOAD
     // chain j: accumulator a = j >> 3, AVX lane w = j & 7.  v[w] = acc[0][w] + acc[1][w]; x[i] = v[i + 4] + v[i]; (x0 + x2) + (x1 + x3).
@@ -189,56 +217,34 @@ __device__ __forceinline__ float ihtp_row_dot(const uint32_t *Arow, const uint32
     return y2 + IHTP_DPP_F(y2, 0xB1);
 }
 
-// Gather a published vector of `len` dots.  Granule e = {epoch, bits of d[e]} sits at slot e: a producer's R rows are R consecutive
-// slots = whole 128-byte lines of its own, written by one wave instruction -- no line is shared between producers.  Thread t polls
-// slots t + 1024 k (coalesced, 8 bytes per lane), re-polling what has not arrived, and returns them in v[k] (k < ceil(len / 1024)).
-__device__ __forceinline__ void ihtp_gather(const u64 *g, uint32_t t, uint32_t len, uint32_t epoch, float v[8])
+// gather word w's 8 dots: granule {epoch, bits of d[8 w + k]} sits at slot k * stride + w (stride = len / 8): coalesced 8-byte loads,
+// re-polled until every lane of the wave has everything.  A poll round moves the whole vector into every CU (64 KiB at n = 8192: 16 MiB
+// chip-wide), so rounds are not free: the first one is issued `nap0` sleeps after the workgroup's own publication -- about when the
+// slowest producer's lines land -- and a missed one is followed after `nap`.  (Two rounds in flight half a round trip apart, to cut the
+// quantisation of the waiting time, measured SLOWER: 14.0 against 10.8 us per iteration, the polls are the traffic.)
+__device__ __forceinline__ void ihtp_gather8(const u64 *g, uint32_t stride, uint32_t w, uint32_t epoch, bool active, uint32_t nap0, uint32_t nap, float d[8])
 {
-    uint32_t pending = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (t + 1024u * k < len) pending |= 1u << k;
+    uint32_t pending = active ? 0xFFu : 0u;
     uint32_t spins = 0;
     u64 t_start = 0;
+    for (uint32_t z = 0; z < nap0; z++) __builtin_amdgcn_s_sleep(1);
     while (true) {
-        u64 raw[8];
+        u64 v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (pending & (1u << k)) raw[k] = __hip_atomic_load((const gu64 *)g + t + 1024u * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pending & (1u << k)) v[k] = __hip_atomic_load((const gu64 *)g + (size_t)k * stride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if ((pending & (1u << k)) && (uint32_t)(raw[k] >> 32) == epoch) {
-                v[k] = __uint_as_float((uint32_t)raw[k]);
+            if ((pending & (1u << k)) && (uint32_t)(v[k] >> 32) == epoch) {
+                d[k] = __uint_as_float((uint32_t)v[k]);
                 pending &= ~(1u << k);
             }
         if (!__any(pending != 0)) break;
-        __builtin_amdgcn_s_sleep(2);
+        for (uint32_t z = 0; z < nap; z++) __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023u) == 0) {                                  // bounded: 4 s on the 100 MHz wall clock, then a trap
             const u64 now = __builtin_amdgcn_s_memrealtime();
             if (!t_start) t_start = now;
             else if (now - t_start > 400000000ull) __builtin_trap();
-        }
-    }
-}
-
-// the gathered dots (thread t holds elements t + 1024 k) -> the owner layout (thread w holds elements 8 w .. 8 w + 7) through the
-// 4096-float staging buffer, 4096 elements per pass.  Contains 1 + 2 (passes - 1) workgroup barriers... the caller must have a barrier
-// between this call's last read of `stage` and its next write (there always is one).
-__device__ __forceinline__ void ihtp_to_owner(const float v[8], uint32_t t, uint32_t len, float *stage, float d[8])
-{
-    const uint32_t passes = (len + 4095u) / 4096u;
-    for (uint32_t p = 0; p < passes; p++) {
-        if (p) __syncthreads();                                         // the previous pass has been read
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float val = p ? v[4 + k] : v[k];
-            if (4096u * p + t + 1024u * k < len) stage[t + 1024u * k] = val;
-        }
-        __syncthreads();
-        if ((t >> 9) == p && 8u * t < len) {
-            const f32x4 lo = *reinterpret_cast<const f32x4 *>(stage + 8u * (t & 511u)), hi = *reinterpret_cast<const f32x4 *>(stage + 8u * (t & 511u) + 4);
-            d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w;
-            d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
         }
     }
 }
@@ -276,27 +282,46 @@ __device__ __forceinline__ void ihtp_requant_saa(const float d[8], uint32_t uw, 
     ow = ihtp_quant8(val, 7.0f / os, q2);
 }
 
+// byte -> the magnitude counts of its two nibbles, th4_count_word's field layout (9 fields of 7 bits)
+__device__ __forceinline__ u64 ihtp_lut_entry(uint32_t b)
+{
+    const uint32_t h = b >> 4, l = b & 15u;
+    const uint32_t mh = h < 8 ? h : 16u - h, ml = l < 8 ? l : 16u - l;
+    return (1ull << (7u * mh)) + (1ull << (7u * ml));
+}
+
 // CloverVector4::threshold(K), FAST rule (threshold4.hip k_thresh_small: same keys, same selection, lowest-index ties), for a vector
 // held one word per thread, blocks = groups of 8 lanes.  n = logical length; s = this thread's block scale.  Returns the new word.
-// Uses hist[1024] (zero on entry, zero again on exit) and wtot[16]; contains 5 workgroup barriers.
-__device__ __forceinline__ uint32_t ihtp_threshold(uint32_t w, float s, uint32_t tid_, uint32_t n, uint32_t k, uint32_t *hist, uint32_t *wtot)
+// All 1024 threads redo this in every workgroup, so instructions and LDS round trips count: the magnitude counts of a word come from a
+// byte table, the 256 bins of a radix level are scanned by ONE wave (16 waves on 4 SIMDs share the issue slots; the others wait for
+// (prefix, need) at a barrier), the per-block cut-offs come from the block's own candidate keys.  Measured and dropped (profiles/
+// r06_iht_persist_notes.txt): every wave scanning for itself (same time); 9-bit levels below the candidates' common leading bits with the
+// bins in 4 copies (3 levels instead of 4, but a level's scan + clear by one wave costs 0.68 us against 0.42).
+// LDS: hist[4 * 256] zero on entry and again on exit; wtot[16], sel[8], lut[256].  9 workgroup barriers.
+__device__ __forceinline__ uint32_t ihtp_threshold(uint32_t w, float s, uint32_t tid_, uint32_t n, uint32_t k, uint32_t *hist, uint32_t *wtot,
+                                                   uint32_t *sel, const u64 *lut, u64 *dbg)
 {
+#define THR_STAMP(k_) do { if (dbg && threadIdx.x == 0) dbg[k_] = __builtin_amdgcn_s_memrealtime(); } while (0)
     const int tid = (int)tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t first = 8u * tid;
     const uint32_t valid = first >= n ? 0u : (n - first < 8u ? n - first : 8u);
     const float s7 = div7(s);
+    const int i = tid & 7;
+    // candidates (block, magnitude): lane i of the group takes magnitude i, lane 0 also magnitude 8
+    const uint32_t key0 = cand_key(s7, i), key1 = cand_key(s7, 8);
     uint32_t tau = 0x7F800000u, keep = 0;
     if (k != 0) {
         // magnitude counts of the block: 9 fields of 7 bits summed over the block's 8 lanes (two 32-bit halves; no carries between fields:
         // a field is at most 64 only when it is the only non-zero one -- 7 bits hold 64)
-        const u64 cw = th4_count_word(w, valid);
+        u64 cw;
+        if (valid == 8) cw = (lut[w & 0xFFu] + lut[(w >> 8) & 0xFFu]) + (lut[(w >> 16) & 0xFFu] + lut[w >> 24]);
+        else cw = th4_count_word(w, valid);
         const uint32_t lo = group8_add((uint32_t)cw), hi = group8_add((uint32_t)(cw >> 32));
         const u64 cnt = ((u64)hi << 32) | lo;
-        // candidates (block, magnitude): lane i of the group takes magnitude i, lane 0 also magnitude 8
-        const int i = tid & 7;
-        const uint32_t wgt0 = (uint32_t)(cnt >> (7 * i)) & 0x7Fu, key0 = cand_key(s7, i);
-        const uint32_t wgt1 = i == 0 ? (uint32_t)(cnt >> 56) & 0x7Fu : 0u, key1 = cand_key(s7, 8);
+        const uint32_t wgt0 = (uint32_t)(cnt >> (7 * i)) & 0x7Fu;
+        const uint32_t wgt1 = i == 0 ? (uint32_t)(cnt >> 56) & 0x7Fu : 0u;
         uint32_t prefix = 0, need = k;
+        THR_STAMP(10);
 #pragma unroll
         for (int level = 0; level < 4; level++) {
             const int shift = 24 - 8 * level;
@@ -304,34 +329,38 @@ __device__ __forceinline__ uint32_t ihtp_threshold(uint32_t w, float s, uint32_t
             if (wgt0 && (level == 0 || (key0 >> (shift + 8)) == prefix)) atomicAdd(&h[(key0 >> shift) & 0xFFu], wgt0);
             if (wgt1 && (level == 0 || (key1 >> (shift + 8)) == prefix)) atomicAdd(&h[(key1 >> shift) & 0xFFu], wgt1);
             __syncthreads();
-            // every wave selects for itself: lane l owns bins 255 - 4 l ... 252 - 4 l (from the top)
-            const u32x4 h4 = *reinterpret_cast<const u32x4 *>(h + 252 - 4 * lane);
-            const uint32_t t0 = h4.w, t1 = h4.z, t2 = h4.y, t3 = h4.x;
-            const uint32_t sum = t0 + t1 + t2 + t3;
-            const uint32_t incl = wave_scan_incl(sum);
-            const u64 hit = __ballot(incl >= need && incl - sum < need);
-            const int L = __builtin_ctzll(hit);                          // exactly one lane: the level's total weight is >= need
-            uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)(incl - sum), L);      // L is wave-uniform: v_readlane, no LDS round trip
-            const uint32_t T0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, L), T1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, L),
-                           T2 = (uint32_t)__builtin_amdgcn_readlane((int)t2, L);
-            uint32_t pick = 0;
-            if (above + T0 < need) { above += T0; pick = 1;
-                if (above + T1 < need) { above += T1; pick = 2;
-                    if (above + T2 < need) { above += T2; pick = 3; } } }
-            prefix = (prefix << 8) | (255u - 4u * (uint32_t)L - pick);
-            need -= above;
+            THR_STAMP(11 + level);
+            if (wave == 0) {
+                // lane l owns bins 255 - 4 l ... 252 - 4 l (from the top)
+                const u32x4 h4 = *reinterpret_cast<const u32x4 *>(h + 252 - 4 * lane);
+                const uint32_t t0 = h4.w, t1 = h4.z, t2 = h4.y, t3 = h4.x;
+                const uint32_t sum = t0 + t1 + t2 + t3;
+                const uint32_t incl = wave_scan_incl(sum);
+                const u64 hit = __ballot(incl >= need && incl - sum < need);
+                const int L = __builtin_ctzll(hit);                      // exactly one lane: the level's total weight is >= need
+                uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)(incl - sum), L);      // L is wave-uniform: v_readlane, no LDS round trip
+                const uint32_t T0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, L), T1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, L),
+                               T2 = (uint32_t)__builtin_amdgcn_readlane((int)t2, L);
+                uint32_t pick = 0;
+                if (above + T0 < need) { above += T0; pick = 1;
+                    if (above + T1 < need) { above += T1; pick = 2;
+                        if (above + T2 < need) { above += T2; pick = 3; } } }
+                if (lane == 0) { sel[2 * level] = (prefix << 8) | (255u - 4u * (uint32_t)L - pick); sel[2 * level + 1] = need - above; }
+            }
+            __syncthreads();
+            prefix = sel[2 * level];
+            need = sel[2 * level + 1];
         }
         tau = prefix;
         keep = need;
     }
-    // per block: magnitudes >= hi_t are above tau, [lo_t, hi_t) equal it
-    uint32_t lo_t = 0, hi_t = 0;
-#pragma unroll
-    for (int mth = 0; mth <= 8; mth++) {
-        const uint32_t key = cand_key(s7, mth);
-        lo_t += key < tau;
-        hi_t += key <= tau;
-    }
+    THR_STAMP(15);
+#undef THR_STAMP
+    // per block: magnitudes >= hi_t are above tau, [lo_t, hi_t) equal it -- counted over the block's 9 candidate keys, one or two per lane
+    uint32_t pk = (key0 < tau ? 1u : 0u) + (key0 <= tau ? 256u : 0u);
+    if (i == 0) pk += (key1 < tau ? 1u : 0u) + (key1 <= tau ? 256u : 0u);
+    pk = group8_add(pk);
+    const uint32_t lo_t = pk & 0xFFu, hi_t = pk >> 8;
     const uint32_t ab = abs_nibbles(swap_nibbles(w));
     const uint32_t vmask = first_nibbles(valid);
     const uint32_t above = ge_nibbles(ab, hi_t);
@@ -361,37 +390,46 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
     float *c1 = reinterpret_cast<float *>(smem + L.offC1), *c2 = reinterpret_cast<float *>(smem + L.offC2);
     float *p1 = reinterpret_cast<float *>(smem + L.offP1), *p2 = reinterpret_cast<float *>(smem + L.offP2);
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + L.offHist), *wtot = reinterpret_cast<uint32_t *>(smem + L.offWtot);
-    float *pub = reinterpret_cast<float *>(smem + L.offPub), *stage = reinterpret_cast<float *>(smem + L.offStage);
+    uint32_t *sel = reinterpret_cast<uint32_t *>(smem + L.offSel);
+    float *pub = reinterpret_cast<float *>(smem + L.offPub);
+    u64 *lut = reinterpret_cast<u64 *>(smem + L.offLut);
 
     const uint32_t tid0 = threadIdx.x, g = blockIdx.x;
     const uint32_t m = A.m, n = A.n, T1 = n / 128, T2 = m / 128;
-    const uint32_t row1 = g * A.R1, row2 = g * A.R2;                     // this workgroup's first row of Phi / PhiT
-    const bool has1 = row1 < m, has2 = row2 < n;
+    const uint32_t u1 = g * (A.R1 >> 4), u2 = g * (A.R2 >> 4);           // this workgroup's first unit of Phi's / PhiT's rows
+    const bool has1 = u1 < m / 16, has2 = u2 < n / 16;
+    const uint32_t H1 = L.TG1 * 8, H2 = L.TG2 * 8;                       // floats per row-group half of the factor arrays
 
     // ---- once per call: the matrix slices, the per-block factors' constant halves, y, x = 0 ----
-    if (has1) ihtp_load_rows(A.Phi, row1, A.R1, T1, L.TG1, A1);
-    if (has2) ihtp_load_rows(A.PhiT, row2, A.R2, T2, L.TG2, A2);
-    for (uint32_t i = tid0; i < L.TG1 * 64; i += IHTP_THREADS) xv[i] = 0;                       // x.clear(): nibbles 0 ...
-    for (uint32_t i = tid0; i < L.TG1 * 8; i += IHTP_THREADS) { c1[i] = 0.0f; p1[i] = 0.0f; }
-    for (uint32_t i = tid0; i < L.TG2 * 8; i += IHTP_THREADS) { c2[i] = 0.0f; p2[i] = 0.0f; }
+    if (has1) ihtp_load_rows(A.Phi, u1, A.R1, T1, L.TG1, A1);
+    if (has2) ihtp_load_rows(A.PhiT, u2, A.R2, T2, L.TG2, A2);
+    for (uint32_t i = tid0; i < L.TG1 * 64; i += IHTP_THREADS) xv[i] = 0;                      // x.clear(): nibbles 0 ...
+    for (uint32_t i = tid0; i < 2 * H1; i += IHTP_THREADS) { c1[i] = 0.0f; p1[i] = 0.0f; }
+    for (uint32_t i = tid0; i < 2 * H2; i += IHTP_THREADS) { c2[i] = 0.0f; p2[i] = 0.0f; }
     for (uint32_t i = tid0; i < L.TG2 * 64; i += IHTP_THREADS) tv[i] = 0;
     hist[tid0] = 0;
+    if (tid0 < 256) lut[tid0] = ihtp_lut_entry(tid0);
     __syncthreads();
     if (has1)
-        for (uint32_t b = tid0; b < n / 64; b += IHTP_THREADS) {
-            const float p = A.sPhi[(size_t)(row1 >> 6) * (n / 64) + b] * CLV_RCP49;
-            p1[dealt_factor(b)] = p;
-            c1[dealt_factor(b)] = p * 1.0f;                                                       // ... scales 1.0
+        for (uint32_t i = tid0; i < 2 * (n / 64); i += IHTP_THREADS) {
+            const uint32_t h = i / (n / 64), b = i - h * (n / 64);
+            const float p = A.sPhi[(size_t)(2 * (u1 >> 3) + h) * (n / 64) + b] * CLV_RCP49;
+            p1[h * H1 + dealt_factor(b)] = p;
+            c1[h * H1 + dealt_factor(b)] = p * 1.0f;                                             // ... scales 1.0
         }
     if (has2)
-        for (uint32_t b = tid0; b < m / 64; b += IHTP_THREADS) p2[dealt_factor(b)] = A.sPhiT[(size_t)(row2 >> 6) * (m / 64) + b] * CLV_RCP49;
-    const bool own_m = tid0 < m / 8, own_n = tid0 < n / 8;                 // this thread owns word tid0 of the m- / n-element vectors
+        for (uint32_t i = tid0; i < 2 * (m / 64); i += IHTP_THREADS) {
+            const uint32_t h = i / (m / 64), b = i - h * (m / 64);
+            p2[h * H2 + dealt_factor(b)] = A.sPhiT[(size_t)(2 * (u2 >> 3) + h) * (m / 64) + b] * CLV_RCP49;
+        }
+    const bool own_m = tid0 < m / 8;                                     // this thread owns word tid of the m- / n-element vectors
     const uint32_t yw = own_m ? A.y[tid0] : 0u;
     const float ys = own_m ? A.sy[tid0 >> 3] : 1.0f;
     uint32_t xw = 0;
     float xs = 1.0f;
     __syncthreads();
 
+    if (A.dbg && tid0 == 0) { A.dbg[((size_t)g * 16 + 15) * 32 + 28] = __builtin_readcyclecounter(); A.dbg[((size_t)g * 16 + 15) * 32 + 29] = __builtin_amdgcn_s_memrealtime(); }
     for (uint32_t it = 0; it < A.iterations; it++) {
         const uint32_t epoch = it + 1;
         // the thread index, opaque to the optimiser once per iteration: everything derived from it (LDS addresses, granule addresses,
@@ -402,31 +440,35 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         IHTP_STAMP(0);
         // ---- P1: t1's row dots -> LDS -> one wave publishes this workgroup's lines ----
         if (has1 && tid < 16 * A.R1) {
-            const float dot = ihtp_row_dot(A1 + (size_t)(tid >> 4) * L.TG1 * 64, xv, c1, T1, tid & 15);
-            if ((tid & 15) == 0) pub[tid >> 4] = dot;
+            const uint32_t lr = tid >> 4;
+            const float dot = ihtp_row_dot(A1 + (size_t)lr * L.TG1 * 64, xv, c1 + ((lr >> 3) & 1u) * H1, T1, tid & 15);
+            if ((tid & 15) == 0) pub[lr] = dot;
         }
         IHTP_STAMP(1);
         __syncthreads();
         if (has1 && tid < A.R1)
-            __hip_atomic_store((gu64 *)A.g1 + row1 + tid, ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu64 *)A.g1 + unit_slot(u1 + (tid >> 4), tid & 15, m), ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         // ---- E1: all of d1 -> t1 = quantize(d1), t2 = quantize(y - t1) ----
-        float d[8];
-        {
-            float v[8];
-            ihtp_gather(A.g1, tid, m, epoch, v);
+        if ((tid & ~63u) < m / 8) {                                      // wave-uniform: waves that own no word skip the gather
+            float d[8];
+            ihtp_gather8(A.g1, m / 8, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
             IHTP_STAMP(2);
-            ihtp_to_owner(v, tid, m, stage, d);
-        }
-        if (tid < m / 8) {
-            uint32_t t1w, t2w;
-            float t1s, t2s;
-            ihtp_requant_saa(d, yw, ys, -1.0f, t1w, t1s, t2w, t2s);
-            tv[dealt_word(tid)] = t2w;
-            if ((tid & 7) == 0) c2[dealt_factor(tid >> 3)] = p2[dealt_factor(tid >> 3)] * t2s;
-            if (last && g == 0) {
-                A.t1[tid] = t1w;
-                A.t2[tid] = t2w;
-                if ((tid & 7) == 0) { A.st1[tid >> 3] = t1s; A.st2[tid >> 3] = t2s; }
+            if (tid < m / 8) {
+                uint32_t t1w, t2w;
+                float t1s, t2s;
+                ihtp_requant_saa(d, yw, ys, -1.0f, t1w, t1s, t2w, t2s);
+                tv[dealt_word(tid)] = t2w;
+                if ((tid & 7) == 0) {
+                    const uint32_t f = dealt_factor(tid >> 3);
+                    c2[f] = p2[f] * t2s;
+                    c2[H2 + f] = p2[H2 + f] * t2s;
+                }
+                if (last && g == 0) {
+                    A.t1[tid] = t1w;
+                    A.t2[tid] = t2w;
+                    if ((tid & 7) == 0) { A.st1[tid >> 3] = t1s; A.st2[tid >> 3] = t2s; }
+                }
             }
         }
         IHTP_STAMP(3);
@@ -434,29 +476,35 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         IHTP_STAMP(4);
         // ---- P2: t3's row dots ----
         if (has2 && tid < 16 * A.R2) {
-            const float dot = ihtp_row_dot(A2 + (size_t)(tid >> 4) * L.TG2 * 64, tv, c2, T2, tid & 15);
-            if ((tid & 15) == 0) pub[tid >> 4] = dot;
+            const uint32_t lr = tid >> 4;
+            const float dot = ihtp_row_dot(A2 + (size_t)lr * L.TG2 * 64, tv, c2 + ((lr >> 3) & 1u) * H2, T2, tid & 15);
+            if ((tid & 15) == 0) pub[lr] = dot;
         }
         IHTP_STAMP(5);
         __syncthreads();
         if (has2 && tid < A.R2)
-            __hip_atomic_store((gu64 *)A.g2 + row2 + tid, ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu64 *)A.g2 + unit_slot(u2 + (tid >> 4), tid & 15, n), ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         // ---- E2: all of d3 -> t3 = quantize(d3), x = quantize(x + mu t3), threshold ----
-        {
-            float v[8];
-            ihtp_gather(A.g2, tid, n, epoch, v);
-            IHTP_STAMP(6);
-            ihtp_to_owner(v, tid, n, stage, d);
-        }
         uint32_t t3w = 0;
         float t3s = 1.0f;
-        if (tid < n / 8) ihtp_requant_saa(d, xw, xs, A.mu, t3w, t3s, xw, xs);
+        if ((tid & ~63u) < n / 8) {
+            float d[8];
+            ihtp_gather8(A.g2, n / 8, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
+            IHTP_STAMP(6);
+            if (tid < n / 8) ihtp_requant_saa(d, xw, xs, A.mu, t3w, t3s, xw, xs);
+        }
         IHTP_STAMP(7);
-        if (A.threshold && A.K < A.x_len) xw = ihtp_threshold(xw, xs, tid, A.x_len, A.K, hist, wtot);       // all 1024 threads: it has barriers
+        if (A.threshold && A.K < A.x_len) xw = ihtp_threshold(xw, xs, tid, A.x_len, A.K, hist, wtot, sel, lut,
+                                                                       A.dbg && it < 16 ? A.dbg + ((size_t)g * 16 + it) * 32 : nullptr);       // all threads: barriers inside
         IHTP_STAMP(8);
         if (tid < n / 8) {
             xv[dealt_word(tid)] = xw;
-            if ((tid & 7) == 0) c1[dealt_factor(tid >> 3)] = p1[dealt_factor(tid >> 3)] * xs;
+            if ((tid & 7) == 0) {
+                const uint32_t f = dealt_factor(tid >> 3);
+                c1[f] = p1[f] * xs;
+                c1[H1 + f] = p1[H1 + f] * xs;
+            }
             if (last && g == 0) {
                 A.t3[tid] = t3w;
                 A.x[tid] = xw;
@@ -466,6 +514,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         __syncthreads();
         IHTP_STAMP(9);
     }
+    if (A.dbg && tid0 == 0) { A.dbg[((size_t)g * 16 + 15) * 32 + 30] = __builtin_readcyclecounter(); A.dbg[((size_t)g * 16 + 15) * 32 + 31] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------------
@@ -513,14 +562,14 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     if (!mode || rng || threshold < 0 || threshold > 1 || !iterations || iterations >= 0x7FFFFFFFull) return 0;
     if (m > IHTP_MAXLEN || n > IHTP_MAXLEN || m % 128 || n % 128 || !m || !n) return 0;
     const int cus = clv_cu_count();
-    const uint32_t rows_min = [] { const char *e = getenv("CLV_IHT_ROWS_MIN"); const int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+    // rows per workgroup: 16 (one unit = one 128-byte line of granules), 32 or 64
     uint32_t R1 = pow2_ceil((uint32_t)((m + cus - 1) / cus)), R2 = pow2_ceil((uint32_t)((n + cus - 1) / cus));
-    if (R1 < rows_min) R1 = pow2_ceil(rows_min);
-    if (R2 < rows_min) R2 = pow2_ceil(rows_min);
+    if (R1 < 16) R1 = 16;
+    if (R2 < 16) R2 = 16;
     if (R1 > 64 || R2 > 64) return 0;
     const IhtpLayout L = ihtp_layout((uint32_t)m, (uint32_t)n, R1, R2);
     if (L.total > 160u * 1024u) return 0;
-    const uint32_t grid = (uint32_t)((m / R1 > n / R2) ? (m + R1 - 1) / R1 : (n + R2 - 1) / R2);
+    const uint32_t grid = (uint32_t)((m / R1 > n / R2) ? m / R1 : n / R2);
     if ((int)grid > cus) return 0;
 
     static std::mutex attr_mutex;
@@ -549,8 +598,12 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     a.t1 = (uint32_t *)t1; a.st1 = st1; a.t2 = (uint32_t *)t2; a.st2 = st2; a.t3 = (uint32_t *)t3; a.st3 = st3;
     a.iterations = (uint32_t)iterations; a.K = (uint32_t)(K > 0xFFFFFFFFull ? 0xFFFFFFFFull : K); a.mu = mu; a.threshold = threshold;
     a.g1 = (u64 *)ws; a.g2 = (u64 *)ws + m;
+    a.nap0 = 10;         // ~0.3 us: measured best of 0 / 10 / 20 / 30 / 40 at N = 8192 (profiles/r06_iht_persist_notes.txt)
+    a.nap = 2;
+    if (const char *e = getenv("CLV_IHT_NAP0")) a.nap0 = (uint32_t)atoi(e);                             // probe only
+    if (const char *e = getenv("CLV_IHT_NAP")) a.nap = (uint32_t)atoi(e);                               // probe only
     a.dbg = nullptr;
-    if (const char *e = getenv("CLV_IHT_DEBUG_STAMPS")) a.dbg = (u64 *)strtoull(e, nullptr, 0);      // probe only: a device buffer of grid * 16 * 16 words
+    if (const char *e = getenv("CLV_IHT_DEBUG_STAMPS")) a.dbg = (u64 *)strtoull(e, nullptr, 0);      // probe only: a device buffer of grid * 16 * 32 words
     hipLaunchKernelGGL(k_iht4_persist, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

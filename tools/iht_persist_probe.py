@@ -96,21 +96,44 @@ def stamps(N, thr=1):
     mat, vecs = problem(m, n, 31)
     x, y, t1, t2, t3 = vecs
     G = 256
-    buf = hip.alloc(G * 16 * 16 * 8)
+    buf = hip.alloc(G * 16 * 32 * 8)
     hip.check(lib.clv_memset(buf.ptr, 0, buf.nbytes, None))
     os.environ["CLV_IHT_PERSISTENT"] = "1"
     os.environ["CLV_IHT_DEBUG_STAMPS"] = hex(buf.ptr)
     hip.check(lib.clm4_iht(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr,
-                           t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 16, n // 4, 1e-3, thr, None, None))
+                           t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, int(os.environ.get("IHT_PROBE_ITERS", "16")), n // 4, 1e-3, thr, None, None))
     hip.sync()
     del os.environ["CLV_IHT_DEBUG_STAMPS"]
-    st = buf.download(np.uint64, G * 16 * 16).reshape(G, 16, 16).astype(np.int64)
+    full = buf.download(np.uint64, G * 16 * 32).reshape(G, 16, 32).astype(np.int64)
+    st, st15 = full[:, :, :16], full[:, :, 16:]
+    ck = full[0, 15, 28:32]
+    if ck[3] > ck[1]:
+        print(f"  core clock over the launch: {(ck[2] - ck[0]) / ((ck[3] - ck[1]) / 100.0):.0f} MHz ({(ck[3] - ck[1]) / 100.0:.1f} us)")
     names = ["P1", "gather1", "requant1", "barrier", "P2", "gather2", "requant2", "threshold", "tail"]
     used = st[:, 0, 0] != 0
     print(f"N={N} thr={thr}: {int(used.sum())} workgroups; per-phase mean / max over workgroups, iterations 4..15, in us (wave 0's view)")
     seg = (st[used][:, 4:, 1:10] - st[used][:, 4:, 0:9]) / 100.0
     for k, nm in enumerate(names):
         print(f"  {nm:10s} mean {seg[:, :, k].mean():6.2f}  max {seg[:, :, k].max():6.2f}  min {seg[:, :, k].min():6.2f}")
+    if thr:
+        inner = st[used][:, 4:, :]
+        marks = [("count", 7, 10), ("level0 atomics+barrier", 10, 11), ("level0 scan..level1 barrier", 11, 12), ("level1 scan..level2 barrier", 12, 13),
+                 ("level2 scan..level3 barrier", 13, 14), ("level3 scan", 14, 15), ("cut-offs, ties, apply", 15, 8)]
+        for nm, a, b in marks:
+            dseg = (inner[:, :, b] - inner[:, :, a]) / 100.0
+            print(f"    threshold/{nm:30s} mean {dseg.mean():6.2f}  max {dseg.max():6.2f}")
+    # the global view: the last producer's P-done stamp against every consumer's gather-done stamp (the 100 MHz counter is chip-wide)
+    u = st[used]
+    for nm, a, b in (("exchange 1", 1, 2), ("exchange 2", 5, 6)):
+        lastpub = u[:, 4:, a].max(axis=0)                       # per iteration: when the slowest workgroup finished its row dots
+        firstpub = u[:, 4:, a].min(axis=0)
+        done = u[:, 4:, b]
+        lat = (done - lastpub[None, :]) / 100.0
+        lat15 = (st15[used][:, 4:, b] - lastpub[None, :]) / 100.0
+        print(f"  {nm}: producers' P-done spread {((lastpub - firstpub) / 100.0).mean():5.2f} us; gather done after the LAST P-done: wave 0 "
+              f"mean {lat.mean():5.2f}  min {lat.min():5.2f}  max {lat.max():5.2f}; wave 15 mean {lat15.mean():5.2f}  max {lat15.max():5.2f}")
+    per_it = (u[:, 5:, 0] - u[:, 4:-1, 0]) / 100.0
+    print(f"  iteration period (stamp 0 to stamp 0): mean {per_it.mean():6.2f}  min {per_it.min():6.2f}  max {per_it.max():6.2f}")
     tot = (st[used][:, 15, 9] - st[used][:, 4, 0]) / 100.0 / 12
     print(f"  iteration  mean {tot.mean():6.2f}")
     start = st[used][:, 0, 0]
