@@ -56,19 +56,19 @@ struct IhtpArgs {
 #define IHTP_STAMP(k) do { if (A.dbg && (threadIdx.x == 0 || threadIdx.x == IHTP_THREADS - 1) && it < 16) A.dbg[((size_t)g * 16 + it) * 32 + (threadIdx.x ? 16 : 0) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // ---- who owns which rows ------------------------------------------------------------------------------------------------------------
-// A consumer thread owns ONE WORD of a vector (elements 8 w .. 8 w + 7) and wants its 8 dots with coalesced loads: element e = 8 w + k
-// lives in granule slot (len / 8) * k + w.  A producer wants whole 128-byte lines of its own (16 slots: a line shared between producers
-// is invalidated under the pollers once per producer -- the first version of this kernel, natural row order: 6-9 us per gather at
-// N = 8192; this dealing: 1.5-1.9).  Both hold when a workgroup owns "units": unit u = (a = u >> 3, k = u & 7) = the 16 rows
-// 128 a + 8 j + k, j = 0..15 = slots (len / 8) k + 16 a + j.  A workgroup takes R / 16 consecutive units (R = 16, 32 or 64 rows); they
-// share `a`, so its rows lie in the two 64-row groups 2 a (j < 8) and 2 a + 1: two sets of per-block factors instead of one.
-__device__ __forceinline__ uint32_t unit_row(uint32_t u, uint32_t j) { return 128u * (u >> 3) + 8u * j + (u & 7u); }
-__device__ __forceinline__ uint32_t unit_slot(uint32_t u, uint32_t j, uint32_t len) { return (len >> 3) * (u & 7u) + 16u * (u >> 3) + j; }
+// A consumer thread owns ONE WORD of a vector (elements 8 w .. 8 w + 7) and wants its 8 dots with coalesced 16-byte loads (two granules
+// each): element e = 8 w + k lives in granule slot (len / 4) * (k >> 1) + 2 w + (k & 1).  A producer wants whole 128-byte lines of its
+// own (16 slots: a line shared between producers is invalidated under the pollers once per producer -- the first version of this kernel,
+// natural row order: 6-9 us per gather at N = 8192; this dealing: 1.5-1.9).  Both hold when a workgroup owns "units": unit u =
+// (a = u >> 2, kk = u & 3) = the 16 rows 64 a + 8 j + 2 kk + i, j = 0..7, i = 0..1 = slots (len / 4) kk + 16 a + 2 j + i.  A workgroup
+// takes R / 16 consecutive units (R = 16, 32 or 64 rows); they share `a`: all its rows lie in the 64-row group a.
+__device__ __forceinline__ uint32_t unit_row(uint32_t u, uint32_t l) { return 64u * (u >> 2) + 8u * (l >> 1) + 2u * (u & 3u) + (l & 1u); }
+__device__ __forceinline__ uint32_t unit_slot(uint32_t u, uint32_t l, uint32_t len) { return (len >> 2) * (u & 3u) + 16u * (u >> 2) + l; }
 
 // ---- LDS layout (bytes; every offset a multiple of 16) -----------------------------------------------------------------------------
 // A row of Phi in LDS is re-dealt so that a chain lane reads FOUR consecutive steps with one ds_read_b128: row word wi = 16 t + j
 // (step t, chain j) sits at word (t >> 2) * 64 + j * 4 + (t & 3).  x / t2 use the same dealing; the per-block factors c[b]
-// (b = 2 t + a, a = j >> 3) sit at float (t >> 2) * 8 + a * 4 + (t & 3), once per row-group half.
+// (b = 2 t + a, a = j >> 3) sit at float (t >> 2) * 8 + a * 4 + (t & 3).
 struct IhtpLayout {
     uint32_t TG1, TG2;            // step groups (4 steps = 512 columns) of Phi's / PhiT's rows
     uint32_t offA1, offA2, offXV, offC1, offTV, offC2, offP1, offP2, offHist, offWtot, offSel, offPub, offLut, total;
@@ -83,17 +83,18 @@ __host__ __device__ inline IhtpLayout ihtp_layout(uint32_t m, uint32_t n, uint32
     L.offA1 = o; o += R1 * L.TG1 * 256;
     L.offA2 = o; o += R2 * L.TG2 * 256;
     L.offXV = o; o += L.TG1 * 256;
-    L.offC1 = o; o += 2 * L.TG1 * 32;      // two row-group halves
+    L.offC1 = o; o += L.TG1 * 32;
     L.offTV = o; o += L.TG2 * 256;
-    L.offC2 = o; o += 2 * L.TG2 * 32;
-    L.offP1 = o; o += 2 * L.TG1 * 32;      // f32(sPhi[rg][b] * 1/49), dealt like c
-    L.offP2 = o; o += 2 * L.TG2 * 32;
+    L.offC2 = o; o += L.TG2 * 32;
+    L.offP1 = o; o += L.TG1 * 32;          // f32(sPhi[rg][b] * 1/49), dealt like c
+    L.offP2 = o; o += L.TG2 * 32;
     L.offHist = o; o += 4 * 256 * 4;
     L.offWtot = o; o += 64;
     L.offSel = o; o += 64;                 // the scanning wave's (prefix, need) per radix level
     L.offPub = o; o += 64 * 4;             // this workgroup's dots on their way to the publishing wave
     L.offLut = o; o += 256 * 8;            // byte -> magnitude counts of its two nibbles (9 fields of 7 bits)
-    L.total = o + 1024;                    // the row-dot loop reads (never uses) up to two step groups past an array's end
+    L.total = o;                           // (the row-dot loop reads, never uses, up to two step groups past an array's end: all of them
+                                           //  have other arrays behind them)
     return L;
 }
 
@@ -217,27 +218,31 @@ __device__ __forceinline__ float ihtp_row_dot(const uint32_t *Arow, const uint32
     return y2 + IHTP_DPP_F(y2, 0xB1);
 }
 
-// gather word w's 8 dots: granule {epoch, bits of d[8 w + k]} sits at slot k * stride + w (stride = len / 8): coalesced 8-byte loads,
-// re-polled until every lane of the wave has everything.  A poll round moves the whole vector into every CU (64 KiB at n = 8192: 16 MiB
-// chip-wide), so rounds are not free: the first one is issued `nap0` sleeps after the workgroup's own publication -- about when the
-// slowest producer's lines land -- and a missed one is followed after `nap`.  (Two rounds in flight half a round trip apart, to cut the
-// quantisation of the waiting time, measured SLOWER: 14.0 against 10.8 us per iteration, the polls are the traffic.)
-__device__ __forceinline__ void ihtp_gather8(const u64 *g, uint32_t stride, uint32_t w, uint32_t epoch, bool active, uint32_t nap0, uint32_t nap, float d[8])
+// gather word w's 8 dots: granules {epoch, bits of d[8 w + k]} sit at slots (len / 4) * (k >> 1) + 2 w + (k & 1): four coalesced 16-byte
+// sc1 loads (two granules each) through a buffer descriptor, re-polled until every lane of the wave has everything.  A poll round moves
+// the whole vector into every CU (64 KiB at n = 8192: 16 MiB chip-wide), so rounds are not free: the first one is issued `nap0` sleeps
+// after the workgroup's own publication -- about when the slowest producer's lines land -- and a missed one is followed after `nap`.
+// (Two rounds in flight half a round trip apart, to cut the quantisation of the waiting time, measured SLOWER: 14.0 against 10.8 us per
+// iteration -- the polls are the traffic.)
+__device__ __forceinline__ void ihtp_gather8(const u64 *g, uint32_t len, uint32_t w, uint32_t epoch, bool active, uint32_t nap0, uint32_t nap, float d[8])
 {
-    uint32_t pending = active ? 0xFFu : 0u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(g), 0, (int)(len * 8u), 0x00020000);
+    const uint32_t off = active ? 16u * w : 0u, region = 2u * len;     // bytes: slot 2 w; (len / 4) slots per kk
+    uint32_t pending = active ? 0xFu : 0u;
     uint32_t spins = 0;
     u64 t_start = 0;
     for (uint32_t z = 0; z < nap0; z++) __builtin_amdgcn_s_sleep(1);
     while (true) {
-        u64 v[8];
+        u32x4 v[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (pending & (1u << k)) v[k] = __hip_atomic_load((const gu64 *)g + (size_t)k * stride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int kk = 0; kk < 4; kk++)
+            if (pending & (1u << kk)) v[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + region * kk, 0, /*sc1*/ 16);
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if ((pending & (1u << k)) && (uint32_t)(v[k] >> 32) == epoch) {
-                d[k] = __uint_as_float((uint32_t)v[k]);
-                pending &= ~(1u << k);
+        for (int kk = 0; kk < 4; kk++)
+            if ((pending & (1u << kk)) && v[kk].y == epoch && v[kk].w == epoch) {
+                d[2 * kk] = __uint_as_float(v[kk].x);
+                d[2 * kk + 1] = __uint_as_float(v[kk].z);
+                pending &= ~(1u << kk);
             }
         if (!__any(pending != 0)) break;
         for (uint32_t z = 0; z < nap; z++) __builtin_amdgcn_s_sleep(1);
@@ -398,30 +403,25 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
     const uint32_t m = A.m, n = A.n, T1 = n / 128, T2 = m / 128;
     const uint32_t u1 = g * (A.R1 >> 4), u2 = g * (A.R2 >> 4);           // this workgroup's first unit of Phi's / PhiT's rows
     const bool has1 = u1 < m / 16, has2 = u2 < n / 16;
-    const uint32_t H1 = L.TG1 * 8, H2 = L.TG2 * 8;                       // floats per row-group half of the factor arrays
 
     // ---- once per call: the matrix slices, the per-block factors' constant halves, y, x = 0 ----
     if (has1) ihtp_load_rows(A.Phi, u1, A.R1, T1, L.TG1, A1);
     if (has2) ihtp_load_rows(A.PhiT, u2, A.R2, T2, L.TG2, A2);
     for (uint32_t i = tid0; i < L.TG1 * 64; i += IHTP_THREADS) xv[i] = 0;                      // x.clear(): nibbles 0 ...
-    for (uint32_t i = tid0; i < 2 * H1; i += IHTP_THREADS) { c1[i] = 0.0f; p1[i] = 0.0f; }
-    for (uint32_t i = tid0; i < 2 * H2; i += IHTP_THREADS) { c2[i] = 0.0f; p2[i] = 0.0f; }
+    for (uint32_t i = tid0; i < L.TG1 * 8; i += IHTP_THREADS) { c1[i] = 0.0f; p1[i] = 0.0f; }
+    for (uint32_t i = tid0; i < L.TG2 * 8; i += IHTP_THREADS) { c2[i] = 0.0f; p2[i] = 0.0f; }
     for (uint32_t i = tid0; i < L.TG2 * 64; i += IHTP_THREADS) tv[i] = 0;
     hist[tid0] = 0;
     if (tid0 < 256) lut[tid0] = ihtp_lut_entry(tid0);
     __syncthreads();
     if (has1)
-        for (uint32_t i = tid0; i < 2 * (n / 64); i += IHTP_THREADS) {
-            const uint32_t h = i / (n / 64), b = i - h * (n / 64);
-            const float p = A.sPhi[(size_t)(2 * (u1 >> 3) + h) * (n / 64) + b] * CLV_RCP49;
-            p1[h * H1 + dealt_factor(b)] = p;
-            c1[h * H1 + dealt_factor(b)] = p * 1.0f;                                             // ... scales 1.0
+        for (uint32_t b = tid0; b < n / 64; b += IHTP_THREADS) {
+            const float p = A.sPhi[(size_t)(u1 >> 2) * (n / 64) + b] * CLV_RCP49;
+            p1[dealt_factor(b)] = p;
+            c1[dealt_factor(b)] = p * 1.0f;                                                       // ... scales 1.0
         }
     if (has2)
-        for (uint32_t i = tid0; i < 2 * (m / 64); i += IHTP_THREADS) {
-            const uint32_t h = i / (m / 64), b = i - h * (m / 64);
-            p2[h * H2 + dealt_factor(b)] = A.sPhiT[(size_t)(2 * (u2 >> 3) + h) * (m / 64) + b] * CLV_RCP49;
-        }
+        for (uint32_t b = tid0; b < m / 64; b += IHTP_THREADS) p2[dealt_factor(b)] = A.sPhiT[(size_t)(u2 >> 2) * (m / 64) + b] * CLV_RCP49;
     const bool own_m = tid0 < m / 8;                                     // this thread owns word tid of the m- / n-element vectors
     const uint32_t yw = own_m ? A.y[tid0] : 0u;
     const float ys = own_m ? A.sy[tid0 >> 3] : 1.0f;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         // ---- P1: t1's row dots -> LDS -> one wave publishes this workgroup's lines ----
         if (has1 && tid < 16 * A.R1) {
             const uint32_t lr = tid >> 4;
-            const float dot = ihtp_row_dot(A1 + (size_t)lr * L.TG1 * 64, xv, c1 + ((lr >> 3) & 1u) * H1, T1, tid & 15);
+            const float dot = ihtp_row_dot(A1 + (size_t)lr * L.TG1 * 64, xv, c1, T1, tid & 15);
             if ((tid & 15) == 0) pub[lr] = dot;
         }
         IHTP_STAMP(1);
@@ -452,18 +452,14 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         // ---- E1: all of d1 -> t1 = quantize(d1), t2 = quantize(y - t1) ----
         if ((tid & ~63u) < m / 8) {                                      // wave-uniform: waves that own no word skip the gather
             float d[8];
-            ihtp_gather8(A.g1, m / 8, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
+            ihtp_gather8(A.g1, m, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
             IHTP_STAMP(2);
             if (tid < m / 8) {
                 uint32_t t1w, t2w;
                 float t1s, t2s;
                 ihtp_requant_saa(d, yw, ys, -1.0f, t1w, t1s, t2w, t2s);
                 tv[dealt_word(tid)] = t2w;
-                if ((tid & 7) == 0) {
-                    const uint32_t f = dealt_factor(tid >> 3);
-                    c2[f] = p2[f] * t2s;
-                    c2[H2 + f] = p2[H2 + f] * t2s;
-                }
+                if ((tid & 7) == 0) c2[dealt_factor(tid >> 3)] = p2[dealt_factor(tid >> 3)] * t2s;
                 if (last && g == 0) {
                     A.t1[tid] = t1w;
                     A.t2[tid] = t2w;
@@ -477,7 +473,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         // ---- P2: t3's row dots ----
         if (has2 && tid < 16 * A.R2) {
             const uint32_t lr = tid >> 4;
-            const float dot = ihtp_row_dot(A2 + (size_t)lr * L.TG2 * 64, tv, c2 + ((lr >> 3) & 1u) * H2, T2, tid & 15);
+            const float dot = ihtp_row_dot(A2 + (size_t)lr * L.TG2 * 64, tv, c2, T2, tid & 15);
             if ((tid & 15) == 0) pub[lr] = dot;
         }
         IHTP_STAMP(5);
@@ -490,7 +486,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         float t3s = 1.0f;
         if ((tid & ~63u) < n / 8) {
             float d[8];
-            ihtp_gather8(A.g2, n / 8, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
+            ihtp_gather8(A.g2, n, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
             IHTP_STAMP(6);
             if (tid < n / 8) ihtp_requant_saa(d, xw, xs, A.mu, t3w, t3s, xw, xs);
         }
@@ -500,11 +496,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         IHTP_STAMP(8);
         if (tid < n / 8) {
             xv[dealt_word(tid)] = xw;
-            if ((tid & 7) == 0) {
-                const uint32_t f = dealt_factor(tid >> 3);
-                c1[f] = p1[f] * xs;
-                c1[H1 + f] = p1[H1 + f] * xs;
-            }
+            if ((tid & 7) == 0) c1[dealt_factor(tid >> 3)] = p1[dealt_factor(tid >> 3)] * xs;
             if (last && g == 0) {
                 A.t3[tid] = t3w;
                 A.x[tid] = xw;
@@ -533,25 +525,30 @@ void clv_internal_persist_forget(hipStream_t stream)
         if (e.valid && e.stream == stream && stream != nullptr) e.valid = false;
 }
 
-static int persist_chain(hipStream_t st)
-{
-    int dev = 0;
-    CLV_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return CLV_OK;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-    if (cs != hipStreamCaptureStatusNone) return CLV_OK;                  // inside a capture the graph's own edges order the launches
-    std::lock_guard<std::mutex> lock(g_persist_mutex);
-    auto &e = g_persist_last[dev];
-    if (e.valid && e.stream != st) {
-        if (!e.ev) CLV_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
-        CLV_HIP(hipEventRecord(e.ev, e.stream));
-        CLV_HIP(hipStreamWaitEvent(st, e.ev, 0));
+// the lock is held from the cross-stream wait to the launch: an event recorded for a later launch on another stream must lie BEHIND this one
+struct PersistChain {
+    std::unique_lock<std::mutex> lock;
+    int rc;
+    explicit PersistChain(hipStream_t st) : lock(g_persist_mutex), rc(begin(st)) {}
+    static int begin(hipStream_t st)
+    {
+        int dev = 0;
+        CLV_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) return CLV_OK;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) return CLV_OK;              // inside a capture the graph's own edges order the launches
+        auto &e = g_persist_last[dev];
+        if (e.valid && e.stream != st) {
+            if (!e.ev) CLV_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+            CLV_HIP(hipEventRecord(e.ev, e.stream));
+            CLV_HIP(hipStreamWaitEvent(st, e.ev, 0));
+        }
+        e.valid = true;
+        e.stream = st;
+        return CLV_OK;
     }
-    e.valid = true;
-    e.stream = st;
-    return CLV_OK;
-}
+};
 
 // returns 1 if the persistent kernel was launched, 0 if the problem does not qualify (the caller runs the launch-per-step loop), < 0 on error
 int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n, int8_t *x,
@@ -590,7 +587,6 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
         clv_set_error("clm4_iht: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
         return -1;
     }
-    if (persist_chain(st)) return -1;
     IhtpArgs a;
     a.Phi = (const uint8_t *)Phi; a.sPhi = sPhi; a.PhiT = (const uint8_t *)PhiT; a.sPhiT = sPhiT;
     a.m = (uint32_t)m; a.n = (uint32_t)n; a.x_len = (uint32_t)x_len; a.R1 = R1; a.R2 = R2;
@@ -604,6 +600,8 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     if (const char *e = getenv("CLV_IHT_NAP")) a.nap = (uint32_t)atoi(e);                               // probe only
     a.dbg = nullptr;
     if (const char *e = getenv("CLV_IHT_DEBUG_STAMPS")) a.dbg = (u64 *)strtoull(e, nullptr, 0);      // probe only: a device buffer of grid * 16 * 32 words
+    PersistChain chain(st);
+    if (chain.rc) return -1;
     hipLaunchKernelGGL(k_iht4_persist, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -1,0 +1,169 @@
+"""The persistent, LDS-resident Q_IHT / Q_GD kernel (clover_amd/csrc/iht_persist.hip; reference loop: test/performance/01_measure.h:923-946,
+999-1021) against (1) the oracle's step sequence -- x AND t1, t2, t3 with their scales, bit for bit -- and (2) the launch-per-step loop
+of iht4.hip on the same inputs, at the sizes where its row dealing, partial step groups and workgroup counts change.
+
+clm4_iht picks the persistent kernel by itself when the problem qualifies (rounding disabled, threshold FAST or none, m, n <= 8192);
+CLV_IHT_PERSISTENT=0 (read per call) forces the launch-per-step loop: that is how the two are compared inside one process."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import random_packed
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+
+
+def nibbles(b):
+    hi = (b.astype(np.int8) >> 4).astype(np.int32)
+    lo = ((b << 4).astype(np.int8) >> 4).astype(np.int32)
+    return np.stack([hi, lo], 1).reshape(-1)
+
+
+def pack(q):
+    return (((q[0::2] & 0xF) << 4) | (q[1::2] & 0xF)).astype(np.uint8)
+
+
+class Problem:
+    def __init__(self, hip, oracle, m, n, seed):
+        rng = np.random.default_rng(seed)
+        self.m, self.n = m, n
+        self.qPhi, _ = random_packed(rng, m * n)
+        self.sPhi = rng.uniform(0.5, 2, size=(m // 64) * (n // 64)).astype(np.float32)
+        self.qT, self.sT = oracle.m4_transpose(self.qPhi, self.sPhi, m, n)
+        self.y = random_packed(rng, m)
+        self.d = {k: hip.to_device(v) for k, v in dict(Phi=self.qPhi, sPhi=self.sPhi, PhiT=self.qT, sPhiT=self.sT, y=self.y[0], sy=self.y[1]).items()}
+        sizes = dict(x=n // 2, sx=n // 16, t1=m // 2, st1=m // 16, t2=m // 2, st2=m // 16, t3=n // 2, st3=n // 16)
+        self.bufs = {k: hip.alloc(max(sz, 4)) for k, sz in sizes.items()}
+        self.hip = hip
+
+    def run(self, iters, K, mu, thr, x_len=None, persistent=True, stream=None, sync=True):
+        hip, d, b = self.hip, self.d, self.bufs
+        os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
+        for v in b.values():                                       # the call must write every output itself
+            hip.check(hip.lib.clv_memset(v.ptr, 0x5A, v.nbytes, stream))
+        hip.check(hip.lib.clm4_iht(d["Phi"].ptr, d["sPhi"].ptr, d["PhiT"].ptr, d["sPhiT"].ptr, self.m, self.n, b["x"].ptr, b["sx"].ptr,
+                                   self.n if x_len is None else x_len, d["y"].ptr, d["sy"].ptr, b["t1"].ptr, b["st1"].ptr, b["t2"].ptr, b["st2"].ptr,
+                                   b["t3"].ptr, b["st3"].ptr, iters, K, float(mu), thr, None, stream))
+        if not sync:
+            return None
+        hip.check(hip.lib.clv_stream_sync(stream))
+        return self.outputs()
+
+    def outputs(self):
+        m, n, b = self.m, self.n, self.bufs
+        return {k: b[k].download(np.uint8, sz) for k, sz in dict(x=n // 2, sx=n // 16, t1=m // 2, st1=m // 16, t2=m // 2, st2=m // 16,
+                                                                 t3=n // 2, st3=n // 16).items()}
+
+
+def lowest_index_threshold(oracle, q, s, n, k):
+    """FAST mode's tie rule on the CPU: everything above the K-th magnitude, then the first ties by index"""
+    mags = np.abs(oracle.v4_restore(q, s))[:n]
+    out = nibbles(q).copy()
+    if k < n:
+        tau = np.sort(mags)[::-1][k - 1] if k > 0 else np.inf
+        keep = mags > tau
+        ties = np.flatnonzero(mags == tau)[: max(k - int(keep.sum()), 0)]
+        keep[ties] = True
+        out[:n] *= keep
+    return pack(out)
+
+
+@pytest.mark.parametrize("shape,thr", [((512, 1024), 1), ((384, 640), 1), ((1024, 512), 0)])
+def test_persistent_loop_matches_oracle_loop_all_vectors(hip, oracle, shape, thr):
+    """x, t1, t2, t3 and their scales after the loop = the oracle's step sequence (the launch-per-step test of test_next_rows.py checks x only)"""
+    m, n = shape
+    P = Problem(hip, oracle, m, n, 7 + m + n)
+    iters, K, mu = 5, n // 4, np.float32(0.002)
+    got = P.run(iters, K, mu, thr)
+    x = (np.zeros(n // 2, np.uint8), np.ones(n // 64, np.float32))
+    t1 = t2 = t3 = None
+    for _ in range(iters):
+        t1 = oracle.m4_mvm(P.qPhi, P.sPhi, m, n, *x)
+        t2 = oracle.v4_scale_and_add(*P.y, *t1, -1.0)
+        t3 = oracle.m4_mvm(P.qT, P.sT, n, m, *t2)
+        x = oracle.v4_scale_and_add(*x, *t3, float(mu))
+        if thr:
+            x = (lowest_index_threshold(oracle, x[0], x[1], n, K), x[1])
+    for name, want in (("x", x[0]), ("sx", x[1]), ("t1", t1[0]), ("st1", t1[1]), ("t2", t2[0]), ("st2", t2[1]), ("t3", t3[0]), ("st3", t3[1])):
+        assert same(got[name], want), name
+
+
+# (m, n): one unit per workgroup and fewer workgroups than CUs; cols % 512 != 0 (a partial step group); the largest that fits (two units of
+# PhiT per workgroup); GD's 1.5 : 1 shape; a single row group against 8192 columns and the reverse
+SHAPES = [(128, 128), (256, 512), (384, 640), (640, 384), (2048, 4096), (4096, 8192), (6144, 4096), (128, 8192), (8192, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_persistent_equals_launch_per_step(hip, oracle, shape):
+    m, n = shape
+    P = Problem(hip, oracle, m, n, 100 + m + n)
+    cases = [(1, n, n // 4, 5, 1e-3), (1, n - 37, n // 8 + 3, 3, 0.05), (1, n, 0, 2, 1e-3), (1, n, n, 2, 1e-3), (1, n, 1, 4, 0.05), (0, n, 0, 4, 1e-3)]
+    for thr, x_len, K, iters, mu in cases:
+        a = P.run(iters, K, mu, thr, x_len=x_len, persistent=True)
+        b = P.run(iters, K, mu, thr, x_len=x_len, persistent=False)
+        for name in a:
+            assert same(a[name], b[name]), (name, thr, x_len, K, iters, mu)
+        if K and thr:
+            assert int((nibbles(a["x"])[:x_len] != 0).sum()) <= K
+
+
+def test_persistent_calls_on_two_streams_are_chained(hip, oracle):
+    """two persistent launches at once could each hold part of the chip and wait for the rest for ever: launches on different streams are
+    chained by an event (iht_persist.hip persist_chain).  Two host threads, two streams, alternating calls: every result is the right one."""
+    m, n = 1024, 2048
+    P = [Problem(hip, oracle, m, n, 500 + i) for i in range(2)]
+    want = [p.run(6, n // 4, 1e-3, 1, persistent=False) for p in P]
+    os.environ["CLV_IHT_PERSISTENT"] = "1"
+    streams = []
+    for _ in range(2):
+        s = C.c_void_p()
+        hip.check(hip.lib.clv_stream_create(C.byref(s)))
+        streams.append(s)
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(20):
+                p, d, b = P[i], P[i].d, P[i].bufs
+                hip.check(hip.lib.clm4_iht(d["Phi"].ptr, d["sPhi"].ptr, d["PhiT"].ptr, d["sPhiT"].ptr, m, n, b["x"].ptr, b["sx"].ptr, n, d["y"].ptr,
+                                           d["sy"].ptr, b["t1"].ptr, b["st1"].ptr, b["t2"].ptr, b["st2"].ptr, b["t3"].ptr, b["st3"].ptr, 6, n // 4,
+                                           1e-3, 1, None, streams[i]))
+            hip.check(hip.lib.clv_stream_sync(streams[i]))
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+        assert not t.is_alive(), "a persistent launch did not finish"
+    assert not errors, errors
+    for i in range(2):
+        got = P[i].outputs()
+        for name in got:
+            assert same(got[name], want[i][name]), (i, name)
+    for s in streams:
+        hip.check(hip.lib.clv_stream_destroy(s))
+
+
+def test_persistent_is_the_path_taken(hip, oracle):
+    """guard against a silent fall-back: at N = 8192 the persistent kernel is several times faster per call than the launch-per-step loop's
+    3 launches per iteration; 200 iterations must finish well inside the loop's time"""
+    import time
+    m, n = 4096, 8192
+    P = Problem(hip, oracle, m, n, 9)
+    times = {}
+    for persistent in (True, False):
+        P.run(50, n // 4, 1e-3, 1, persistent=persistent)
+        t0 = time.perf_counter()
+        P.run(200, n // 4, 1e-3, 1, persistent=persistent)
+        times[persistent] = time.perf_counter() - t0
+    assert times[True] < 0.8 * times[False], times
