@@ -40,6 +40,8 @@ __device__ __forceinline__ void dot_hand_over_and_collect(float t, unsigned long
         part[k] = 0.0f;
         if ((int)threadIdx.x + DOT_FAST_THREADS * k < count) need |= 1u << k;
     }
+    uint32_t spins = 0;
+    unsigned long long t_start = 0;
     while (need) {
         unsigned long long v[MAXS];
 #pragma unroll
@@ -51,7 +53,16 @@ __device__ __forceinline__ void dot_hand_over_and_collect(float t, unsigned long
                 part[k] = __uint_as_float((uint32_t)v[k]);
                 need &= ~(1u << k);
             }
-        if (need) __builtin_amdgcn_s_sleep(1);
+        if (need) {
+            __builtin_amdgcn_s_sleep(1);
+            // bounded: HIP does not promise that every other workgroup of the grid has been dispatched when the last one runs (it holds on
+            // this hardware); 4 s on the 100 MHz wall clock without a slot turn a scheduling anomaly into an error instead of a hang
+            if ((++spins & 4095u) == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (!t_start) t_start = now;
+                else if (now - t_start > 400000000ull) __builtin_trap();
+            }
+        }
     }
     float acc2 = 0.0f;
 #pragma unroll

@@ -211,8 +211,8 @@ __device__ __forceinline__ u32x4 saa8_pack(const float v[16], float k, const uin
 }
 
 template <bool NT>
-__global__ __launch_bounds__(256) void k_v8_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
-                                                          const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nq16)
+__global__ __launch_bounds__(256) void k_v8_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *qv,
+                                                          const float *sv, float a, u32x4 *r, float *sr, uint64_t nq16)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq16; i += stride) {
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void k_v8_scale_and_add(const u32x4 *qu, const
 // contiguous KiB per instruction), then the per-block arithmetic ONCE per block with lane = block (phases A, C) and ds_bpermute between
 // that lane and the block's four quarter-block lanes.
 template <bool NT>
-__global__ __launch_bounds__(256) void k_v8_scale_and_add_blk(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
-                                                              const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nblocks)
+__global__ __launch_bounds__(256) void k_v8_scale_and_add_blk(const u32x4 *qu, const float *su, const u32x4 *qv,
+                                                              const float *sv, float a, u32x4 *r, float *sr, uint64_t nblocks)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform chunk index: scalar base addresses
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void k_v8_scale_and_add_blk(const u32x4 *qu, c
 // stochastic: the segment walk of the other vector kernels.  Element e of a block takes draw e>>5, byte e&3 of word (e&31)>>2
 // (CloverVector8.h:1104-1126, 1193-1229): lane c (= 16 elements) reads the four words W[4 (c & 1) ..] of draw c >> 1.
 template <int S>
-__global__ __launch_bounds__(256) void k_v8_scale_and_add_st(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
-                                                             const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nblocks,
+__global__ __launch_bounds__(256) void k_v8_scale_and_add_st(const u32x4 *qu, const float *su, const u32x4 *qv,
+                                                             const float *sv, float a, u32x4 *r, float *sr, uint64_t nblocks,
                                                              uint64_t *state, uint64_t seq, RngTables T)
 {
     typedef StShape<S> Sh;
@@ -667,7 +667,9 @@ extern "C" int clv8_dot(const int8_t *qu, const float *su, const int8_t *qv, con
         return clv_internal_dot_chain(workspace, qpad, out_dev, st);
     }
     const uint64_t nvec = n_pad / 16;
-    const uint64_t want = (nvec + DOT_FAST_THREADS - 1) / DOT_FAST_THREADS, cap = (uint64_t)clv_cu_count() * 4;
+    // the collector reads at most DOT_FAST_THREADS * DOT_MAX_SLOTS_PER_THREAD slots (dot_common.h): the grid never exceeds that, whatever the CU count
+    const uint64_t want = (nvec + DOT_FAST_THREADS - 1) / DOT_FAST_THREADS, cap_cu = (uint64_t)clv_cu_count() * 4,
+                   cap = cap_cu < (uint64_t)DOT_FAST_THREADS * DOT_MAX_SLOTS_PER_THREAD ? cap_cu : (uint64_t)DOT_FAST_THREADS * DOT_MAX_SLOTS_PER_THREAD;
     const int grid = (int)(want < cap ? want : cap);
     void *slots = nullptr;
     int rc = clv_internal_sync_slots(&slots, (uint64_t)grid * 8, st);

@@ -129,6 +129,15 @@ int clv_internal_sync_slots(void **ptr, uint64_t bytes, hipStream_t stream)
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     for (auto &w : g_slots)
         if (w.dev == dev && w.stream == stream) { *ptr = w.ptr; return CLV_OK; }
+    // first use on this stream: an allocation, which a stream capture must not contain (hipMalloc is illegal under a global-mode capture and
+    // the memset would become a graph node that re-zeroes the slots under a running collector on replay)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone) {
+        clv_set_error("this stream is being captured and has not run a single-launch reduction yet: make one ordinary clv4_dot / clv8_dot (FAST) call "
+                      "on it before hipStreamBeginCapture");
+        return CLV_ERR_INVALID;
+    }
     void *p = nullptr;
     CLV_HIP(hipMalloc(&p, CLV_SYNC_SLOT_BYTES));
     if (hipMemsetAsync(p, 0, CLV_SYNC_SLOT_BYTES, stream) != hipSuccess) {       // stream-ordered in front of the first kernel that uses them

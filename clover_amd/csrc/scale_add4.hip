@@ -37,8 +37,8 @@ __device__ __forceinline__ void saa_values(uint32_t wu, uint32_t wv, float su7, 
 #define SAA_U 1
 #endif
 template <bool NT, int U>
-__global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
-                                                          const float *__restrict__ sv, float a, u32x4 *r, float *sr,
+__global__ __launch_bounds__(256) void k_v4_scale_and_add(const u32x4 *qu, const float *su, const u32x4 *qv,
+                                                          const float *sv, float a, u32x4 *r, float *sr,
                                                           uint64_t nquads)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -111,8 +111,8 @@ __device__ __forceinline__ uint32_t quant_pack8_k(const float v[8], float k)    
 }
 
 template <bool NT>
-__global__ __launch_bounds__(256) void k_v4_scale_and_add_blk(const u32x4 *qu, const float *su, const u32x4 *__restrict__ qv,
-                                                              const float *__restrict__ sv, float a, u32x4 *r, float *sr, uint64_t nblocks)
+__global__ __launch_bounds__(256) void k_v4_scale_and_add_blk(const u32x4 *qu, const float *su, const u32x4 *qv,
+                                                              const float *sv, float a, u32x4 *r, float *sr, uint64_t nblocks)
 {
     const int lane = threadIdx.x & 63;
     // the chunk index is wave-uniform: told to the compiler (readfirstlane), so that the chunk's base addresses and the full / ragged
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void k_v4_scale_and_add_blk(const u32x4 *qu, c
 // stochastic variant: same segment walk as k_v4_quantize_st (rng4.hip); the nibbles are unpacked by bit
 // position there, so noise group g of AVX lane j meets element 8j + (g ^ 1) (CloverVector4.h:1236-1243).
 template <int S, bool NT = false>
-__global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu, const float *su, const uint32_t *__restrict__ qv,
-                                                             const float *__restrict__ sv, float a, uint32_t *r, float *sr,
+__global__ __launch_bounds__(256) void k_v4_scale_and_add_st(const uint32_t *qu, const float *su, const uint32_t *qv,
+                                                             const float *sv, float a, uint32_t *r, float *sr,
                                                              uint64_t nblocks, uint64_t *state, uint64_t seq, RngTables T)
 {
     typedef StShape<S> Sh;

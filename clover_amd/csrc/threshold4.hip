@@ -995,7 +995,7 @@ __device__ __forceinline__ unsigned long long thr_ancestors(uint32_t lane)
 
 template <bool IN_LDS>
 __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ vals, uint32_t n, uint32_t k, uint2 *__restrict__ gheap,
-                                                     uint32_t *__restrict__ keep)
+                                                     uint32_t *__restrict__ keep, uint2 *__restrict__ heap_out)
 {
     // heap indices: 32 bits while the heap fits LDS (k <= 20000: (pos + 1) << 5 stays small), 64 when part of it is in global memory
     typedef typename std::conditional<IN_LDS, uint32_t, unsigned long long>::type hidx_t;
@@ -1104,8 +1104,9 @@ __global__ __launch_bounds__(64) void k_thr_ref_walk(const float *__restrict__ v
     __syncthreads();
     // "Only copy the max K elements" (:1966-1969): the indices left in the heap survive
     for (uint32_t i = lane; i < k; i += 64) {
-        const uint32_t idx = ThrHeap::ld<IN_LDS>(h, i).y;
-        atomicOr(&keep[idx >> 5], 1u << (idx & 31));
+        const uint2 e = ThrHeap::ld<IN_LDS>(h, i);
+        atomicOr(&keep[e.y >> 5], 1u << (e.y & 31));
+        if (heap_out) heap_out[i] = e;                                     // threshold_min_heap's caller keeps the heap (CloverVector4.h:1929)
     }
 }
 
@@ -1125,19 +1126,24 @@ __global__ __launch_bounds__(256) void k_thr_ref_apply(uint32_t *__restrict__ q,
     }
 }
 
-extern "C" uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad)
+extern "C" uint64_t clv_threshold_reference_workspace_bytes_k(uint64_t n_pad, uint64_t k)
 {
-    // [|value| per element: 4 n][survivor bitmap: n / 8][heap entries beyond LDS when k > 20000: 8 n] + alignment slack
-    return n_pad * 4 + ((n_pad / 8 + 255) & ~255ull) + n_pad * 8 + 512;
+    // [|value| per element: 4 n][survivor bitmap: n / 8][the heap's entries, ONLY when it does not fit LDS (k > 20000): 8 (k + 1)] + slack
+    const uint64_t kk = k < n_pad ? k : n_pad;
+    return n_pad * 4 + ((n_pad / 8 + 255) & ~255ull) + (kk > THR_LDS_WHOLE_MAX ? (kk + 1) * 8 : 0) + 512;
 }
+extern "C" uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad) { return clv_threshold_reference_workspace_bytes_k(n_pad, n_pad); }   // any k
 
 template <int BITS>
-static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, hipStream_t st)
+static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, hipStream_t st,
+                               uint2 *heap_out = nullptr)
 {
     // the walk steps a 32-bit element index 64 at a time (k_thr_ref_walk): base + 64 must not wrap
     CLV_REQUIRE(n <= 0xFFFFFFFFull - 64, "threshold (reference order): n=%llu, at most 2^32 - 65 elements", (unsigned long long)n);
     if (!workspace) {
-        int rc = clv_internal_workspace(&workspace, clv_threshold_reference_workspace_bytes(n_pad), st);
+        // the library's own scratch is sized for THIS k: the 8-bytes-per-element heap region exists only beyond the LDS heap (ADVICE r5:
+        // a 2^30-element vector used to pin 13 GB of grow-only scratch for any k)
+        int rc = clv_internal_workspace(&workspace, clv_threshold_reference_workspace_bytes_k(n_pad, k), st);
         if (rc) return rc;
     }
     float *vals = (float *)workspace;
@@ -1154,11 +1160,11 @@ static int threshold_reference(uint32_t *q, const float *s, uint64_t n, uint64_t
     } else if (k <= THR_LDS_WHOLE_MAX) {
         const size_t lds = ((size_t)k + 1) * sizeof(uint2);                                  // + the sentinel entry
         if (lds > 64 * 1024) CLV_HIP(hipFuncSetAttribute((const void *)k_thr_ref_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_thr_ref_walk<true>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
+        hipLaunchKernelGGL(k_thr_ref_walk<true>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep, heap_out);
     } else {
         const size_t lds = (size_t)THR_LDS_ENTRIES * sizeof(uint2);                          // the top 14 levels; the rest in the workspace
         CLV_HIP(hipFuncSetAttribute((const void *)k_thr_ref_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_thr_ref_walk<false>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep);
+        hipLaunchKernelGGL(k_thr_ref_walk<false>, dim3(1), dim3(64), lds, st, vals, (uint32_t)n, (uint32_t)k, gheap, keep, heap_out);
     }
     hipLaunchKernelGGL(k_thr_ref_apply<BITS>, grid, dim3(256), 0, st, q, n, keep);
     CLV_LAUNCH_CHECK();
@@ -1174,6 +1180,26 @@ extern "C" int clv4_threshold_mode(int8_t *q, const float *s, uint64_t n, uint64
     CLV_REQUIRE(n < (1ull << 32), "clv4_threshold_mode: vectors of 2^32 or more elements are not supported");
     if (k >= n || n == 0) return CLV_OK;
     return threshold_reference<4>((uint32_t *)q, s, n, n_pad, k, workspace, as_stream(stream));
+}
+
+// threshold_min_heap (CloverVector4.h:1929-1970, CloverVector8.h:1696-1737): the REFERENCE walk, and the K-entry heap as the walk leaves it
+template <int BITS>
+static int threshold_heap(const char *fn, int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *heap_dev, void *workspace, void *stream)
+{
+    CLV_REQUIRE(q && s && heap_dev, "%s: null pointer", fn);
+    CLV_REQUIRE(n_pad % 128 == 0 && n <= n_pad, "%s: n=%llu n_pad=%llu", fn, (unsigned long long)n, (unsigned long long)n_pad);
+    CLV_REQUIRE(n < (1ull << 32), "%s: vectors of 2^32 or more elements are not supported", fn);
+    // the reference's loop copies the first k elements into the heap unconditionally: k > n reads beyond the vector there -- rejected here
+    CLV_REQUIRE(k >= 1 && k <= n, "%s: k=%llu must lie in 1 .. n=%llu", fn, (unsigned long long)k, (unsigned long long)n);
+    return threshold_reference<BITS>((uint32_t *)q, s, n, n_pad, k, workspace, as_stream(stream), (uint2 *)heap_dev);
+}
+extern "C" int clv4_threshold_heap(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *heap_dev, void *workspace, void *stream)
+{
+    return threshold_heap<4>("clv4_threshold_heap", q, s, n, n_pad, k, heap_dev, workspace, stream);
+}
+extern "C" int clv8_threshold_heap(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *heap_dev, void *workspace, void *stream)
+{
+    return threshold_heap<8>("clv8_threshold_heap", q, s, n, n_pad, k, heap_dev, workspace, stream);
 }
 
 // CloverVector8::threshold(K) (CloverVector8.h:1680-1740): same algorithm and tie rule on |q * scale / 127|

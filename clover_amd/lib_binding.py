@@ -82,7 +82,10 @@ SIGNATURES = {
     "clv4_threshold_workspace_bytes": (_u64, [_u64]),
     "clv4_threshold": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     "clv_threshold_reference_workspace_bytes": (_u64, [_u64]),
+    "clv_threshold_reference_workspace_bytes_k": (_u64, [_u64, _u64]),
     "clv4_threshold_mode": (C.c_int, [_vp, _vp, _u64, _u64, _u64, C.c_int, _vp, _vp]),
+    "clv4_threshold_heap": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "clv8_threshold_heap": (C.c_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "clm4_transpose": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "clm4_mvm_f32": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "clm4_iht": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64,

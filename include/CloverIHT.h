@@ -44,12 +44,17 @@ inline void Q_GD(QMatrix &Phi, QMatrix &PhiT, QVector &x, QVector &y, QVector &t
 }
 
 
-/* The 4-bit containers of this directory pair every scaleAndAdd with the mvm before it (CloverMatrix4::mvm_scaleAndAdd:
- * one launch instead of two, identical results), so the same calls -- Q_IHT(Phi, PhiT, x, y, t1, t2, t3, ...) -- pick
- * these overloads. */
+/* The 4-bit containers of this directory run the whole loop in ONE call when rounding is deterministic (CloverMatrix4::iht_loop ->
+ * clm4_iht: a persistent launch with Phi and PhiT resident in LDS for the sizes the reference publishes, 9 us per iteration at
+ * N = 8192), and otherwise pair every scaleAndAdd with the mvm before it (CloverMatrix4::mvm_scaleAndAdd: one launch instead of two);
+ * identical results either way, so the same calls -- Q_IHT(Phi, PhiT, x, y, t1, t2, t3, ...) -- pick these overloads. */
 inline void Q_IHT(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, CloverVector4 &y, CloverVector4 &t1, CloverVector4 &t2,
                   CloverVector4 &t3, const uint64_t iterations, const uint64_t K, const float mu)
 {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+    Phi.iht_loop(PhiT, x, y, t1, t2, t3, iterations, K, mu, true);
+    return;
+#endif
     x.clear();
     for (uint64_t i = 0; i < iterations; i += 1) {
         Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);      /* residual:  t1 = Phi x,  t2 = y - t1   (one launch) */
@@ -61,6 +66,10 @@ inline void Q_IHT(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, Clo
 inline void Q_GD(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, CloverVector4 &y, CloverVector4 &t1, CloverVector4 &t2,
                  CloverVector4 &t3, const uint64_t iterations, const float mu)
 {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+    Phi.iht_loop(PhiT, x, y, t1, t2, t3, iterations, 0, mu, false);
+    return;
+#endif
     x.clear();
     for (uint64_t i = 0; i < iterations; i += 1) {
         Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);

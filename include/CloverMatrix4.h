@@ -228,6 +228,26 @@ public:
         const_cast<CloverVector4 &>(u).scaleAndAdd(t, a, r);
 #endif
     }
+    /* The WHOLE quantized IHT / GD loop of 01_measure.h:923-946, 999-1021 with this matrix as Phi, in one call (clm4_iht): x.clear(), then
+     * `iterations` times t1 = Phi x; t2 = y - t1; t3 = PhiT t2; x += mu t3; [threshold(K)].  One persistent launch with Phi and PhiT in
+     * LDS when the problem qualifies (clover_hip.h), else the launch-per-step loop; same bits as the five method calls.  Deterministic
+     * rounding only (each step of a stochastic loop draws from its own object's generator: CloverIHT.h keeps the calls apart there). */
+    void iht_loop(CloverMatrix4 &PhiT, CloverVector4 &x, const CloverVector4 &y, CloverVector4 &t1, CloverVector4 &t2, CloverVector4 &t3,
+                  uint64_t iterations, uint64_t K, float mu, bool with_threshold)
+    {
+        if (PhiT.getRows() != getCols() || PhiT.getCols() != getRows() || x.size_pad() != getCols() || y.size_pad() != getRows() ||
+            t1.size_pad() != getRows() || t2.size_pad() != getRows() || t3.size_pad() != getCols()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        const int thr = !with_threshold ? 0 : (clover_hip::threshold_mode() == CLV_THRESHOLD_FAST ? 1 : 2);
+        clover_hip::check(clm4_iht(dev_values(), dev_scales(), PhiT.dev_values(), PhiT.dev_scales(), rows, cols, x.dev_values_wo(), x.dev_scales_wo(),
+                                   x.size(), y.dev_values_ro(), y.dev_scales_ro(), t1.dev_values_wo(), t1.dev_scales_wo(), t2.dev_values_wo(),
+                                   t2.dev_scales_wo(), t3.dev_values_wo(), t3.dev_scales_wo(), iterations, K, mu, thr, nullptr, nullptr),
+                          "CloverMatrix4::iht_loop");
+        x.commit();
+        if (iterations) { t1.commit(); t2.commit(); t3.commit(); }
+    }
     /* in place: u = quantize(u + a * (this * x)) */
     void mvm_scaleAndAdd(const CloverVector4 &x, CloverVector4 &u, float a, CloverVector4 &t)
     {

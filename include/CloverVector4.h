@@ -252,6 +252,20 @@ public:
         commit();
     }
     void threshold_parallel(uint64_t k) { threshold(k); }
+    /* threshold with the caller's own heap memory (CloverVector4.h:1929-1970, 1975-2057): ALWAYS the reference's walk, whatever the
+     * exactness switch says -- the caller keeps the heap, so it gets the reference's: min_heap[i] = {|value|, bits, idx} of the K
+     * survivors in the reference's array order.  k <= size().  _parallel: the reference merges per-thread heaps, which keeps the same K
+     * largest but orders the array differently; here it is the sequential method (the device is the parallel implementation). */
+    typedef clover_hip::idx_t idx_t;
+    void threshold_min_heap(idx_t *min_heap, uint64_t k)
+    {
+        if (k == 0 || k > length) { std::cout << "threshold_min_heap: k must lie in 1 .. size(). Exiting ..." << std::endl; exit(1); }
+        clover_hip::threshold_heap_to_host(clv4_threshold_heap, dev_values_rw(), dev_scales_ro(), length, length_pad, min_heap, k,
+                                           "CloverVector4::threshold_min_heap");
+        commit();
+        for (uint64_t i = 0; i < k; i++) min_heap[i].bits.i = getBits(min_heap[i].idx);       /* survivors keep their bits */
+    }
+    void threshold_min_heap_parallel(idx_t *min_heaps, uint64_t k) { threshold_min_heap(min_heaps, k); }
 
     /* ---- device views, used by CloverMatrix4 ------------------------------------------------------ */
     const int8_t *dev_values_ro() const { return reinterpret_cast<const int8_t *>(mem.dev_ro()); }

@@ -226,6 +226,17 @@ public:
         commit();
     }
     void threshold_parallel(uint64_t k) { threshold(k); }
+    /* threshold with the caller's own heap memory (CloverVector8.h:1696-1737, 1742-1824): as CloverVector4::threshold_min_heap */
+    typedef clover_hip::idx_t idx_t;
+    void threshold_min_heap(idx_t *min_heap, uint64_t k)
+    {
+        if (k == 0 || k > length) { std::cout << "threshold_min_heap: k must lie in 1 .. size(). Exiting ..." << std::endl; exit(1); }
+        clover_hip::threshold_heap_to_host(clv8_threshold_heap, dev_values_rw(), dev_scales_ro(), length, length_pad, min_heap, k,
+                                           "CloverVector8::threshold_min_heap");
+        commit();
+        for (uint64_t i = 0; i < k; i++) min_heap[i].bits.i = getBits(min_heap[i].idx);
+    }
+    void threshold_min_heap_parallel(idx_t *min_heaps, uint64_t k) { threshold_min_heap(min_heaps, k); }
 
     /* ---- device views, used by CloverMatrix4 ------------------------------------------------------ */
     const int8_t *dev_values_ro() const { return reinterpret_cast<const int8_t *>(mem.dev_ro()); }

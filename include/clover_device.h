@@ -842,6 +842,39 @@ inline uint64_t *rng_or_null(RandomState &r)
 #endif
 }
 
+/* the reference's heap entry (CloverBase.h:202-211) for threshold_min_heap(idx_t *, k): callers that bring their own heap memory */
+union Restorator {
+    int32_t i;
+    float f;
+};
+typedef struct {
+    float value;
+    Restorator bits;
+    uint64_t idx;
+} idx_t;
+
+/* threshold_min_heap of the 4- and 8-bit vectors: the reference's walk on the device (clvN_threshold_heap) and its heap -- {|value|, index}
+ * per entry, in the reference's array order -- copied into the caller's idx_t array; the caller fills in `bits` from its own values */
+typedef int (*threshold_heap_fn)(int8_t *, const float *, uint64_t, uint64_t, uint64_t, void *, void *, void *);
+inline void threshold_heap_to_host(threshold_heap_fn fn, int8_t *dev_values, const float *dev_scales, uint64_t length, uint64_t length_pad,
+                                   idx_t *min_heap, uint64_t k, const char *what)
+{
+    void *heap_dev = nullptr;
+    check(clv_malloc(&heap_dev, k * 8), what);
+    const int rc = fn(dev_values, dev_scales, length, length_pad, k, heap_dev, nullptr, nullptr);
+    if (rc) { clv_free(heap_dev); check(rc, what); }
+    uint32_t *pairs = static_cast<uint32_t *>(malloc(k * 8));
+    if (!pairs) { std::cout << "We ran out of memory, while allocating thresholding memory. Exiting ..." << std::endl; exit(1); }
+    check(clv_memcpy_d2h(pairs, heap_dev, k * 8, nullptr), what);
+    clv_free(heap_dev);
+    for (uint64_t i = 0; i < k; i++) {
+        memcpy(&min_heap[i].value, &pairs[2 * i], 4);
+        min_heap[i].idx = pairs[2 * i + 1];
+        min_heap[i].bits.i = 0;
+    }
+    free(pairs);
+}
+
 }  // namespace clover_hip
 
 /* CloverRandom::setRandomKeys(__m256i key1, __m256i key2) (CloverRandom.h:90-94), for callers compiled with AVX: the

@@ -39,7 +39,17 @@
  *    buffer per (device, stream): calls on different streams never share scratch and may overlap.  clv4_dot / clv8_dot in CLV_DOT_FAST
  *    mode are ONE launch whose workgroups hand their partials over through 64 KiB of zero-initialised slots, also per (device, stream),
  *    allocated (hipMalloc + a memset on the stream) by the first such call there: make one ordinary call on a stream before capturing
- *    it into a hipGraph (tests/test_graph_capture.py); the kernel leaves the slots zero, so replays need nothing else.
+ *    it into a hipGraph (tests/test_graph_capture.py; a first call under capture returns CLV_ERR_INVALID with that advice); the kernel
+ *    leaves the slots zero, so replays need nothing else.  Two limits of the single-launch form: (a) a captured graph holds the slot
+ *    pointer of the stream it was captured on -- do not replay it on another stream WHILE that stream runs a FAST dot (two kernels
+ *    would share slots); (b) the collecting workgroup (the grid's last) assumes every other workgroup of the grid has been dispatched
+ *    when it runs: true of this hardware's dispatchers, not a guarantee of the HIP model -- its wait is bounded (4 s, then a trap) so
+ *    that an anomaly is an error, not a hang.
+ *  - clm4_iht runs Q_IHT / Q_GD as ONE persistent launch when the problem qualifies (rounding disabled, threshold FAST or none, m and
+ *    n <= 8192 and both matrices fit the chip's LDS): every workgroup of its grid must be resident at once, so (a) two such launches on
+ *    different streams of one device are chained by an event (the second waits for the first; no host blocking), (b) ANOTHER PROCESS
+ *    running such a launch on the same device at the same time is not covered -- the kernel's waits are bounded (4 s, then a trap),
+ *    (c) CLV_IHT_PERSISTENT=0 in the environment (read per call) selects the launch-per-step loop.  Same bits either way.
  */
 #ifndef CLOVER_HIP_H
 #define CLOVER_HIP_H
@@ -243,12 +253,19 @@ int  clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint6
  *                            wavefront with the heap in LDS.  Sequential by definition (which of several equal magnitudes survive
  *                            depends on the whole insertion history): about 0.4 us per heap insert -- N = 8192, K = 1024: 0.85 ms.
  *                            The C++ containers take this mode by default (clover_device.h: the exactness switch); here it is a mode.
- * `workspace` (NULL = library scratch of the stream) needs clv_threshold_reference_workspace_bytes(n_pad) in REFERENCE mode.
+ * `workspace` (NULL = library scratch of the stream, sized for the k of the call) needs clv_threshold_reference_workspace_bytes_k(n_pad, k)
+ * in REFERENCE mode.
  * clm4_iht / clm4_iht_v8 take threshold = 2 for this mode (1 = FAST, 0 = no threshold: Q_GD). */
 #define CLV_THRESHOLD_FAST 0
 #define CLV_THRESHOLD_REFERENCE 1
-uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad);
+uint64_t clv_threshold_reference_workspace_bytes(uint64_t n_pad);                    /* enough for any k */
+uint64_t clv_threshold_reference_workspace_bytes_k(uint64_t n_pad, uint64_t k);      /* for this k: the 8 (k + 1)-byte heap region only when k > 20000 */
 int  clv4_threshold_mode(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, int mode, void *workspace, void *stream);
+/* CloverVector4::threshold_min_heap(idx_t *min_heap, uint64_t k) (CloverVector4.h:1929-1970; CloverVector8.h:1696-1737): the REFERENCE
+ * mode above, and the K-entry heap the reference leaves in the caller's memory: heap_dev[i] = {fp32 |value|, uint32 element index},
+ * i < k (8 k bytes of device memory), entry for entry in the reference's array order after the walk.  1 <= k <= n. */
+int  clv4_threshold_heap(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *heap_dev, void *workspace, void *stream);
+int  clv8_threshold_heap(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *heap_dev, void *workspace, void *stream);
 /* CloverMatrix4::transpose (CloverMatrix4.h:1549-1663; _parallel :2508-2640): qt(j,i) = q(i,j), tile scales
  * transposed.  q is rows x cols, qt is cols x rows.  Exact. */
 int  clm4_transpose(const int8_t *q, const float *s, uint64_t rows, uint64_t cols, int8_t *qt, float *st, void *stream);

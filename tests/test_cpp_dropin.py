@@ -202,6 +202,21 @@ def test_gemm_operand_cache_follows_the_matrix(tmp_path, tracking):
     assert p.returncode == 0 and "gemm_cache ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("explicit", [False, True])
+def test_threshold_min_heap_hands_back_the_reference_heap(tmp_path, explicit):
+    """CloverVector4 / CloverVector8 ::threshold_min_heap(idx_t *, k) (CloverVector4.h:1929-1970): the caller's heap memory receives the
+    reference's heap entry for entry (value, bits, idx) -- compared with the reference's method restated over std::make_heap on the host --
+    and the vector keeps exactly the heap's elements; both container builds"""
+    lib = build_hip_library()
+    exe = tmp_path / "threshold_min_heap"
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-DCLOVER_STOCHASTIC_ROUNDING_DISABLED=1", *(["-DCLOVER_HIP_EXPLICIT_SYNC"] if explicit else []),
+                    f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "threshold_min_heap.cpp"), "-o", str(exe), f"-L{lib.parent}", "-lclover_hip",
+                    f"-Wl,-rpath,{lib.parent}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "threshold_min_heap OK" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
 # ---- explicit residency (-DCLOVER_HIP_EXPLICIT_SYNC, include/clover_device.h): no signal handler, no mprotect -----------------------
 def _build_explicit(tmp_path, explicit: bool):
     lib = build_hip_library()

@@ -40,6 +40,59 @@ static double per_iteration_us(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, V &x, V 
     return us[us.size() / 2];
 }
 
+// the reference's threshold (CloverVector4.h:1929-1970) on ONE host core: std::make_heap over the first k, every later element against the
+// root, min_heapify (CloverBase.h:226-249) -- magnitudes decoded per element as getAbs does.  What the device's REFERENCE mode is up against.
+struct HostHeapItem { float value; uint64_t idx; };
+static bool host_gt(const HostHeapItem &a, const HostHeapItem &b) { return (a.value > b.value) || a.value != a.value; }
+static double host_heap_walk_us(const CloverVector4 &v, uint64_t n, uint64_t k, int reps)
+{
+    std::vector<double> us;
+    std::vector<HostHeapItem> h(k);
+    uint64_t sink = 0;
+    for (int r = 0; r < reps; r++) {
+        const double t0 = now();
+        for (uint64_t i = 0; i < k; i++) { h[i].value = v.getAbs(i); h[i].idx = i; }
+        std::make_heap(h.begin(), h.end(), host_gt);
+        for (uint64_t i = k; i < n; i++) {
+            const float value = v.getAbs(i);
+            if (value > h[0].value) {
+                h[0].value = value;
+                h[0].idx = i;
+                uint32_t pos = 0, smallest = 0;
+                for (;;) {
+                    const uint32_t l = pos * 2 + 1, rr = pos * 2 + 2;
+                    if (l < k && h[l].value < h[smallest].value) smallest = l;
+                    if (rr < k && h[rr].value < h[smallest].value) smallest = rr;
+                    if (smallest == pos) break;
+                    std::swap(h[pos], h[smallest]);
+                    pos = smallest;
+                }
+            }
+        }
+        for (uint64_t i = 0; i < k; i++) sink += h[i].idx;
+        us.push_back((now() - t0) * 1e6);
+    }
+    if (sink == 1) std::printf(" ");
+    std::sort(us.begin(), us.end());
+    return us[us.size() / 2];
+}
+
+// one x.threshold(K) through the headers on a fresh copy of `src`, microseconds (median), incl. waiting for the device
+static double device_threshold_us(const CloverVector4 &src, uint64_t k, int reps)
+{
+    std::vector<double> us;
+    for (int r = 0; r < reps; r++) {
+        CloverVector4 w(src);
+        w.toDevice();
+        const double t0 = now();
+        w.threshold(k);
+        clv_device_sync();
+        us.push_back((now() - t0) * 1e6);
+    }
+    std::sort(us.begin(), us.end());
+    return us[us.size() / 2];
+}
+
 int main()
 {
     int ndev = 0;
@@ -83,13 +136,35 @@ int main()
         gen.push_back((t[1] - t[0]) / 200 * 1e6);
     }
     std::sort(gen.begin(), gen.end());
+    // the same at the reference's own K = 25 % of N (00_test.cpp:702, 750; performance.txt:566)
+    const uint64_t K25 = N / 4;
+    const double fast4_k25 = per_iteration_us(Phi, PhiT, x, y, t1, t2, t3, K25, 100, 300, 5);
+    const double fast8_k25 = per_iteration_us(Phi, PhiT, x8, y8, u1, u2, u3, K25, 100, 300, 5);
+    clover_hip::set_exactness(clover_hip::REFERENCE_BITS);
+    const double ref4_k25 = per_iteration_us(Phi, PhiT, x, y, t1, t2, t3, K25, 4, 12, 3);
+    // threshold alone, REFERENCE order: the device's single-wavefront walk against the same walk on one host core
+    CloverVector32 r32(N);
+    r32.setRandomInteger(10, 11);
+    CloverVector4 xr(N);
+    xr.quantize(r32);
+    (void)xr.getBits(0);
+    const double dev_thr[2] = {device_threshold_us(xr, K, 9), device_threshold_us(xr, K25, 9)};
+    const double host_thr[2] = {host_heap_walk_us(xr, N, K, 21), host_heap_walk_us(xr, N, K25, 21)};
+    clover_hip::set_exactness(clover_hip::FAST);
+    const double dev_thr_fast[2] = {device_threshold_us(xr, K, 9), device_threshold_us(xr, K25, 9)};
 #ifdef CLOVER_HIP_EXPLICIT_SYNC
     const char *build = "explicit residency (-DCLOVER_HIP_EXPLICIT_SYNC)";
 #else
     const char *build = "page-tracked mirrors (default)";
 #endif
     std::printf("{\"build\": \"%s\", \"N\": %llu, \"M\": %llu, \"K\": %llu, "
-                "\"us_per_iteration\": {\"fast\": %.2f, \"fast_v8\": %.2f, \"fast_generic_five_calls\": %.2f, \"reference_bits\": %.1f, \"reference_bits_v8\": %.1f}}\n",
-                build, (unsigned long long)N, (unsigned long long)M, (unsigned long long)K, fast4, fast8, gen[2], ref4, ref8);
+                "\"us_per_iteration\": {\"fast\": %.2f, \"fast_v8\": %.2f, \"fast_generic_five_calls\": %.2f, \"reference_bits\": %.1f, \"reference_bits_v8\": %.1f}, "
+                "\"us_per_iteration_K2048_reference_ratio\": {\"fast\": %.2f, \"fast_v8\": %.2f, \"reference_bits\": %.1f}, "
+                "\"threshold_alone_us\": {\"K1024\": {\"device_reference_walk\": %.1f, \"one_host_core_same_walk\": %.1f, \"device_fast\": %.1f}, "
+                "\"K2048\": {\"device_reference_walk\": %.1f, \"one_host_core_same_walk\": %.1f, \"device_fast\": %.1f}, "
+                "\"note\": \"x.threshold(K) through the headers incl. the wait for the device, against the reference's heap walk (std::make_heap + "
+                "min_heapify over getAbs) on one host core; the walk is sequential by definition: REFERENCE mode buys the reference's survivor set, not speed\"}}\n",
+                build, (unsigned long long)N, (unsigned long long)M, (unsigned long long)K, fast4, fast8, gen[2], ref4, ref8, fast4_k25, fast8_k25, ref4_k25,
+                dev_thr[0], host_thr[0], dev_thr_fast[0], dev_thr[1], host_thr[1], dev_thr_fast[1]);
     return 0;
 }
