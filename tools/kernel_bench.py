@@ -102,6 +102,10 @@ rngm = hip.new_rng(3, 4)
 rec("matrix_quantize_32768^2", 4.5625 * M * N, lambda: hip.check(lib.clm4_quantize(A.ptr, M, N, qA.ptr, sA.ptr, None, None)), reps=3)
 rec("matrix_quantize_stochastic_32768^2", 4.5625 * M * N, lambda: hip.check(lib.clm4_quantize(A.ptr, M, N, qT.ptr, sT.ptr, rngm.ptr, None)), reps=3)
 rec("transpose_32768^2", 2 * (M * N // 2 + 4 * (M // 64) * (N // 64)), lambda: hip.check(lib.clm4_transpose(qA.ptr, sA.ptr, M, N, qT.ptr, sT.ptr, None)), reps=3)
+# shapes whose rows / cols are 128 * odd: edge tiles are masked on the same kernel (r6; the 64-thread kernel they used to fall to is gone)
+for (Mr, Nr) in ((32640, 32640), (32768, 32640), (32640, 32768)):
+    rec(f"transpose_{Mr}x{Nr}", 2 * (Mr * Nr // 2 + 4 * (Mr // 64) * (Nr // 64)),
+        lambda Mr=Mr, Nr=Nr: hip.check(lib.clm4_transpose(qA.ptr, sA.ptr, Mr, Nr, qT.ptr, sT.ptr, None)), reps=3)
 x, sx = hip.alloc(N // 2), hip.alloc(N // 16)
 r, sr = hip.alloc(M // 2), hip.alloc(M // 16)
 hip.check(lib.clv_fill_random_nibbles(x.ptr, x.nbytes, 9, 0, None))
