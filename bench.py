@@ -1437,24 +1437,24 @@ def extras(hip, torch, dev, stream) -> dict:
     side = C.c_void_p()
     hip.check(lib.clv_stream_create(C.byref(side)))
 
-    def iht_call(K=m // 4, iters=100):
+    def iht_call(K=m // 4, iters=100, rs=None):
         hip.check(lib.clm4_iht(Phi.data_ptr(), sPhi.data_ptr(), PhiT.data_ptr(), sPhiT.data_ptr(), m, nn, xq.data_ptr(), xs_.data_ptr(), nn,
                                yq.data_ptr(), ys_.data_ptr(), t1q.data_ptr(), t1s.data_ptr(), t2q.data_ptr(), t2s.data_ptr(),
-                               t3q.data_ptr(), t3s.data_ptr(), iters, K, 1e-3, 1, None, side))
+                               t3q.data_ptr(), t3s.data_ptr(), iters, K, 1e-3, 1, rs, side))
         hip.check(lib.clv_stream_sync(side))
 
-    def iht_time(K, persistent):
+    def iht_time(K, persistent, rs=None):
         # per-iteration time of ONE call with many iterations, by difference of two call lengths (the per-call cost -- a memset, the
         # launch, the matrix slices' way into LDS -- drops out); CLV_IHT_PERSISTENT is read per call (iht_persist.hip)
         os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
         try:
-            iht_call(K, 100)
+            iht_call(K, 100, rs)
             best = {}
             for iters in (100, 1100):
                 best[iters] = 1e9
                 for _ in range(3):
                     t0 = time.perf_counter()
-                    iht_call(K, iters)
+                    iht_call(K, iters, rs)
                     best[iters] = min(best[iters], time.perf_counter() - t0)
             return (best[1100] - best[100]) / 1000 * 1e3, best[100] * 1e3
         finally:
@@ -1463,6 +1463,8 @@ def extras(hip, torch, dev, stream) -> dict:
     g25_ms, _ = iht_time(nn // 4, True)                                  # K = 25 % of N = 2048: the reference's table (00_test.cpp:702, 750)
     gl_ms, gl_call100_ms = iht_time(m // 4, False)                       # the launch-per-step loop (iht4.hip): three launches per iteration
     gl25_ms, _ = iht_time(nn // 4, False)
+    gst_ms, _ = iht_time(nn // 4, True, rng_state.ptr)                   # every re-quantisation drawing from one XORShift stream, same kernel
+    glst_ms, _ = iht_time(nn // 4, False, rng_state.ptr)
     hip.check(lib.clv_stream_destroy(side))
     # the reference's published "4-bit" IHT: CloverMatrix4 with CloverVector8 vectors (02_bit04.cpp:140), whole loop from C++
     def vec8(n_, sd):
@@ -1493,8 +1495,9 @@ def extras(hip, torch, dev, stream) -> dict:
            "ms_per_iteration_clm4_iht": round(g_ms, 5), "GB/s_clm4_iht": round(iht_bytes / g_ms / 1e6, 1),
            "clm4_iht": {"path": "one persistent launch, Phi and PhiT resident in LDS (iht_persist.hip)",
                         "us_per_iteration_K1024": round(g_ms * 1e3, 2), "us_per_iteration_K2048_reference_ratio": round(g25_ms * 1e3, 2),
-                        "ms_per_call_100_iterations": round(g_call100_ms, 4),
+                        "ms_per_call_100_iterations": round(g_call100_ms, 4), "us_per_iteration_stochastic_K2048": round(gst_ms * 1e3, 2),
                         "launch_per_step_loop": {"us_per_iteration_K1024": round(gl_ms * 1e3, 2), "us_per_iteration_K2048": round(gl25_ms * 1e3, 2),
+                                                 "us_per_iteration_stochastic_K2048": round(glst_ms * 1e3, 2),
                                                  "ms_per_call_100_iterations": round(gl_call100_ms, 4)},
                         "method": "difference of a 1100- and a 100-iteration call, best of 3 each"},
            "ms_per_iteration_clm4_iht_v8": round(g8_ms, 5), "GB/s_clm4_iht_v8": round(iht8_bytes / g8_ms / 1e6, 1),

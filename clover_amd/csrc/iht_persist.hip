@@ -17,16 +17,17 @@
 // Bit-exact with the launch-per-step loop: same chains, same tree, same re-quantisation arithmetic (matrix4.hip's epilogue).
 // Residency: the grid is <= the CU count and a workgroup takes more than half a CU's LDS or 1024 threads... the host checks the occupancy
 // query before launching; every spin is bounded (a trap after 4 s turns a scheduling anomaly into an error, not a hang).
-#include "common.h"
+#include "rng_device.h"
 #include "thresh_device.h"
 
 #include <mutex>
 #include <stdlib.h>
+#include <string.h>
 
 #define IHTP_THREADS 1024
 #define IHTP_MAXLEN 8192u          // vectors up to 8192 elements: one 32-bit word (8 elements) per thread
 
-typedef unsigned long long u64;
+typedef uint64_t u64;
 typedef __attribute__((address_space(1))) u64 gu64;          // granules are touched through GLOBAL agent-scope accesses only, never flat ones
 
 struct IhtpArgs {
@@ -50,6 +51,12 @@ struct IhtpArgs {
     float mu;
     int threshold;                // 0: Q_GD, 1: Q_IHT with the FAST threshold
     u64 *g1, *g2;                 // granules: m and n of them, zero before the launch
+    // stochastic rounding (k_iht4_persist<true>): the XORShift state (rng_device.h), this launch's sequence number, T^(16 e) in row form,
+    // and the per-iteration jumps T^(D - 16), T^(D - 17) in column form (D = draws per iteration = 4 (m + n) / 64)
+    u64 *rng;
+    u64 seq;
+    const u64 *seg_rows;
+    u64 jump[64], jump1[64];
     uint32_t nap0, nap;           // s_sleep(1) units before the first poll round of a gather / between two rounds
     u64 *dbg;                     // NULL, or 16 wall-clock stamps (100 MHz) per iteration and workgroup for tools/iht_persist_probe.py
 };
@@ -71,10 +78,10 @@ __device__ __forceinline__ uint32_t unit_slot(uint32_t u, uint32_t l, uint32_t l
 // (b = 2 t + a, a = j >> 3) sit at float (t >> 2) * 8 + a * 4 + (t & 3).
 struct IhtpLayout {
     uint32_t TG1, TG2;            // step groups (4 steps = 512 columns) of Phi's / PhiT's rows
-    uint32_t offA1, offA2, offXV, offC1, offTV, offC2, offP1, offP2, offHist, offWtot, offSel, offPub, offLut, total;
+    uint32_t offA1, offA2, offXV, offC1, offTV, offC2, offP1, offP2, offHist, offWtot, offSel, offPub, offLut, offRaw, total;
 };
 
-__host__ __device__ inline IhtpLayout ihtp_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2)
+__host__ __device__ inline IhtpLayout ihtp_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2, bool st)
 {
     IhtpLayout L;
     L.TG1 = (n / 128 + 3) / 4;
@@ -93,6 +100,10 @@ __host__ __device__ inline IhtpLayout ihtp_layout(uint32_t m, uint32_t n, uint32
     L.offSel = o; o += 64;                 // the scanning wave's (prefix, need) per radix level
     L.offPub = o; o += 64 * 4;             // this workgroup's dots on their way to the publishing wave
     L.offLut = o; o += 256 * 8;            // byte -> magnitude counts of its two nibbles (9 fields of 7 bits)
+    // stochastic: the raw draws of one vector phase (4 per block: 2 for the mvm's re-quantisation, 2 for the scaleAndAdd), generated in
+    // segments of 16 draws; the two phases of an iteration use the buffer one after the other
+    const uint32_t gmax = (m > n ? m : n) / 64;
+    L.offRaw = o; o += st ? ((gmax + 3) / 4) * 16 * 32 : 0;
     L.total = o;                           // (the row-dot loop reads, never uses, up to two step groups past an array's end: all of them
                                            //  have other arrays behind them)
     return L;
@@ -106,6 +117,16 @@ __device__ __forceinline__ float group8_max(float v)
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));       // quad_perm [1,0,3,2]
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));       // quad_perm [2,3,0,1]
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));   // row_half_mirror
+}
+// the same for the 64-bit magnitude tables: a 7-bit field straddles bit 32, so the halves must be added WITH their carry
+__device__ __forceinline__ u64 group8_add64(u64 v)
+{
+#define IHTP_DPP64(x, ctrl) (((u64)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((x) >> 32), ctrl, 0xF, 0xF, false) << 32) | \
+                             (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x), ctrl, 0xF, 0xF, false))
+    v += IHTP_DPP64(v, 0xB1);
+    v += IHTP_DPP64(v, 0x4E);
+    return v + IHTP_DPP64(v, 0x141);
+#undef IHTP_DPP64
 }
 __device__ __forceinline__ uint32_t group8_add(uint32_t v)
 {
@@ -254,26 +275,39 @@ __device__ __forceinline__ void ihtp_gather8(const u64 *g, uint32_t len, uint32_
     }
 }
 
-// quantise 8 values with the block factor k (rounding disabled: noise 0) -> one word
-__device__ __forceinline__ uint32_t ihtp_quant8(const float v[8], float k, int q[8])
-{
-#pragma unroll
-    for (int e = 0; e < 8; e++) q[e] = quant1(v[e], k, 0.0f);
-    return pack8_perm(q);
-}
-
 // One vector step after a gather, for the thread that owns word w of the vectors (8 lanes = one 64-element block):
 //   r = quantize(d)                                (the mvm's re-quantisation, CloverMatrix4.h:919-1080)
 //   o = quantize(u + a * r)                        (scaleAndAdd, CloverVector4.h:1196-1478; the arithmetic of matrix4.hip's fused epilogue)
-// returns r's word / scale and o's word / scale
-__device__ __forceinline__ void ihtp_requant_saa(const float d[8], uint32_t uw, float us, float a, uint32_t &rw, float &rs, uint32_t &ow, float &os)
+// returns r's word / scale and o's word / scale.  ST: W[0..1] = this word's dword of the block's two mvm draws, W[2..3] = of its two
+// scaleAndAdd draws: element e = 8 i + e' of the block takes group e' of lane i -- draw e' >> 2, byte e' & 3 -- in the mvm (lane map
+// 8 j + g, CloverMatrix4.h:925-932) and group e' ^ 1 in scaleAndAdd (8 j + (g ^ 1), CloverVector4.h:1236-1243).
+template <bool ST>
+__device__ __forceinline__ void ihtp_requant_saa(const float d[8], uint32_t uw, float us, float a, const uint32_t W[4], uint32_t &rw, float &rs,
+                                                 uint32_t &ow, float &os)
 {
+    float nm[8], ns[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) nm[e] = ns[e] = 0.0f;
+    if (ST) {
+        float t[4];
+        noise4_of(W[0], nm);
+        noise4_of(W[1], nm + 4);
+        noise4_of(W[2], t);
+        ns[0] = t[1]; ns[1] = t[0]; ns[2] = t[3]; ns[3] = t[2];
+        noise4_of(W[3], t);
+        ns[4] = t[1]; ns[5] = t[0]; ns[6] = t[3]; ns[7] = t[2];
+    }
     float mx = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; e++) mx = fmaxf(mx, __builtin_fabsf(d[e]));
     rs = fix_zero_max(group8_max(mx));
     int q[8];
-    rw = ihtp_quant8(d, 7.0f / rs, q);
+    {
+        const float k = 7.0f / rs;
+#pragma unroll
+        for (int e = 0; e < 8; e++) q[e] = quant1(d[e], k, nm[e]);
+        rw = pack8_perm(q);
+    }
     const float su7 = div7(us), sv7 = div7(rs * a);
     float val[8];
     float m2 = 0.0f;
@@ -284,7 +318,44 @@ __device__ __forceinline__ void ihtp_requant_saa(const float d[8], uint32_t uw, 
     }
     os = fix_zero_max(group8_max(m2));
     int q2[8];
-    ow = ihtp_quant8(val, 7.0f / os, q2);
+    {
+        const float k = 7.0f / os;
+#pragma unroll
+        for (int e = 0; e < 8; e++) q2[e] = quant1(val[e], k, ns[e]);
+        ow = pack8_perm(q2);
+    }
+}
+
+// ---- stochastic rounding: the generator lanes ----
+// v -> M v for a matrix in ROW form in global memory (bit j of the result = parity of row j & v): the one-off jump to a segment start
+__device__ __forceinline__ u64 ihtp_rows_matvec(const u64 *__restrict__ rows, u64 v)
+{
+    u64 r = 0;
+    for (int j = 0; j < 64; j++) r |= (u64)(__builtin_popcountll(rows[j] & v) & 1) << j;
+    return r;
+}
+// v -> M v for a matrix in COLUMN form held in the kernel arguments (scalar loads): the per-iteration jump, 3 VALU per column
+__device__ __forceinline__ u64 ihtp_cols_matvec(const u64 (&cols)[64], u64 v)
+{
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 16
+    for (int i = 0; i < 64; i++) {
+        const uint32_t mask = 0u - (uint32_t)((v >> i) & 1ull);
+        lo ^= mask & (uint32_t)cols[i];
+        hi ^= mask & (uint32_t)(cols[i] >> 32);
+    }
+    return ((u64)hi << 32) | lo;
+}
+// 16 draws of generator lane k from state a: raw[(16 seg + s) * 4 + k] = the 64-bit output (dwords W[2k], W[2k+1] of draw 16 seg + s)
+__device__ __forceinline__ u64 ihtp_gen16(u64 a, u64 *raw, uint32_t seg, uint32_t k)
+{
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_++) {
+        const u64 n = xs_T(a);
+        raw[(16 * seg + s_) * 4 + k] = n + a;
+        a = n;
+    }
+    return a;
 }
 
 // byte -> the magnitude counts of its two nibbles, th4_count_word's field layout (9 fields of 7 bits)
@@ -316,13 +387,12 @@ __device__ __forceinline__ uint32_t ihtp_threshold(uint32_t w, float s, uint32_t
     const uint32_t key0 = cand_key(s7, i), key1 = cand_key(s7, 8);
     uint32_t tau = 0x7F800000u, keep = 0;
     if (k != 0) {
-        // magnitude counts of the block: 9 fields of 7 bits summed over the block's 8 lanes (two 32-bit halves; no carries between fields:
-        // a field is at most 64 only when it is the only non-zero one -- 7 bits hold 64)
+        // magnitude counts of the block: 9 fields of 7 bits summed over the block's 8 lanes (no carries between fields: a field is at
+        // most 64, and 7 bits hold 64; the field of magnitude 4 straddles bit 32: a true 64-bit addition)
         u64 cw;
         if (valid == 8) cw = (lut[w & 0xFFu] + lut[(w >> 8) & 0xFFu]) + (lut[(w >> 16) & 0xFFu] + lut[w >> 24]);
         else cw = th4_count_word(w, valid);
-        const uint32_t lo = group8_add((uint32_t)cw), hi = group8_add((uint32_t)(cw >> 32));
-        const u64 cnt = ((u64)hi << 32) | lo;
+        const u64 cnt = group8_add64(cw);
         const uint32_t wgt0 = (uint32_t)(cnt >> (7 * i)) & 0x7Fu;
         const uint32_t wgt1 = i == 0 ? (uint32_t)(cnt >> 56) & 0x7Fu : 0u;
         uint32_t prefix = 0, need = k;
@@ -386,10 +456,11 @@ __device__ __forceinline__ uint32_t ihtp_threshold(uint32_t w, float s, uint32_t
     return w & swap_nibbles(full);
 }
 
+template <bool ST>
 __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const IhtpLayout L = ihtp_layout(A.m, A.n, A.R1, A.R2);
+    const IhtpLayout L = ihtp_layout(A.m, A.n, A.R1, A.R2, ST);
     uint32_t *A1 = reinterpret_cast<uint32_t *>(smem + L.offA1), *A2 = reinterpret_cast<uint32_t *>(smem + L.offA2);
     uint32_t *xv = reinterpret_cast<uint32_t *>(smem + L.offXV), *tv = reinterpret_cast<uint32_t *>(smem + L.offTV);
     float *c1 = reinterpret_cast<float *>(smem + L.offC1), *c2 = reinterpret_cast<float *>(smem + L.offC2);
@@ -398,6 +469,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
     uint32_t *sel = reinterpret_cast<uint32_t *>(smem + L.offSel);
     float *pub = reinterpret_cast<float *>(smem + L.offPub);
     u64 *lut = reinterpret_cast<u64 *>(smem + L.offLut);
+    u64 *raw = reinterpret_cast<u64 *>(smem + L.offRaw);
 
     const uint32_t tid0 = threadIdx.x, g = blockIdx.x;
     const uint32_t m = A.m, n = A.n, T1 = n / 128, T2 = m / 128;
@@ -427,6 +499,21 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
     const float ys = own_m ? A.sy[tid0 >> 3] : 1.0f;
     uint32_t xw = 0;
     float xs = 1.0f;
+    // stochastic: the LAST 4 * segs1 (segs2) threads are the generator lanes of the first (second) vector phase: thread -> (generator lane
+    // k, segment of 16 draws).  They start at T^(position)(a0[k]) and advance by the iteration's D draws with one matrix product each
+    const uint32_t G1 = m / 64, G2 = n / 64, segs1 = (G1 + 3) / 4, segs2 = (G2 + 3) / 4;
+    const int gi1 = ST ? (int)tid0 - (int)(IHTP_THREADS - 4 * segs1) : -1, gi2 = ST ? (int)tid0 - (int)(IHTP_THREADS - 4 * segs2) : -1;
+    u64 ga = 0, gb = 0;
+    int rng_slot = 0;
+    if (ST) {
+        const u64 seq = rng_effective_seq(A.rng, A.seq);
+        rng_slot = rng_read_slot(A.rng, seq);
+        if (gi1 >= 0) ga = ihtp_rows_matvec(A.seg_rows + (size_t)(gi1 >> 2) * 64, A.rng[rng_slot * RNG_SLOT_WORDS + 4 + (gi1 & 3)]);
+        if (gi2 >= 0) {
+            gb = ihtp_rows_matvec(A.seg_rows + (size_t)((gi2 >> 2) + ((4 * G1) >> 4)) * 64, A.rng[rng_slot * RNG_SLOT_WORDS + 4 + (gi2 & 3)]);
+            for (uint32_t z = 0; z < ((4 * G1) & 15u); z++) gb = xs_T(gb);      // m = 128 (mod 256): the phase starts half a segment in
+        }
+    }
     __syncthreads();
 
     if (A.dbg && tid0 == 0) { A.dbg[((size_t)g * 16 + 15) * 32 + 28] = __builtin_readcyclecounter(); A.dbg[((size_t)g * 16 + 15) * 32 + 29] = __builtin_amdgcn_s_memrealtime(); }
@@ -444,6 +531,16 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
             const float dot = ihtp_row_dot(A1 + (size_t)lr * L.TG1 * 64, xv, c1, T1, tid & 15);
             if ((tid & 15) == 0) pub[lr] = dot;
         }
+        if (ST && gi1 >= 0) {                                            // the first phase's draws, beside the row dots of other waves
+            ga = ihtp_gen16(ga, raw, (uint32_t)gi1 >> 2, (uint32_t)gi1 & 3u);
+            if (last && g == 0 && gi1 < 4) {                             // the state the launch leaves behind: part1 = T^(total - 1), part2 = T^total
+                u64 *next = A.rng + (rng_slot ^ 1) * RNG_SLOT_WORDS;
+                const u64 f = ihtp_cols_matvec(A.jump1, ga);
+                next[gi1] = f;
+                next[4 + gi1] = xs_T(f);
+            }
+            ga = ihtp_cols_matvec(A.jump, ga);
+        }
         IHTP_STAMP(1);
         __syncthreads();
         if (has1 && tid < A.R1)
@@ -455,9 +552,13 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
             ihtp_gather8(A.g1, m, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
             IHTP_STAMP(2);
             if (tid < m / 8) {
-                uint32_t t1w, t2w;
+                uint32_t t1w, t2w, W[4] = {0u, 0u, 0u, 0u};
                 float t1s, t2s;
-                ihtp_requant_saa(d, yw, ys, -1.0f, t1w, t1s, t2w, t2s);
+                if (ST) {
+                    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(raw) + (tid & 7u), b = tid >> 3;
+                    W[0] = r32[(2 * b) * 8]; W[1] = r32[(2 * b + 1) * 8]; W[2] = r32[(2 * G1 + 2 * b) * 8]; W[3] = r32[(2 * G1 + 2 * b + 1) * 8];
+                }
+                ihtp_requant_saa<ST>(d, yw, ys, -1.0f, W, t1w, t1s, t2w, t2s);
                 tv[dealt_word(tid)] = t2w;
                 if ((tid & 7) == 0) c2[dealt_factor(tid >> 3)] = p2[dealt_factor(tid >> 3)] * t2s;
                 if (last && g == 0) {
@@ -476,6 +577,10 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
             const float dot = ihtp_row_dot(A2 + (size_t)lr * L.TG2 * 64, tv, c2, T2, tid & 15);
             if ((tid & 15) == 0) pub[lr] = dot;
         }
+        if (ST && gi2 >= 0) {                                            // the second phase's draws (the first phase's have been used)
+            gb = ihtp_gen16(gb, raw, (uint32_t)gi2 >> 2, (uint32_t)gi2 & 3u);
+            gb = ihtp_cols_matvec(A.jump, gb);
+        }
         IHTP_STAMP(5);
         __syncthreads();
         if (has2 && tid < A.R2)
@@ -488,7 +593,14 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
             float d[8];
             ihtp_gather8(A.g2, n, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
             IHTP_STAMP(6);
-            if (tid < n / 8) ihtp_requant_saa(d, xw, xs, A.mu, t3w, t3s, xw, xs);
+            if (tid < n / 8) {
+                uint32_t W[4] = {0u, 0u, 0u, 0u};
+                if (ST) {
+                    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(raw) + (tid & 7u), b = tid >> 3;
+                    W[0] = r32[(2 * b) * 8]; W[1] = r32[(2 * b + 1) * 8]; W[2] = r32[(2 * G2 + 2 * b) * 8]; W[3] = r32[(2 * G2 + 2 * b + 1) * 8];
+                }
+                ihtp_requant_saa<ST>(d, xw, xs, A.mu, W, t3w, t3s, xw, xs);
+            }
         }
         IHTP_STAMP(7);
         if (A.threshold && A.K < A.x_len) xw = ihtp_threshold(xw, xs, tid, A.x_len, A.K, hist, wtot, sel, lut,
@@ -507,6 +619,13 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
         IHTP_STAMP(9);
     }
     if (A.dbg && tid0 == 0) { A.dbg[((size_t)g * 16 + 15) * 32 + 30] = __builtin_readcyclecounter(); A.dbg[((size_t)g * 16 + 15) * 32 + 31] = __builtin_amdgcn_s_memrealtime(); }
+    if (ST && g == 0) {                                                  // stamp the slot written in the last iteration (rng_device.h: rng_commit)
+        __syncthreads();
+        if (tid0 == IHTP_THREADS - 4 * segs1) {
+            __threadfence();
+            A.rng[(rng_slot ^ 1) * RNG_SLOT_WORDS + RNG_STAMP_WORD] = rng_effective_seq(A.rng, A.seq);
+        }
+    }
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------------
@@ -556,7 +675,8 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
                         float *st3, uint64_t iterations, uint64_t K, float mu, int threshold, uint64_t *rng, hipStream_t st)
 {
     const int mode = [] { const char *e = getenv("CLV_IHT_PERSISTENT"); return e ? atoi(e) : 1; }();      // read per call: A/B runs flip it
-    if (!mode || rng || threshold < 0 || threshold > 1 || !iterations || iterations >= 0x7FFFFFFFull) return 0;
+    if (!mode || threshold < 0 || threshold > 1 || !iterations || iterations >= 0x7FFFFFFFull) return 0;
+    if (rng && (m + n) / 64 * 4 < 32) return 0;                             // stochastic: the per-iteration jumps T^(D - 16), T^(D - 17) want D >= 32
     if (m > IHTP_MAXLEN || n > IHTP_MAXLEN || m % 128 || n % 128 || !m || !n) return 0;
     const int cus = clv_cu_count();
     // rows per workgroup: 16 (one unit = one 128-byte line of granules), 32 or 64
@@ -564,7 +684,7 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     if (R1 < 16) R1 = 16;
     if (R2 < 16) R2 = 16;
     if (R1 > 64 || R2 > 64) return 0;
-    const IhtpLayout L = ihtp_layout((uint32_t)m, (uint32_t)n, R1, R2);
+    const IhtpLayout L = ihtp_layout((uint32_t)m, (uint32_t)n, R1, R2, rng != nullptr);
     if (L.total > 160u * 1024u) return 0;
     const uint32_t grid = (uint32_t)((m / R1 > n / R2) ? m / R1 : n / R2);
     if ((int)grid > cus) return 0;
@@ -576,7 +696,8 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     {
         std::lock_guard<std::mutex> lock(attr_mutex);
         if (dev >= 0 && dev < 64 && attr_set[dev] < L.total) {
-            CLV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht4_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CLV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht4_persist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CLV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht4_persist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set[dev] = 160u * 1024u;
         }
     }
@@ -594,6 +715,36 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     a.t1 = (uint32_t *)t1; a.st1 = st1; a.t2 = (uint32_t *)t2; a.st2 = st2; a.t3 = (uint32_t *)t3; a.st3 = st3;
     a.iterations = (uint32_t)iterations; a.K = (uint32_t)(K > 0xFFFFFFFFull ? 0xFFFFFFFFull : K); a.mu = mu; a.threshold = threshold;
     a.g1 = (u64 *)ws; a.g2 = (u64 *)ws + m;
+    a.rng = rng;
+    a.seq = 0;
+    a.seg_rows = nullptr;
+    if (rng) {
+        // T^(D - 16) and T^(D - 17), column form, by square and multiply on the host (64 x 64 bits: microseconds)
+        RngTables T;
+        if (clv_rng_tables(&T)) return -1;
+        a.seg_rows = T.seg_rows;
+        const uint64_t D = (m + n) / 64 * 4;
+        auto power = [](uint64_t e, u64 *out) {
+            u64 sq[64], tmp[64];
+            for (int i = 0; i < 64; i++) { sq[i] = xs_T(1ull << i); out[i] = 1ull << i; }
+            for (; e; e >>= 1) {
+                if (e & 1) { for (int i = 0; i < 64; i++) tmp[i] = gf2_matvec(sq, out[i]); for (int i = 0; i < 64; i++) out[i] = tmp[i]; }
+                for (int i = 0; i < 64; i++) tmp[i] = gf2_matvec(sq, sq[i]);
+                for (int i = 0; i < 64; i++) sq[i] = tmp[i];
+            }
+        };
+        static std::mutex jump_mutex;                                     // the last D's matrices are kept: ~40 us of host time per call otherwise
+        static uint64_t jump_D = 0;
+        static u64 jump_kept[2][64];
+        std::lock_guard<std::mutex> lock(jump_mutex);
+        if (jump_D != D) {
+            power(D - 16, jump_kept[0]);
+            power(D - 17, jump_kept[1]);
+            jump_D = D;
+        }
+        memcpy(a.jump, jump_kept[0], sizeof(a.jump));
+        memcpy(a.jump1, jump_kept[1], sizeof(a.jump1));
+    }
     a.nap0 = 10;         // ~0.3 us: measured best of 0 / 10 / 20 / 30 / 40 at N = 8192 (profiles/r06_iht_persist_notes.txt)
     a.nap = 2;
     if (const char *e = getenv("CLV_IHT_NAP0")) a.nap0 = (uint32_t)atoi(e);                             // probe only
@@ -602,7 +753,12 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     if (const char *e = getenv("CLV_IHT_DEBUG_STAMPS")) a.dbg = (u64 *)strtoull(e, nullptr, 0);      // probe only: a device buffer of grid * 16 * 32 words
     PersistChain chain(st);
     if (chain.rc) return -1;
-    hipLaunchKernelGGL(k_iht4_persist, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
+    if (rng) {
+        a.seq = clv_rng_seq_for(rng, st);                                  // right in front of the launch, as every stochastic call
+        hipLaunchKernelGGL(k_iht4_persist<true>, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
+    } else {
+        hipLaunchKernelGGL(k_iht4_persist<false>, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         clv_set_error("clm4_iht: persistent launch failed: %s", hipGetErrorString(e));

@@ -30,19 +30,24 @@ def problem(m, n, seed):
     return (Phi, sPhi, PhiT, sPhiT), [vec(n, seed + 2), vec(m, seed + 4), vec(m, seed + 6), vec(m, seed + 8), vec(n, seed + 10)]
 
 
-def run(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent):
+def run(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent, seed=None):
     os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
     x, y, t1, t2, t3 = vecs
+    rng = hip.new_rng(*seed) if seed else None
     for v in (x, t1, t2, t3):
         hip.check(lib.clv_memset(v[0].ptr, 0x5A, v[0].nbytes, None))
         hip.check(lib.clv_memset(v[1].ptr, 0x3C, v[1].nbytes, None))
     hip.check(lib.clm4_iht(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, x_len, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
-                           t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, mu, thr, None, None))
+                           t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, mu, thr, rng.ptr if rng else None, None))
     hip.sync()
-    return [np.concatenate([v[0].download(np.uint8, v[0].nbytes), v[1].download(np.uint8, v[1].nbytes)]) for v in (x, t1, t2, t3)]
+    out = [np.concatenate([v[0].download(np.uint8, v[0].nbytes), v[1].download(np.uint8, v[1].nbytes)]) for v in (x, t1, t2, t3)]
+    if rng:
+        k1, k2 = hip.rng_get(rng)
+        out.append(np.concatenate([np.asarray(k1, np.uint64), np.asarray(k2, np.uint64)]).view(np.uint8))
+    return out
 
 
-def check():
+def check(seed=None):
     bad = 0
     cases = [(128, 128), (256, 512), (384, 640), (640, 384), (1024, 2048), (1536, 1024), (2048, 4096), (4096, 8192), (6144, 4096), (8192, 1024), (128, 8192)]
     for (m, n) in cases:
@@ -52,13 +57,13 @@ def check():
                 if thr == 0 and K != n // 4:
                     continue
                 for mu in (1e-3, 0.05):
-                    a = run(mat, vecs, m, n, x_len, iters, K, mu, thr, True)
-                    b = run(mat, vecs, m, n, x_len, iters, K, mu, thr, False)
+                    a = run(mat, vecs, m, n, x_len, iters, K, mu, thr, True, seed)
+                    b = run(mat, vecs, m, n, x_len, iters, K, mu, thr, False, seed)
                     ok = all(np.array_equal(u, v) for u, v in zip(a, b))
                     nz = int((a[0][: n // 2] != 0).sum())
                     if not ok:
                         bad += 1
-                        which = [nm for nm, u, v in zip(("x", "t1", "t2", "t3"), a, b) if not np.array_equal(u, v)]
+                        which = [nm for nm, u, v in zip(("x", "t1", "t2", "t3", "rng state"), a, b) if not np.array_equal(u, v)]
                         print(f"MISMATCH m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu}: {which}")
                     else:
                         print(f"ok m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu} (nonzero x bytes {nz})")
@@ -66,17 +71,18 @@ def check():
     return bad
 
 
-def timing(Ns):
+def timing(Ns, seed=None):
     for N in Ns:
         m, n = N // 2, N
         mat, vecs = problem(m, n, 31)
         x, y, t1, t2, t3 = vecs
+        rng = hip.new_rng(*seed) if seed else None
         for persistent in (0, 1):
             os.environ["CLV_IHT_PERSISTENT"] = str(persistent)
             for thr, K in ((1, n // 4), (1, m // 4), (0, 0)):
                 def call(iters):
                     hip.check(lib.clm4_iht(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr,
-                                           t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, 1e-3, thr, None, None))
+                                           t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, 1e-3, thr, rng.ptr if rng else None, None))
                     hip.sync()
                 call(10)
                 res = {}
@@ -145,6 +151,8 @@ if __name__ == "__main__":
     rc = 0
     if not args or "check" in args:
         rc = check()
+    if "check_st" in args:
+        rc = check(seed=(12345, 67890))
     if "stamps" in args:
         for N in [int(a) for a in args if a.isdigit()] or [256, 8192]:
             stamps(N, 1)
@@ -152,4 +160,6 @@ if __name__ == "__main__":
     if not args or "time" in args:
         Ns = [int(a) for a in args if a.isdigit()] or [256, 1024, 2048, 4096, 8192]
         timing(Ns)
+    if "time_st" in args:
+        timing([int(a) for a in args if a.isdigit()] or [256, 4096, 8192], seed=(5, 6))
     sys.exit(1 if rc else 0)
