@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A few IHT iterations at N = 8192 (for rocprofv3 passes)."""
+"""A few IHT iterations at N = 8192 (for rocprofv3 passes).  IHT_ITERS (default 20) iterations, IHT_K (default m / 4) survivors."""
+import os
 import sys
 from pathlib import Path
 
@@ -9,6 +10,8 @@ from clover_amd.lib_binding import CloverHip  # noqa: E402
 hip = CloverHip()
 lib = hip.lib
 m, n = 4096, 8192
+ITERS = int(os.environ.get("IHT_ITERS", "20"))
+KK = int(os.environ.get("IHT_K", str(m // 4)))
 Phi, PhiT = hip.alloc(m * n // 2), hip.alloc(m * n // 2)
 sPhi, sPhiT = hip.alloc((m // 64) * (n // 64) * 4), hip.alloc((m // 64) * (n // 64) * 4)
 hip.check(lib.clv_fill_random_nibbles(Phi.ptr, Phi.nbytes, 31, 0, None))
@@ -32,12 +35,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "v8":            # the mixed configurati
         return q, s
     x, y, t1, t2, t3 = vec8(n, 41), vec8(m, 43), vec8(m, 45), vec8(m, 47), vec8(n, 49)
     hip.check(lib.clm4_iht_v8(Phi.ptr, sPhi.ptr, PhiT.ptr, sPhiT.ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
-                              t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 20, m // 4, 1e-3, 1, None, None))
+                              t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, ITERS, KK, 1e-3, 1, None, None))
     hip.sync()
     print("iht v8 probe done")
     sys.exit(0)
 rng = hip.new_rng(5, 6) if len(sys.argv) > 1 and sys.argv[1] == "st" else None      # "st": stochastic rounding
 hip.check(lib.clm4_iht(Phi.ptr, sPhi.ptr, PhiT.ptr, sPhiT.ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
-                       t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 20, m // 4, 1e-3, 1, rng.ptr if rng else None, None))
+                       t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, ITERS, KK, 1e-3, 1, rng.ptr if rng else None, None))
 hip.sync()
 print("iht probe done")
