@@ -938,6 +938,30 @@ def gemm_sharded_measure(args, torch, hip, n: int) -> dict:
             hip.check(lib.clv_device_sync())
             full.append(host)
         hip.check(lib.clv_set_device(0))
+        # the other two exchange modes of the loop (round 6): panels to device 0 only / no exchange, C stays row-sharded like A
+        modes = {}
+        for mname, mode in (("gather_root", 1), ("sharded", 2)):
+            msteps = 30
+            hip.check(lib.clm4_sharded_gemm_begin_mode(ctx, B.data_ptr(), sB.data_ptr(), G, 0, steps, mode))
+            for w_ in range(10):
+                hip.check(lib.clm4_sharded_gemm_enqueue(ctx, w_, 0))
+            hip.check(lib.clm4_sharded_sync(ctx))
+            t0 = time.perf_counter()
+            for i in range(msteps):
+                hip.check(lib.clm4_sharded_gemm_enqueue(ctx, i, 0))
+            hip.check(lib.clm4_sharded_sync(ctx))
+            mel = time.perf_counter() - t0
+            held = {}
+            for d in sorted({0, n - 1}):
+                cp = C.c_void_p()
+                hip.check(lib.clm4_sharded_gemm_full(ctx, d, (msteps - 1) & 1, C.byref(cp)))
+                host = np.empty(G * G, np.float32)
+                hip.check(lib.clv_set_device(0 if debug else d))
+                hip.check(lib.clv_memcpy_d2h(host.ctypes.data, cp, host.nbytes, None))
+                hip.check(lib.clv_device_sync())
+                held[d] = host
+            hip.check(lib.clv_set_device(0))
+            modes[mname] = {"ms": mel / msteps * 1e3, "held": held}
     finally:
         lib.clm4_sharded_destroy(ctx)
         hip.check(lib.clv_set_device(0))
@@ -951,6 +975,19 @@ def gemm_sharded_measure(args, torch, hip, n: int) -> dict:
     torch.cuda.synchronize()
     ref = C0.cpu().numpy().view(np.uint32)
     verified = all(np.array_equal(f.view(np.uint32), ref) for f in full)
+    rows_per = G // n
+    mode_out = {}
+    for mname, mres in modes.items():
+        oks = []
+        for d, host in mres["held"].items():
+            h = host.view(np.uint32)
+            if mname == "gather_root" and d == 0:
+                oks.append(bool(np.array_equal(h, ref)))                                         # the root holds the whole C
+            else:
+                oks.append(bool(np.array_equal(h[d * rows_per * G:(d + 1) * rows_per * G], ref[d * rows_per * G:(d + 1) * rows_per * G])))      # its own panel
+        mtops = 2.0 * G ** 3 / mres["ms"] / 1e9
+        mode_out[mname] = {"ms_per_step": round(mres["ms"], 5), "value": round(mtops, 1), "unit": "TOP/s", "frac": round(mtops / (n * FP6_PEAK_TOPS), 4),
+                           "bytes_received": ({"root": (n - 1) * rows_per * G * 4, "others": 0} if mname == "gather_root" else 0), "verified": all(oks)}
     del A0, sA0, C0, B, sB
     torch.cuda.empty_cache()
     ops = 2.0 * G ** 3
@@ -971,6 +1008,8 @@ def gemm_sharded_measure(args, torch, hip, n: int) -> dict:
         "exchange": ("device copies (same-device rehearsal)" if debug else "ncclAllGather of the fp32 panels, in place, one per device and step"
                      if ranks.value and equal.value else "none (one shard)" if n == 1 and not ranks.value else "per-owner ncclBroadcast"),
         "rccl_ranks": ranks.value, "gathered_c_verified": bool(verified),
+        "other_exchange_modes": {**mode_out, "note": "clm4_sharded_gemm_begin_mode: gather_root = panels to device 0 only (grouped ncclSend / ncclRecv), "
+                                 "sharded = no exchange, C stays row-sharded like A; the headline figures above are the all-gather of SURVEY 8(e)"},
         "verified_how": "the whole C held by the first and the last device after the last step == clm4_gemm of the unsharded operands, all bits",
         **({"degraded": True} if degraded else {}),
     }

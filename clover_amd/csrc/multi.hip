@@ -28,6 +28,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t);      // optional (gather-to-root of the GEMM panels)
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t);
     ncclResult_t (*CommCount)(const ncclComm_t, int *);      // optional
     ncclResult_t (*GroupStart)();
     ncclResult_t (*GroupEnd)();
@@ -47,6 +49,8 @@ static RcclApi *rccl()
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
         a.Broadcast = (decltype(a.Broadcast))dlsym(h, "ncclBroadcast");
         a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+        a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
         a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
         a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
         a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
@@ -115,6 +119,7 @@ struct clm4_shard_ctx {
     // GEMM loop form (clm4_sharded_gemm_begin / _enqueue): two FULL C buffers per device, [2*d + buf]; device d computes its row panel
     // in place and the panels are all-gathered on the exchange stream ("shard rows of A, replicate B, all-gather C row panels")
     uint64_t gemm_loop_n = 0;
+    int gemm_mode = 0;          // CLM4_GEMM_ALL_GATHER / _GATHER_ROOT / _SHARDED: what clm4_sharded_gemm_enqueue exchanges
     std::vector<float *> Cf;
 };
 
@@ -668,9 +673,29 @@ extern "C" int clm4_sharded_gemm_result(const clm4_shard_ctx *c, int part, const
 //     clm4_sharded_sync          the one host wait;
 //     clm4_sharded_step_timing   kernel (re-code + MFMA kernel) and exchange time of a timed step;
 //     clm4_sharded_gemm_full     device pointer of the whole C (rows x N fp32) in buffer `buf` on shard `part`.
+// What happens to the C row panels after a step's kernels (clm4_sharded_gemm_begin_mode):
+//   CLM4_GEMM_ALL_GATHER   every device ends with the whole C (SURVEY 8(e) as written).  (N - 1) / N of C enters EVERY device: at configs[3]
+//                          split 8 ways 224 MiB per device and step against 0.06 ms of kernel -- exchange-bound by construction;
+//   CLM4_GEMM_GATHER_ROOT  the panels go to shard 0's device only (grouped ncclSend / ncclRecv): the consumer of C sits on one device; 7 of 8
+//                          devices send 32 MiB and receive nothing;
+//   CLM4_GEMM_SHARDED      nothing is exchanged: C stays row-sharded like A (the natural form when the consumer is sharded the same way, e.g.
+//                          the next product's left operand); the step is the kernel.
+// The panel of shard d is at rows row_begin[d] of its device's C buffer in every mode; bits never depend on the mode.
+extern "C" int clm4_sharded_gemm_begin_mode(clm4_shard_ctx *c, const int8_t *B, const float *sB, uint64_t N, int b_on_host, int slots, int mode)
+{
+    CLV_REQUIRE(c, "clm4_sharded_gemm_begin_mode: bad argument");
+    CLV_REQUIRE(mode == CLM4_GEMM_ALL_GATHER || mode == CLM4_GEMM_GATHER_ROOT || mode == CLM4_GEMM_SHARDED, "clm4_sharded_gemm_begin_mode: unknown mode %d", mode);
+    CLV_REQUIRE(mode != CLM4_GEMM_GATHER_ROOT || !c->use_rccl || (rccl()->Send && rccl()->Recv),
+                "clm4_sharded_gemm_begin_mode: this librccl has no ncclSend / ncclRecv");
+    int rc = clm4_sharded_gemm_begin(c, B, sB, N, b_on_host, slots);
+    if (rc == CLV_OK) c->gemm_mode = mode;
+    return rc;
+}
+
 extern "C" int clm4_sharded_gemm_begin(clm4_shard_ctx *c, const int8_t *B, const float *sB, uint64_t N, int b_on_host, int slots)
 {
     CLV_REQUIRE(c && B && sB && N && N % 128 == 0, "clm4_sharded_gemm_begin: bad argument");
+    c->gemm_mode = CLM4_GEMM_ALL_GATHER;
     for (int d = 0; d < c->ndev; d++)
         CLV_REQUIRE(c->row_count[d] % 128 == 0, "clm4_sharded_gemm_begin: shard %d has %llu rows, not a multiple of 128", d, (unsigned long long)c->row_count[d]);
     int rc = clm4_sharded_loop_begin(c, slots);
@@ -709,8 +734,9 @@ extern "C" int clm4_sharded_gemm_enqueue(clm4_shard_ctx *c, int step, int timed)
     CLV_REQUIRE(c->loop_ready && c->gemm_loop_n, "clm4_sharded_gemm_enqueue: call clm4_sharded_gemm_begin first");
     CLV_REQUIRE(!timed || step < c->slots, "clm4_sharded_gemm_enqueue: step %d has no event slot (%d reserved)", step, c->slots);
     DeviceGuard guard;
-    const int n = c->ndev, b = step & 1;
-    const bool exchange = n > 1 || c->use_rccl;
+    const int n = c->ndev, b = step & 1, mode = c->gemm_mode;
+    const bool exchange = (n > 1 || c->use_rccl) && mode != CLM4_GEMM_SHARDED;
+    const bool to_root = mode == CLM4_GEMM_GATHER_ROOT;
     const uint64_t N = c->gemm_loop_n, K = c->cols;
     auto slot = [&](int e, int d) { return c->slot_ev[(3 * (size_t)step + e) * n + d]; };
     auto Cb = [&](int d) { return c->Cf[2 * d + b]; };
@@ -729,12 +755,16 @@ extern "C" int clm4_sharded_gemm_enqueue(clm4_shard_ctx *c, int step, int timed)
         if (timed) CLV_HIP(hipEventRecord(slot(1, d), c->st[d]));
         if (exchange) CLV_HIP(hipEventRecord(c->kdone[2 * d + b], c->st[d]));
     }
-    if (!exchange) {                                            // one shard, no communicator: see clm4_sharded_mvm_enqueue
-        if (timed) CLV_HIP(hipEventRecord(slot(2, 0), c->st[0]));
+    if (!exchange) {                                            // one shard and no communicator (see clm4_sharded_mvm_enqueue), or C stays sharded
+        if (timed)
+            for (int d = 0; d < (mode == CLM4_GEMM_SHARDED ? n : 1); d++) {
+                CLV_HIP(hipSetDevice(c->dev[d]));
+                CLV_HIP(hipEventRecord(slot(2, d), c->st[d]));
+            }
         return CLV_OK;
     }
     if (n > 1 && c->loopback) {
-        for (int d = 0; d < n; d++) {
+        for (int d = 0; d < (to_root ? 1 : n); d++) {
             CLV_HIP(hipSetDevice(c->dev[d]));
             for (int o = 0; o < n; o++) {
                 CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * o + b], 0));
@@ -748,7 +778,15 @@ extern "C" int clm4_sharded_gemm_enqueue(clm4_shard_ctx *c, int step, int timed)
             CLV_HIP(hipSetDevice(c->dev[d]));
             CLV_HIP(hipStreamWaitEvent(c->cs[d], c->kdone[2 * d + b], 0));
         }
-        if (c->use_rccl) {
+        if (c->use_rccl && to_root) {
+            RcclGroup g;
+            CLV_NCCL(g.start());
+            for (int d = 1; d < n; d++) {                         // shard d's panel: device d -> device 0, same offset in both C buffers
+                CLV_NCCL(rccl()->Send(Cb(d) + c->row_begin[d] * N, c->row_count[d] * N, ncclFloat32, 0, c->comm[d], c->cs[d]));
+                CLV_NCCL(rccl()->Recv(Cb(0) + c->row_begin[d] * N, c->row_count[d] * N, ncclFloat32, d, c->comm[0], c->cs[0]));
+            }
+            CLV_NCCL(g.end());
+        } else if (c->use_rccl) {
             RcclGroup g;
             CLV_NCCL(g.start());
             if (c->equal) {

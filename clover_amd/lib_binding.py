@@ -109,6 +109,7 @@ SIGNATURES = {
     "clm4_sharded_gemm": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, _vp]),
     "clm4_sharded_gemm_result": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "clm4_sharded_gemm_begin": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, C.c_int]),
+    "clm4_sharded_gemm_begin_mode": (C.c_int, [_vp, _vp, _vp, _u64, C.c_int, C.c_int, C.c_int]),
     "clm4_sharded_gemm_enqueue": (C.c_int, [_vp, C.c_int, C.c_int]),
     "clm4_sharded_gemm_full": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "clv_fill_random_nibbles": (C.c_int, [_vp, _u64, _u64, _u64, _vp]),

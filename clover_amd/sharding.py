@@ -92,6 +92,26 @@ def partition_gemm_rows(rows: int, nparts: int, part: int) -> tuple[int, int]:
     return b0 * 128, (base + (1 if part < extra else 0)) * 128
 
 
+def exchange_gemm_rows(c_local: torch.Tensor, rows_total: int, ncols: int, mode: str = "all_gather", group=None):
+    """What happens to the per-rank row shards of C after a step, the three modes of clm4_sharded_gemm_begin_mode (multi.hip):
+    "all_gather" -> every rank returns the whole C; "gather_root" -> rank 0 returns the whole C, the others their own panel (they send
+    it and receive nothing); "sharded" -> no exchange, every rank returns its own panel."""
+    if mode == "all_gather":
+        return gather_gemm_rows(c_local, rows_total, ncols, group)
+    if mode == "sharded":
+        return c_local
+    assert mode == "gather_root", mode
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [partition_gemm_rows(rows_total, world, k)[1] for k in range(world)]
+    if rank == 0:
+        parts = [c_local.reshape(-1)] + [torch.empty(counts[k] * ncols, dtype=torch.float32, device=c_local.device) for k in range(1, world)]
+        for k in range(1, world):
+            dist.recv(parts[k], src=k, group=group)
+        return torch.cat(parts).view(rows_total, ncols)
+    dist.send(c_local.reshape(-1).contiguous(), dst=0, group=group)
+    return c_local
+
+
 def gather_gemm_rows(c_local: torch.Tensor, rows_total: int, ncols: int, group=None) -> torch.Tensor:
     """All-gather the per-rank row shards of C (fp32, [rows_k, ncols]) in rank order -> [rows_total, ncols]."""
     world = dist.get_world_size(group)

@@ -334,6 +334,18 @@ int  clm4_sharded_gemm_result(const clm4_shard_ctx *ctx, int part, const float *
  *   clm4_sharded_gemm_full     device pointer of the whole C in buffer `buf` on shard `part`.
  * Bit-identical to clm4_gemm on the unsharded matrix.  A context runs ONE loop at a time (mvm or gemm: they share the step events). */
 int  clm4_sharded_gemm_begin(clm4_shard_ctx *ctx, const int8_t *B, const float *sB, uint64_t N, int b_on_host, int slots);
+/* The same loop with a choice of what is exchanged after a step's kernels (the all-gather moves (N - 1) / N of C into EVERY device --
+ * 224 MiB per device and step at configs[3] on 8 GPUs against 0.06 ms of kernel: exchange-bound by construction):
+ *   CLM4_GEMM_ALL_GATHER   = clm4_sharded_gemm_begin: every device ends with the whole C;
+ *   CLM4_GEMM_GATHER_ROOT  the panels go to shard 0's device only (grouped ncclSend / ncclRecv): clm4_sharded_gemm_full(part 0) is the whole C,
+ *                          the other devices' buffers hold their own panel;
+ *   CLM4_GEMM_SHARDED      nothing is exchanged, C stays row-sharded like A: clm4_sharded_gemm_full(part) + row_begin(part) * N is shard
+ *                          `part`'s panel.  The step is the kernel.
+ * The bits of C never depend on the mode. */
+#define CLM4_GEMM_ALL_GATHER 0
+#define CLM4_GEMM_GATHER_ROOT 1
+#define CLM4_GEMM_SHARDED 2
+int  clm4_sharded_gemm_begin_mode(clm4_shard_ctx *ctx, const int8_t *B, const float *sB, uint64_t N, int b_on_host, int slots, int mode);
 int  clm4_sharded_gemm_enqueue(clm4_shard_ctx *ctx, int step, int timed);
 int  clm4_sharded_gemm_full(const clm4_shard_ctx *ctx, int part, int buf, const float **C_dev);
 

@@ -137,6 +137,38 @@ static int run_layout(const char *name, Whole &w, int nparts, const int *devices
                 if (!(k > 0.0f) || !(g >= 0.0f)) gemm_ok = 0;
             }
             if (!gemm_ok) { std::printf("%s: a shard's all-gathered C differs from clm4_gemm\n", name); return 1; }
+            // the other two exchange modes (round 6): panels to shard 0's device only -- its buffer is the whole C, every other device holds
+            // (at least) its own panel -- and no exchange at all: every device's buffer holds its own panel.  The buffers are poisoned first.
+            for (int mode = CLM4_GEMM_GATHER_ROOT; mode <= CLM4_GEMM_SHARDED && gemm_ok; mode++) {
+                CHECK(clm4_sharded_gemm_begin_mode(ctx, B, sB, N, 0, 3, mode));
+                for (int p = 0; p < nparts; p++)
+                    for (int buf = 0; buf < 2; buf++) {
+                        const float *cf; int dev;
+                        CHECK(clm4_sharded_gemm_full(ctx, p, buf, &cf));
+                        CHECK(clm4_sharded_info(ctx, p, &dev, nullptr, nullptr, nullptr, nullptr));
+                        CHECK(clv_set_device(dev));
+                        CHECK(clv_memset((void *)cf, 0xFF, w.rows * N * 4, nullptr));
+                        CHECK(clv_device_sync());
+                        CHECK(clv_set_device(before));
+                    }
+                for (int step = 0; step < 3; step++) CHECK(clm4_sharded_gemm_enqueue(ctx, step, 1));
+                CHECK(clm4_sharded_sync(ctx));
+                for (int p = 0; p < nparts && gemm_ok; p++) {
+                    const float *cf; int dev; uint64_t rb, rc;
+                    CHECK(clm4_sharded_gemm_full(ctx, p, 2 & 1, &cf));
+                    CHECK(clm4_sharded_info(ctx, p, &dev, &rb, &rc, nullptr, nullptr));
+                    CHECK(clv_set_device(dev));
+                    CHECK(clv_memcpy_d2h(C2.data(), cf, C2.size() * 4, nullptr));
+                    CHECK(clv_device_sync());
+                    CHECK(clv_set_device(before));
+                    if (mode == CLM4_GEMM_GATHER_ROOT && p == 0) gemm_ok = std::memcmp(C1.data(), C2.data(), C1.size() * 4) == 0;      // the whole C
+                    else gemm_ok = std::memcmp(C1.data() + rb * N, C2.data() + rb * N, rc * N * 4) == 0;                               // its own panel
+                    float k, g;
+                    CHECK(clm4_sharded_step_timing(ctx, p, 2, &k, &g));
+                    if (!(k > 0.0f) || !(g >= 0.0f)) gemm_ok = 0;
+                }
+                if (!gemm_ok) { std::printf("%s: sharded GEMM mode %d differs from clm4_gemm\n", name, mode); return 1; }
+            }
         }
         CHECK(clv_free(B)); CHECK(clv_free(sB)); CHECK(clv_free(C));
         if (!gemm_ok) { std::printf("%s: sharded GEMM differs from clm4_gemm\n", name); return 1; }

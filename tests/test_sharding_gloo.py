@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from clover_amd.sharding import (gather_gemm_rows, gather_packed, packed_bytes, partition_gemm_rows, partition_rows,  # noqa: E402
+from clover_amd.sharding import (exchange_gemm_rows, gather_gemm_rows, gather_packed, packed_bytes, partition_gemm_rows, partition_rows,  # noqa: E402
                                  unpack_gathered)
 
 
@@ -99,7 +99,14 @@ def _gemm_worker(rank, world, port, M, N, K, ret):
         C_loc = orc.m4_gemm(qA[b * K // 2:(b + c) * K // 2], sA[(b // 64) * kb:((b + c) // 64) * kb], c, K, qB, sB, N)
         full = gather_gemm_rows(torch.from_numpy(np.ascontiguousarray(C_loc)).reshape(c, N), M, N)
         ref = orc.m4_gemm(qA, sA, M, K, qB, sB, N).reshape(M, N)
-        ret[rank] = bool(np.array_equal(full.numpy().view(np.uint32), ref.view(np.uint32)))
+        ok = bool(np.array_equal(full.numpy().view(np.uint32), ref.view(np.uint32)))
+        # the other two exchange modes (clm4_sharded_gemm_begin_mode): the root ends with the whole C, everybody else with its own panel
+        loc = torch.from_numpy(np.ascontiguousarray(C_loc)).reshape(c, N)
+        for mode in ("gather_root", "sharded"):
+            got = exchange_gemm_rows(loc, M, N, mode).numpy().view(np.uint32)
+            want = ref.view(np.uint32) if (mode == "gather_root" and rank == 0) else ref.view(np.uint32)[b:b + c]
+            ok = ok and got.shape == want.shape and bool(np.array_equal(got, want))
+        ret[rank] = ok
     finally:
         dist.destroy_process_group()
 
