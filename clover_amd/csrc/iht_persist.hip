@@ -628,6 +628,380 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
     }
 }
 
+// =====================================================================================================================================
+// The same loop for CloverVector8 vectors: clm4_iht_v8, the configuration the reference measures and publishes as its "4-bit" IHT / GD
+// (CloverMatrix4 x CloverVector8: test/performance/02_bit04.cpp:140, doc/results/performance.txt:597-606).
+//
+// What differs from the 4-bit kernel above is the row dot (CloverMatrix4.h:1093-1441): per row EIGHT fp32 fma chains, chain L taking from
+// EVERY 64-column block b the exact integer I = sum of q4 * q8 over elements 4L..4L+3 and 32+4L..32+4L+3, acc = fma(c_b, (float)I, acc)
+// with c_b = f32(f32(sA/7) * f32(sx/127)) -- n / 64 dependent steps per chain -- and ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)).
+// Lane = (row, chain).  For v_dot8_i32_i4 both operands are laid out per (block, chain):
+//   * the matrix slice is re-dealt ONCE, on its way into LDS: word (b, L) = the chain's 8 nibbles (two half words of the row's block);
+//   * an int8 x = 16 (xh + xc) + xl with xl = its signed low nibble, xc = 1 only for x >= 120 (where the high part would be 8), xh in
+//     [-8, 7]: three nibble images of the vector, written by the thread that re-quantises the element, and
+//     I = 16 (dot8(A, xh) + dot8(A, xc)) + dot8(A, xl): three instructions, exact, instead of the two v_dot4_i32_i8 and four widening
+//     operations per half word of the launch-per-step kernel (k_m4_mvm8).
+// Everything else is the 4-bit kernel's: units, granules, gathers, one re-quantisation per consumer.  Deterministic rounding, threshold
+// FAST (k_thresh8_small's algorithm: element keys, four 8-bit levels, 8 copies of the bins) or none; otherwise clm4_iht_v8 keeps its loop.
+struct Ihtp8Layout {
+    uint32_t GB1, GB2;            // groups of 4 blocks of Phi's / PhiT's rows
+    uint32_t offA1, offA2, offX, offT, offC1, offC2, offP1, offP2, offHist, offHsum, offWtot, offPub, total;
+};
+__host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2)
+{
+    Ihtp8Layout L;
+    L.GB1 = (n / 64 + 3) / 4;
+    L.GB2 = (m / 64 + 3) / 4;
+    uint32_t o = 0;
+    L.offA1 = o; o += R1 * L.GB1 * 128;                                 // [row][group][chain][4 blocks] words
+    L.offA2 = o; o += R2 * L.GB2 * 128;
+    L.offX = o; o += 3 * L.GB1 * 128;                                   // x: the high / carry / low nibble images, [group][chain][4 blocks]
+    L.offT = o; o += 3 * L.GB2 * 128;                                   // t2 likewise
+    L.offC1 = o; o += L.GB1 * 16;                                       // c_b, [group][4 blocks]
+    L.offC2 = o; o += L.GB2 * 16;
+    L.offP1 = o; o += L.GB1 * 16;                                       // f32(sA_b / 7)
+    L.offP2 = o; o += L.GB2 * 16;
+    L.offHist = o; o += 8 * 256 * 4;                                    // one radix level, 8 copies
+    L.offHsum = o; o += 2 * 256 * 4;
+    L.offWtot = o; o += 64;
+    L.offPub = o; o += 64 * 4;
+    L.total = o + 256;                                                  // the dot loop reads one group past an array's end
+    return L;
+}
+__device__ __forceinline__ uint32_t dealt8(uint32_t b, uint32_t L) { return ((b >> 2) * 8 + L) * 4 + (b & 3); }
+
+// this workgroup's R rows into LDS, re-dealt per (block, chain): work item = (local row, group of 4 blocks, word pair k): words k and
+// 4 + k of four blocks -> chains 2k (their low halves) and 2k + 1 (their high halves), two ds_write_b128
+__device__ __forceinline__ void ihtp8_load_rows(const uint8_t *__restrict__ A, uint32_t u0, uint32_t R, uint32_t NB, uint32_t GB, uint32_t *lds)
+{
+    const uint32_t items = R * GB * 4;
+    for (uint32_t it = threadIdx.x; it < items; it += IHTP_THREADS) {
+        const uint32_t k = it & 3, g = (it >> 2) % GB, lr = (it >> 2) / GB;
+        const uint64_t row = unit_row(u0 + (lr >> 4), lr & 15);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(A + row * (uint64_t)NB * 32);
+        uint32_t ev[4], od[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t b = 4 * g + i;
+            const uint32_t lo = b < NB ? src[b * 8 + k] : 0u, hi = b < NB ? src[b * 8 + 4 + k] : 0u;
+            ev[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);           // elements 8k..8k+3 | 32+8k..32+8k+3: chain 2k
+            od[i] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);           // elements 8k+4..8k+7 | 36+8k..39+8k: chain 2k + 1
+        }
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lds + ((size_t)(lr * GB + g) * 8 + 2 * k) * 4);
+        dst[0] = u32x4{ev[0], ev[1], ev[2], ev[3]};
+        dst[1] = u32x4{od[0], od[1], od[2], od[3]};
+    }
+}
+
+struct Ihtp8Regs { u32x4 a, h, c, l; f32x4 f; };
+__device__ __forceinline__ float ihtp8_step(uint32_t a, uint32_t xh, uint32_t xc, uint32_t xl, float f, float acc)
+{
+    const int hi = sdot8(a, xc, sdot8z(a, xh));
+    return __builtin_fmaf(f, (float)sdot8(a, xl, hi << 4), acc);
+}
+// the row dot of lane (row, chain L) and the reference's tree over the row's 8 lanes (CloverMatrix4.h:1229-1234); every lane returns it
+__device__ __forceinline__ float ihtp8_row_dot(const uint32_t *Arow, const uint32_t *X, uint32_t xs /* words per nibble image */, const float *cf,
+                                               uint32_t NB, int L)
+{
+    const u32x4 *Ap = reinterpret_cast<const u32x4 *>(Arow) + L;
+    const u32x4 *Hp = reinterpret_cast<const u32x4 *>(X) + L, *Cp = Hp + xs / 4, *Lp = Cp + xs / 4;
+    const f32x4 *Fp = reinterpret_cast<const f32x4 *>(cf);
+    float acc = 0.0f;
+    const uint32_t full = NB >> 2;
+#define IHTP8_LOAD(R, G) do { R.a = Ap[(G) * 8]; R.h = Hp[(G) * 8]; R.c = Cp[(G) * 8]; R.l = Lp[(G) * 8]; R.f = Fp[(G)]; } while (0)
+#define IHTP8_GROUP(R)                                                                                              \
+    do {                                                                                                            \
+        acc = ihtp8_step(R.a.x, R.h.x, R.c.x, R.l.x, R.f.x, acc);                                                   \
+        acc = ihtp8_step(R.a.y, R.h.y, R.c.y, R.l.y, R.f.y, acc);                                                   \
+        acc = ihtp8_step(R.a.z, R.h.z, R.c.z, R.l.z, R.f.z, acc);                                                   \
+        acc = ihtp8_step(R.a.w, R.h.w, R.c.w, R.l.w, R.f.w, acc);                                                   \
+    } while (0)
+    Ihtp8Regs r0, r1;
+    IHTP8_LOAD(r0, 0);
+    uint32_t g = 0;
+    for (; g + 2 <= full; g += 2) {                                      // r0 = group g; the next group is read while this one is used
+        IHTP8_LOAD(r1, g + 1);
+        IHTP8_GROUP(r0);
+        IHTP8_LOAD(r0, g + 2);
+        IHTP8_GROUP(r1);
+    }
+    if (g < full) {
+        IHTP8_LOAD(r1, g + 1);
+        IHTP8_GROUP(r0);
+        r0 = r1;
+    }
+    if (NB & 3) {                                                      // the partial group (cols % 256 != 0)
+        const uint32_t rem = NB & 3;
+        acc = ihtp8_step(r0.a.x, r0.h.x, r0.c.x, r0.l.x, r0.f.x, acc);
+        if (rem > 1) acc = ihtp8_step(r0.a.y, r0.h.y, r0.c.y, r0.l.y, r0.f.y, acc);
+        if (rem > 2) acc = ihtp8_step(r0.a.z, r0.h.z, r0.c.z, r0.l.z, r0.f.z, acc);
+    }
+#undef IHTP8_LOAD
+#undef IHTP8_GROUP
+    // h[L & 3] = a[L] + a[L ^ 4] (lanes 4..7 of the group take lane - 4: row_shr:4 on banks 1, 3; lanes 0..3 lane + 4: row_shl:4 on banks 0, 2)
+    int o = __builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x114, 0xF, 0xA, false);
+    o = __builtin_amdgcn_update_dpp(o, __float_as_int(acc), 0x104, 0xF, 0x5, false);
+    const float h = acc + __int_as_float(o);
+    const float x2 = h + IHTP_DPP_F(h, 0x4E);                            // h0 + h2 | h1 + h3
+    return x2 + IHTP_DPP_F(x2, 0xB1);
+}
+
+// the three nibble images of 4 int8 values (one chain's half word): x = 16 (xh + xc) + xl
+__device__ __forceinline__ void ihtp8_split4(const int q[4], uint32_t &h, uint32_t &c, uint32_t &l)
+{
+    h = c = l = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int xl = ((q[e] & 15) ^ 8) - 8, rem = (q[e] - xl) >> 4, cy = rem == 8 ? 1 : 0;
+        const int sh = 8 * (e >> 1) + ((e & 1) ? 0 : 4);               // even elements in the high nibble of their byte, as the matrix stores them
+        h |= (uint32_t)((rem - cy) & 15) << sh;
+        c |= (uint32_t)cy << sh;
+        l |= (uint32_t)(xl & 15) << sh;
+    }
+}
+// thread (block b, position i) writes its 8 elements' images: elements 8i..8i+3 -> chain 2 (i & 3), 8i+4..8i+7 -> the next chain, low half
+// word for i < 4 (elements 0..31 of the block), high half word for i >= 4
+__device__ __forceinline__ void ihtp8_store_images(uint32_t *X, uint32_t xs, uint32_t b, uint32_t i, const int q[8])
+{
+    uint16_t *X16 = reinterpret_cast<uint16_t *>(X);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        uint32_t h, c, l;
+        ihtp8_split4(q + 4 * half, h, c, l);
+        const uint32_t w = dealt8(b, 2 * (i & 3) + half) * 2 + (i >> 2);       // 16-bit index
+        X16[w] = (uint16_t)h;
+        X16[w + 2 * xs] = (uint16_t)c;
+        X16[w + 4 * xs] = (uint16_t)l;
+    }
+}
+
+// r = quantize8(d), o = quantize8(u + a r) for the thread's 8 elements (k_m4_mvm8's fused epilogue, mixed8.hip: CloverMatrix4.h:1246-1440,
+// CloverVector8.h:1089-1358); u = the thread's two words of u
+__device__ __forceinline__ void ihtp8_requant_saa(const float d[8], const uint32_t uw[2], float us, float a, int q[8], float &rs, int q2[8], float &os)
+{
+    float mx = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) mx = fmaxf(mx, __builtin_fabsf(d[e]));
+    rs = fix_zero_max(group8_max(mx));
+    const float k = 127.0f / rs;
+#pragma unroll
+    for (int e = 0; e < 8; e++) q[e] = quant1(d[e], k, 0.0f);
+    const float su127 = div127(us), sv127 = div127(rs * a);
+    float val[8], m2 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float qu = (float)((int)(uw[e >> 2] << (24 - 8 * (e & 3))) >> 24);
+        val[e] = __builtin_fmaf((float)q[e], sv127, qu * su127);
+        m2 = fmaxf(m2, __builtin_fabsf(val[e]));
+    }
+    os = fix_zero_max(group8_max(m2));
+    const float k2 = 127.0f / os;
+#pragma unroll
+    for (int e = 0; e < 8; e++) q2[e] = quant1(val[e], k2, 0.0f);
+}
+__device__ __forceinline__ uint32_t pack4_i8(const int q[4]) { return ((uint32_t)q[0] & 0xFFu) | (((uint32_t)q[1] & 0xFFu) << 8) | (((uint32_t)q[2] & 0xFFu) << 16) | ((uint32_t)q[3] << 24); }
+
+// CloverVector8::threshold(K), FAST rule: k_thresh8_small's algorithm (threshold4.hip) for a vector held 8 elements per thread.  q: the
+// thread's elements; returns them with the losers zeroed.  hist[8][256] zero on entry and again on exit; hsum[2][256], wtot[16].
+// (Measured and dropped: counting the keys that share the bin of the thread's first key in a register and adding them up over the block's 8
+// lanes before ONE atomic -- the upper levels' bins are few -- changed nothing: 18.0 against 17.5 us per iteration at N = 8192.)
+__device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_, uint32_t n, uint32_t k, uint32_t *hist, uint32_t *hsum, uint32_t *wtot)
+{
+    const int tid = (int)tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t keys[8], valid = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        keys[e] = __float_as_uint(__builtin_fabsf(div127((float)q[e] * s)));
+        if (8u * tid + e < n) valid |= 1u << e;
+    }
+    uint32_t tau = 0x7F800000u, keep = 0;
+    if (k != 0) {
+        uint32_t prefix = 0, need = k;
+        uint32_t *hp = hist + 256 * (tid & 7);
+#pragma unroll
+        for (int level = 0; level < 4; level++) {
+            const int shift = 24 - 8 * level;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (((valid >> e) & 1u) && (level == 0 || (keys[e] >> (shift + 8)) == prefix)) atomicAdd(&hp[(keys[e] >> shift) & 0xFFu], 1u);
+            __syncthreads();
+            if (tid < 256) {                                             // the copies are added up once, and cleared for the next level / call
+                uint32_t mine = 0;
+#pragma unroll
+                for (int cpy = 0; cpy < 8; cpy++) { mine += hist[256 * cpy + tid]; hist[256 * cpy + tid] = 0; }
+                hsum[256 * (level & 1) + tid] = mine;
+            }
+            __syncthreads();
+            const u32x4 h4 = *reinterpret_cast<const u32x4 *>(hsum + 256 * (level & 1) + 252 - 4 * lane);
+            const uint32_t t0 = h4.w, t1 = h4.z, t2 = h4.y, t3 = h4.x;
+            const uint32_t sum = t0 + t1 + t2 + t3;
+            const uint32_t incl = wave_scan_incl(sum);
+            const u64 hit = __ballot(incl >= need && incl - sum < need);
+            const int Ls = __builtin_ctzll(hit);
+            uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)(incl - sum), Ls);
+            const uint32_t T0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, Ls), T1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, Ls),
+                           T2 = (uint32_t)__builtin_amdgcn_readlane((int)t2, Ls);
+            uint32_t pick = 0;
+            if (above + T0 < need) { above += T0; pick = 1;
+                if (above + T1 < need) { above += T1; pick = 2;
+                    if (above + T2 < need) { above += T2; pick = 3; } } }
+            prefix = (prefix << 8) | (255u - 4u * (uint32_t)Ls - pick);
+            need -= above;
+        }
+        tau = prefix;
+        keep = need;
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) c += ((valid >> e) & 1u) && keys[e] == tau;
+    const uint32_t vinc = wave_scan_incl(c);
+    if (lane == 63) wtot[wave] = vinc;
+    __syncthreads();
+    const uint32_t tot = lane < 16 ? wtot[lane] : 0;
+    const uint32_t inc = wave_scan_incl(tot);
+    uint32_t rank = vinc - c + (uint32_t)__builtin_amdgcn_readlane((int)(inc - tot), wave);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        if (!((valid >> e) & 1u)) continue;                              // padding is left alone
+        if (keys[e] > tau) continue;
+        if (keys[e] == tau) { if (rank >= keep) q[e] = 0; rank++; }
+        else q[e] = 0;
+    }
+}
+
+struct Ihtp8Args {
+    const uint8_t *Phi;
+    const float *sPhi;
+    const uint8_t *PhiT;
+    const float *sPhiT;
+    uint32_t m, n, x_len, R1, R2;
+    uint32_t *x;
+    float *sx;
+    const uint32_t *y;
+    const float *sy;
+    uint32_t *t1;
+    float *st1;
+    uint32_t *t2;
+    float *st2;
+    uint32_t *t3;
+    float *st3;
+    uint32_t iterations, K;
+    float mu;
+    int threshold;
+    u64 *g1, *g2;
+    uint32_t nap0, nap;
+};
+
+__global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Ihtp8Layout L = ihtp8_layout(A.m, A.n, A.R1, A.R2);
+    uint32_t *A1 = reinterpret_cast<uint32_t *>(smem + L.offA1), *A2 = reinterpret_cast<uint32_t *>(smem + L.offA2);
+    uint32_t *X = reinterpret_cast<uint32_t *>(smem + L.offX), *T = reinterpret_cast<uint32_t *>(smem + L.offT);
+    float *c1 = reinterpret_cast<float *>(smem + L.offC1), *c2 = reinterpret_cast<float *>(smem + L.offC2);
+    float *p1 = reinterpret_cast<float *>(smem + L.offP1), *p2 = reinterpret_cast<float *>(smem + L.offP2);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + L.offHist), *hsum = reinterpret_cast<uint32_t *>(smem + L.offHsum);
+    uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + L.offWtot);
+    float *pub = reinterpret_cast<float *>(smem + L.offPub);
+
+    const uint32_t tid0 = threadIdx.x, g = blockIdx.x;
+    const uint32_t m = A.m, n = A.n, NB1 = n / 64, NB2 = m / 64, XS1 = L.GB1 * 32, XS2 = L.GB2 * 32;      // words per nibble image
+    const uint32_t u1 = g * (A.R1 >> 4), u2 = g * (A.R2 >> 4);
+    const bool has1 = u1 < m / 16, has2 = u2 < n / 16;
+
+    if (has1) ihtp8_load_rows(A.Phi, u1, A.R1, NB1, L.GB1, A1);
+    if (has2) ihtp8_load_rows(A.PhiT, u2, A.R2, NB2, L.GB2, A2);
+    for (uint32_t i = tid0; i < 3 * XS1; i += IHTP_THREADS) X[i] = 0;                          // x.clear(): every image of 0 is 0 ...
+    for (uint32_t i = tid0; i < 3 * XS2; i += IHTP_THREADS) T[i] = 0;
+    for (uint32_t i = tid0; i < L.GB1 * 4; i += IHTP_THREADS) { c1[i] = 0.0f; p1[i] = 0.0f; }
+    for (uint32_t i = tid0; i < L.GB2 * 4; i += IHTP_THREADS) { c2[i] = 0.0f; p2[i] = 0.0f; }
+    hist[tid0] = 0;
+    hist[tid0 + 1024] = 0;
+    __syncthreads();
+    if (has1)
+        for (uint32_t b = tid0; b < NB1; b += IHTP_THREADS) {
+            const float p = A.sPhi[(size_t)(u1 >> 2) * NB1 + b] * (1.0f / 7.0f);              // CloverMatrix4.h:1147-1149
+            p1[b] = p;
+            c1[b] = p * (1.0f * (1.0f / 127.0f));                                                // ... scales 1.0
+        }
+    if (has2)
+        for (uint32_t b = tid0; b < NB2; b += IHTP_THREADS) p2[b] = A.sPhiT[(size_t)(u2 >> 2) * NB2 + b] * (1.0f / 7.0f);
+    const bool own_m = tid0 < m / 8;
+    uint32_t yw[2] = {own_m ? A.y[2 * tid0] : 0u, own_m ? A.y[2 * tid0 + 1] : 0u};
+    const float ys = own_m ? A.sy[tid0 >> 3] : 1.0f;
+    uint32_t xw[2] = {0u, 0u};
+    float xs = 1.0f;
+    __syncthreads();
+
+    for (uint32_t it = 0; it < A.iterations; it++) {
+        const uint32_t epoch = it + 1;
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const bool last = it + 1 == A.iterations;
+        // ---- P1 ----
+        if (has1 && tid < 8 * A.R1) {
+            const uint32_t lr = tid >> 3;
+            const float dot = ihtp8_row_dot(A1 + (size_t)lr * L.GB1 * 32, X, XS1, c1, NB1, tid & 7);
+            if ((tid & 7) == 0) pub[lr] = dot;
+        }
+        __syncthreads();
+        if (has1 && tid < A.R1)
+            __hip_atomic_store((gu64 *)A.g1 + unit_slot(u1 + (tid >> 4), tid & 15, m), ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        // ---- E1 ----
+        if ((tid & ~63u) < m / 8) {
+            float d[8];
+            ihtp_gather8(A.g1, m, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
+            if (tid < m / 8) {
+                int q1[8], q2[8];
+                float t1s, t2s;
+                ihtp8_requant_saa(d, yw, ys, -1.0f, q1, t1s, q2, t2s);
+                ihtp8_store_images(T, XS2, tid >> 3, tid & 7, q2);
+                if ((tid & 7) == 0) c2[tid >> 3] = p2[tid >> 3] * (t2s * (1.0f / 127.0f));
+                if (last && g == 0) {
+                    A.t1[2 * tid] = pack4_i8(q1); A.t1[2 * tid + 1] = pack4_i8(q1 + 4);
+                    A.t2[2 * tid] = pack4_i8(q2); A.t2[2 * tid + 1] = pack4_i8(q2 + 4);
+                    if ((tid & 7) == 0) { A.st1[tid >> 3] = t1s; A.st2[tid >> 3] = t2s; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P2 ----
+        if (has2 && tid < 8 * A.R2) {
+            const uint32_t lr = tid >> 3;
+            const float dot = ihtp8_row_dot(A2 + (size_t)lr * L.GB2 * 32, T, XS2, c2, NB2, tid & 7);
+            if ((tid & 7) == 0) pub[lr] = dot;
+        }
+        __syncthreads();
+        if (has2 && tid < A.R2)
+            __hip_atomic_store((gu64 *)A.g2 + unit_slot(u2 + (tid >> 4), tid & 15, n), ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        // ---- E2 ----
+        int q3[8], qx[8];
+        float t3s = 1.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) q3[e] = qx[e] = 0;
+        if ((tid & ~63u) < n / 8) {
+            float d[8];
+            ihtp_gather8(A.g2, n, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
+            if (tid < n / 8) ihtp8_requant_saa(d, xw, xs, A.mu, q3, t3s, qx, xs);
+        }
+        if (A.threshold && A.K < A.x_len) ihtp8_threshold(qx, xs, tid, A.x_len, A.K, hist, hsum, wtot);
+        if (tid < n / 8) {
+            xw[0] = pack4_i8(qx);
+            xw[1] = pack4_i8(qx + 4);
+            ihtp8_store_images(X, XS1, tid >> 3, tid & 7, qx);
+            if ((tid & 7) == 0) c1[tid >> 3] = p1[tid >> 3] * (xs * (1.0f / 127.0f));
+            if (last && g == 0) {
+                A.t3[2 * tid] = pack4_i8(q3); A.t3[2 * tid + 1] = pack4_i8(q3 + 4);
+                A.x[2 * tid] = xw[0]; A.x[2 * tid + 1] = xw[1];
+                if ((tid & 7) == 0) { A.st3[tid >> 3] = t3s; A.sx[tid >> 3] = xs; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------------------------
 static uint32_t pow2_ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -762,6 +1136,61 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         clv_set_error("clm4_iht: persistent launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 1;
+}
+
+// the CloverVector8 loop (clm4_iht_v8): 1 = launched, 0 = does not qualify, < 0 = error
+int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n, int8_t *x, float *sx,
+                           uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1, int8_t *t2, float *st2, int8_t *t3, float *st3,
+                           uint64_t iterations, uint64_t K, float mu, int threshold, uint64_t *rng, hipStream_t st)
+{
+    const int mode = [] { const char *e = getenv("CLV_IHT_PERSISTENT"); return e ? atoi(e) : 1; }();
+    if (!mode || rng || threshold < 0 || threshold > 1 || !iterations || iterations >= 0x7FFFFFFFull) return 0;
+    if (m > IHTP_MAXLEN || n > IHTP_MAXLEN || m % 128 || n % 128 || !m || !n) return 0;
+    const int cus = clv_cu_count();
+    uint32_t R1 = pow2_ceil((uint32_t)((m + cus - 1) / cus)), R2 = pow2_ceil((uint32_t)((n + cus - 1) / cus));
+    if (R1 < 16) R1 = 16;
+    if (R2 < 16) R2 = 16;
+    if (R1 > 64 || R2 > 64) return 0;
+    const Ihtp8Layout L = ihtp8_layout((uint32_t)m, (uint32_t)n, R1, R2);
+    if (L.total > 160u * 1024u) return 0;
+    const uint32_t grid = (uint32_t)((m / R1 > n / R2) ? m / R1 : n / R2);
+    if ((int)grid > cus) return 0;
+    static std::mutex attr_mutex;
+    static bool attr_set[64];
+    int dev = 0;
+    CLV_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            CLV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht8_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev] = true;
+        }
+    }
+    void *ws = nullptr;
+    if (clv_internal_workspace(&ws, (m + n) * sizeof(u64), st)) return -1;
+    if (hipMemsetAsync(ws, 0, (m + n) * sizeof(u64), st) != hipSuccess) {
+        clv_set_error("clm4_iht_v8: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+        return -1;
+    }
+    Ihtp8Args a;
+    a.Phi = (const uint8_t *)Phi; a.sPhi = sPhi; a.PhiT = (const uint8_t *)PhiT; a.sPhiT = sPhiT;
+    a.m = (uint32_t)m; a.n = (uint32_t)n; a.x_len = (uint32_t)x_len; a.R1 = R1; a.R2 = R2;
+    a.x = (uint32_t *)x; a.sx = sx; a.y = (const uint32_t *)y; a.sy = sy;
+    a.t1 = (uint32_t *)t1; a.st1 = st1; a.t2 = (uint32_t *)t2; a.st2 = st2; a.t3 = (uint32_t *)t3; a.st3 = st3;
+    a.iterations = (uint32_t)iterations; a.K = (uint32_t)(K > 0xFFFFFFFFull ? 0xFFFFFFFFull : K); a.mu = mu; a.threshold = threshold;
+    a.g1 = (u64 *)ws; a.g2 = (u64 *)ws + m;
+    a.nap0 = 10;
+    a.nap = 2;
+    if (const char *e = getenv("CLV_IHT_NAP0")) a.nap0 = (uint32_t)atoi(e);                             // probe only
+    PersistChain chain(st);
+    if (chain.rc) return -1;
+    hipLaunchKernelGGL(k_iht8_persist, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        clv_set_error("clm4_iht_v8: persistent launch failed: %s", hipGetErrorString(e));
         return -1;
     }
     return 1;

@@ -871,6 +871,11 @@ __global__ void k_v8_clear(uint32_t *q, float *s, uint64_t nwords, uint64_t nblo
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks; i += stride) s[i] = 1.0f;
 }
 
+// iht_persist.hip: the whole loop as one persistent launch (N <= 8192, rounding disabled, threshold FAST or none); 1 = launched, 0 = no, < 0 = error
+int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n, int8_t *x, float *sx,
+                           uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1, int8_t *t2, float *st2, int8_t *t3, float *st3,
+                           uint64_t iterations, uint64_t K, float mu, int threshold, uint64_t *rng, hipStream_t st);
+
 extern "C" int clm4_iht_v8(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n, int8_t *x,
                            float *sx, uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1, int8_t *t2, float *st2,
                            int8_t *t3, float *st3, uint64_t iterations, uint64_t K, float mu, int threshold, uint64_t *rng_state_dev,
@@ -880,6 +885,12 @@ extern "C" int clm4_iht_v8(const int8_t *Phi, const float *sPhi, const int8_t *P
     CLV_REQUIRE(m % 128 == 0 && n % 128 == 0 && x_len <= n, "clm4_iht_v8: m=%llu n=%llu x_len=%llu", (unsigned long long)m,
                 (unsigned long long)n, (unsigned long long)x_len);
     hipStream_t st = as_stream(stream);
+    {
+        const int p = clm4_iht_v8_persistent(Phi, sPhi, PhiT, sPhiT, m, n, x, sx, x_len, y, sy, t1, st1, t2, st2, t3, st3, iterations, K, mu, threshold,
+                                             rng_state_dev, st);
+        if (p < 0) return CLV_ERR_HIP;
+        if (p > 0) return CLV_OK;
+    }
     hipLaunchKernelGGL(k_v8_clear, dim3(64), dim3(256), 0, st, (uint32_t *)x, sx, n / 4, n / 64);      // x.clear()
     CLV_LAUNCH_CHECK();
     for (uint64_t it = 0; it < iterations; it++) {

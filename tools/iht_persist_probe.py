@@ -30,6 +30,76 @@ def problem(m, n, seed):
     return (Phi, sPhi, PhiT, sPhiT), [vec(n, seed + 2), vec(m, seed + 4), vec(m, seed + 6), vec(m, seed + 8), vec(n, seed + 10)]
 
 
+def problem8(m, n, seed):
+    mat, _ = problem(m, n, seed)
+
+    def vec8(k, sd):
+        q, s = hip.alloc(k), hip.alloc(k // 16)
+        hip.check(lib.clv_fill_random_nibbles(q.ptr, q.nbytes, sd, 0, None))      # bytes whose nibbles are in [-7, 7]: any int8 but -128
+        hip.check(lib.clv_fill_random_scales(s.ptr, s.nbytes // 4, sd + 1, 0, None))
+        return q, s
+    return mat, [vec8(n, seed + 2), vec8(m, seed + 4), vec8(m, seed + 6), vec8(m, seed + 8), vec8(n, seed + 10)]
+
+
+def run8(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent):
+    os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
+    x, y, t1, t2, t3 = vecs
+    for v in (x, t1, t2, t3):
+        hip.check(lib.clv_memset(v[0].ptr, 0x5A, v[0].nbytes, None))
+        hip.check(lib.clv_memset(v[1].ptr, 0x3C, v[1].nbytes, None))
+    hip.check(lib.clm4_iht_v8(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, x_len, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
+                              t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, mu, thr, None, None))
+    hip.sync()
+    return [np.concatenate([v[0].download(np.uint8, v[0].nbytes), v[1].download(np.uint8, v[1].nbytes)]) for v in (x, t1, t2, t3)]
+
+
+def check8():
+    bad = 0
+    cases = [(128, 128), (256, 512), (384, 640), (640, 384), (1024, 2048), (2048, 4096), (4096, 8192), (6144, 4096), (8192, 1024), (128, 8192)]
+    for (m, n) in cases:
+        mat, vecs = problem8(m, n, 300 + m + n)
+        for thr in (1, 0):
+            for (x_len, K, iters) in ((n, n // 4, 5), (n - 37, n // 8 + 3, 3), (n, 0, 2), (n, n, 2), (n, 1, 4)):
+                if thr == 0 and K != n // 4:
+                    continue
+                for mu in (1e-3, 0.05):
+                    a = run8(mat, vecs, m, n, x_len, iters, K, mu, thr, True)
+                    b = run8(mat, vecs, m, n, x_len, iters, K, mu, thr, False)
+                    ok = all(np.array_equal(u, v) for u, v in zip(a, b))
+                    if not ok:
+                        bad += 1
+                        which = [(nm, int(np.flatnonzero(u != v)[0]), int((u != v).sum())) for nm, u, v in zip(("x", "t1", "t2", "t3"), a, b) if not np.array_equal(u, v)]
+                        print(f"MISMATCH v8 m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu}: {which}")
+                    else:
+                        print(f"ok v8 m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu} (nonzero x bytes {int((a[0][:n] != 0).sum())})")
+    print("CHECK v8", "FAILED" if bad else "PASSED", bad)
+    return bad
+
+
+def timing8(Ns):
+    for N in Ns:
+        m, n = N // 2, N
+        mat, vecs = problem8(m, n, 31)
+        x, y, t1, t2, t3 = vecs
+        for persistent in (0, 1):
+            os.environ["CLV_IHT_PERSISTENT"] = str(persistent)
+            for thr, K in ((1, n // 4), (0, 0)):
+                def call(iters):
+                    hip.check(lib.clm4_iht_v8(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr,
+                                              t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, 1e-3, thr, None, None))
+                    hip.sync()
+                call(10)
+                res = {}
+                for iters in (100, 1000):
+                    best = 1e9
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        call(iters)
+                        best = min(best, time.perf_counter() - t0)
+                    res[iters] = best
+                print(f"v8 N={N} persistent={persistent} thr={thr} K={K}: {(res[1000] - res[100]) / 900 * 1e6:.2f} us/iteration", flush=True)
+
+
 def run(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent, seed=None):
     os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
     x, y, t1, t2, t3 = vecs
@@ -151,6 +221,10 @@ if __name__ == "__main__":
     rc = 0
     if not args or "check" in args:
         rc = check()
+    if "check8" in args:
+        rc = check8()
+    if "time8" in args:
+        timing8([int(a) for a in args if a.isdigit()] or [256, 4096, 8192])
     if "check_st" in args:
         rc = check(seed=(12345, 67890))
     if "stamps" in args:
