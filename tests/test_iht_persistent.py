@@ -144,6 +144,41 @@ def test_persistent_threshold_on_clustered_magnitudes(hip, oracle, seed):
             assert same(a[name], b[name]), (name, K, mu)
 
 
+@pytest.mark.parametrize("shape", [(128, 128), (256, 512), (384, 640), (640, 384), (2048, 4096), (4096, 8192), (6144, 4096), (128, 8192), (8192, 128)])
+def test_persistent_v8_equals_launch_per_step(hip, oracle, shape):
+    """clm4_iht_v8 -- CloverMatrix4 with CloverVector8 vectors, the reference's published "4-bit" IHT / GD (02_bit04.cpp:140) -- as one
+    persistent launch (k_iht8_persist: matrix words re-dealt per fma chain, three nibble images of the int8 vector, v_dot8_i32_i4) against
+    its launch-per-step loop (k_m4_mvm8 + k_thresh8_small): x, t1, t2, t3 and their scales, every bit.  (The oracle-loop comparison of
+    tests/test_mixed8.py runs through the persistent kernel as well: its sizes qualify.)"""
+    m, n = shape
+    rng = np.random.default_rng(300 + m + n)
+    qPhi, _ = random_packed(rng, m * n)
+    sPhi = rng.uniform(0.5, 2, size=(m // 64) * (n // 64)).astype(np.float32)
+    qT, sT = oracle.m4_transpose(qPhi, sPhi, m, n)
+    y = rng.integers(-127, 128, size=m).astype(np.int8)
+    y[:8] = [127, -127, 120, 119, -120, -121, 112, 0]                 # the carry image of the int8 split: x >= 120
+    sy = rng.uniform(0.5, 2, size=m // 64).astype(np.float32)
+    d = {k: hip.to_device(v) for k, v in dict(Phi=qPhi, sPhi=sPhi, PhiT=qT, sPhiT=sT, y=y.view(np.uint8), sy=sy).items()}
+    sizes = dict(x=n, sx=n // 16, t1=m, st1=m // 16, t2=m, st2=m // 16, t3=n, st3=n // 16)
+    b = {k: hip.alloc(max(sz, 4)) for k, sz in sizes.items()}
+
+    def run(iters, K, mu, thr, x_len, persistent):
+        os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
+        for v in b.values():
+            hip.check(hip.lib.clv_memset(v.ptr, 0x5A, v.nbytes, None))
+        hip.check(hip.lib.clm4_iht_v8(d["Phi"].ptr, d["sPhi"].ptr, d["PhiT"].ptr, d["sPhiT"].ptr, m, n, b["x"].ptr, b["sx"].ptr, x_len, d["y"].ptr, d["sy"].ptr,
+                                      b["t1"].ptr, b["st1"].ptr, b["t2"].ptr, b["st2"].ptr, b["t3"].ptr, b["st3"].ptr, iters, K, float(mu), thr, None, None))
+        hip.sync()
+        return {k: b[k].download(np.uint8, sz) for k, sz in sizes.items()}
+
+    for thr, x_len, K, iters, mu in [(1, n, n // 4, 5, 1e-3), (1, n - 37, n // 8 + 3, 3, 0.05), (1, n, 0, 2, 1e-3), (1, n, n, 2, 1e-3), (1, n, 1, 4, 0.05),
+                                     (0, n, 0, 4, 1e-3), (1, n, n // 2, 3, 0.5)]:
+        a_, b_ = run(iters, K, mu, thr, x_len, True), run(iters, K, mu, thr, x_len, False)
+        for name in a_:
+            assert same(a_[name], b_[name]), (name, thr, x_len, K, iters, mu)
+    os.environ.pop("CLV_IHT_PERSISTENT", None)
+
+
 def test_persistent_calls_on_two_streams_are_chained(hip, oracle):
     """two persistent launches at once could each hold part of the chip and wait for the rest for ever: launches on different streams are
     chained by an event (iht_persist.hip persist_chain).  Two host threads, two streams, alternating calls: every result is the right one."""
