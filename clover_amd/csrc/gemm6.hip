@@ -412,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_m4_gemm_fp6_t256(const uint8_t *__rest
         if constexpr (I32) G6T_RUN(G6T_LOOP_ASM_I32_V##N); \
         else G6T_RUN(G6T_LOOP_ASM_V##N);                \
     }
-        G6T_VARIANT(1) G6T_VARIANT(2) G6T_VARIANT(3) G6T_VARIANT(4) G6T_VARIANT(5) G6T_VARIANT(6) G6T_VARIANT(7) G6T_VARIANT(8) G6T_VARIANT(9) G6T_VARIANT(10) G6T_VARIANT(11) G6T_VARIANT(12)
+        G6T_VARIANT(1) G6T_VARIANT(2) G6T_VARIANT(3) G6T_VARIANT(4) G6T_VARIANT(5) G6T_VARIANT(6) G6T_VARIANT(7) G6T_VARIANT(8) G6T_VARIANT(9) G6T_VARIANT(10) G6T_VARIANT(11) G6T_VARIANT(12) G6T_VARIANT(13)
 #undef G6T_VARIANT
 #endif
 #undef G6T_RUN
@@ -542,6 +542,7 @@ static int gemm_fp6_run(const clm4_gemm_operand *opA, const int8_t *A, const flo
         case 10: G6T_LAUNCH_V(10); break;
         case 11: G6T_LAUNCH_V(11); break;
         case 12: G6T_LAUNCH_V(12); break;
+        case 13: G6T_LAUNCH_V(13); break;
 #endif
         default: G6T_LAUNCH_V(0); break;
         }

@@ -83,6 +83,10 @@ inline void Q_GD(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector4 &x, Clov
 inline void Q_IHT(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector8 &x, CloverVector8 &y, CloverVector8 &t1, CloverVector8 &t2,
                   CloverVector8 &t3, const uint64_t iterations, const uint64_t K, const float mu)
 {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+    Phi.iht_loop(PhiT, x, y, t1, t2, t3, iterations, K, mu, true);
+    return;
+#endif
     x.clear();
     for (uint64_t i = 0; i < iterations; i += 1) {
         Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);
@@ -94,6 +98,10 @@ inline void Q_IHT(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector8 &x, Clo
 inline void Q_GD(CloverMatrix4 &Phi, CloverMatrix4 &PhiT, CloverVector8 &x, CloverVector8 &y, CloverVector8 &t1, CloverVector8 &t2,
                  CloverVector8 &t3, const uint64_t iterations, const float mu)
 {
+#ifdef CLOVER_STOCHASTIC_ROUNDING_DISABLED
+    Phi.iht_loop(PhiT, x, y, t1, t2, t3, iterations, 0, mu, false);
+    return;
+#endif
     x.clear();
     for (uint64_t i = 0; i < iterations; i += 1) {
         Phi.mvm_scaleAndAdd(x, y, -1.0f, t1, t2);

@@ -248,6 +248,23 @@ public:
         x.commit();
         if (iterations) { t1.commit(); t2.commit(); t3.commit(); }
     }
+    /* the same loop with CloverVector8 vectors (clm4_iht_v8): the reference's published "4-bit" IHT / GD configuration (02_bit04.cpp:140) */
+    void iht_loop(CloverMatrix4 &PhiT, CloverVector8 &x, const CloverVector8 &y, CloverVector8 &t1, CloverVector8 &t2, CloverVector8 &t3,
+                  uint64_t iterations, uint64_t K, float mu, bool with_threshold)
+    {
+        if (PhiT.getRows() != getCols() || PhiT.getCols() != getRows() || x.size_pad() != getCols() || y.size_pad() != getRows() ||
+            t1.size_pad() != getRows() || t2.size_pad() != getRows() || t3.size_pad() != getCols()) {
+            std::cout << "MVM can not be performed. Exiting ..." << std::endl;
+            exit(1);
+        }
+        const int thr = !with_threshold ? 0 : (clover_hip::threshold_mode() == CLV_THRESHOLD_FAST ? 1 : 2);
+        clover_hip::check(clm4_iht_v8(dev_values(), dev_scales(), PhiT.dev_values(), PhiT.dev_scales(), rows, cols, x.dev_values_wo(), x.dev_scales_wo(),
+                                      x.size(), y.dev_values_ro(), y.dev_scales_ro(), t1.dev_values_wo(), t1.dev_scales_wo(), t2.dev_values_wo(),
+                                      t2.dev_scales_wo(), t3.dev_values_wo(), t3.dev_scales_wo(), iterations, K, mu, thr, nullptr, nullptr),
+                          "CloverMatrix4::iht_loop");
+        x.commit();
+        if (iterations) { t1.commit(); t2.commit(); t3.commit(); }
+    }
     /* in place: u = quantize(u + a * (this * x)) */
     void mvm_scaleAndAdd(const CloverVector4 &x, CloverVector4 &u, float a, CloverVector4 &t)
     {

@@ -27,6 +27,11 @@ for G in [int(g) for g in os.environ.get("GB_SIZES", "4096,8192").split(",")]:
     fn = lambda: hip.check(lib.clm4_gemm(A.ptr, sA.ptr, G, G, B.ptr, sB.ptr, G, Cc.ptr, None))
     if mode == "i32":
         fn = lambda: hip.check(lib.clm4_gemm_i32(A.ptr, G, G, B.ptr, G, 0, G // 64, Cc.ptr, None))
+    elif mode == "i32prepared":                         # the plain FP6 GEMM: exact int32 sums of ALL K-blocks from cached FP6 images, no fold
+        opA, opB = C.c_void_p(), C.c_void_p()
+        hip.check(lib.clm4_gemm_prepare(A.ptr, G, G, C.byref(opA), None))
+        hip.check(lib.clm4_gemm_prepare(B.ptr, G, G, C.byref(opB), None))
+        fn = lambda: hip.check(lib.clm4_gemm_i32_prepared(opA, None, G, G, opB, None, G, 0, G // 64, Cc.ptr, None))
     elif mode.startswith("prepared"):
         opA, opB = C.c_void_p(), C.c_void_p()
         if mode == "prepared":

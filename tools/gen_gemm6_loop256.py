@@ -318,7 +318,10 @@ EXPERIMENTS = {1: {"dma"}, 2: {"lds"}, 3: {"dma", "lds"}, 4: {"barrier"}, 5: {"f
                8: {"dma", "store"}, 9: {"dma", "lds", "barrier", "store", "salu"}, 10: {"dma", "lds", "store", "salu"},
                # round 4: the bound of the one lever left (128 x 64 wave tiles at two waves per SIMD): what a quarter fewer fragment reads
                # could give at UNCHANGED occupancy (11), and together with a store that costs nothing (12)
-               11: {"lds25"}, 12: {"lds25", "store"}}
+               11: {"lds25"}, 12: {"lds25", "store"},
+               # round 6: the bound of wave specialisation (loader waves issue every LDS-DMA request, the MFMA waves none): 1 = the requests
+               # gone from the MFMA waves' stream, 13 = the requests AND the stage barriers gone (what loader waves could at the very most buy)
+               13: {"dma", "barrier"}}
 
 
 CANDIDATES = {1: {"FOLD": "fmac"}, 2: {"FOLD": "pk"}, 3: {"FOLD": "mixed"}}      # `candidates`: CORRECT alternative schedules in slots v1..
