@@ -1119,7 +1119,7 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
         memcpy(a.jump, jump_kept[0], sizeof(a.jump));
         memcpy(a.jump1, jump_kept[1], sizeof(a.jump1));
     }
-    a.nap0 = 10;         // ~0.3 us: measured best of 0 / 10 / 20 / 30 / 40 at N = 8192 (profiles/r06_iht_persist_notes.txt)
+    a.nap0 = 14;         // ~0.4 us: measured best of 0 / 6 / 10 / 14 / 18 / 22 / 26 ... 40 at N = 8192 (profiles/r06_iht_persist_notes.txt)
     a.nap = 2;
     if (const char *e = getenv("CLV_IHT_NAP0")) a.nap0 = (uint32_t)atoi(e);                             // probe only
     if (const char *e = getenv("CLV_IHT_NAP")) a.nap = (uint32_t)atoi(e);                               // probe only
@@ -1182,7 +1182,7 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
     a.t1 = (uint32_t *)t1; a.st1 = st1; a.t2 = (uint32_t *)t2; a.st2 = st2; a.t3 = (uint32_t *)t3; a.st3 = st3;
     a.iterations = (uint32_t)iterations; a.K = (uint32_t)(K > 0xFFFFFFFFull ? 0xFFFFFFFFull : K); a.mu = mu; a.threshold = threshold;
     a.g1 = (u64 *)ws; a.g2 = (u64 *)ws + m;
-    a.nap0 = 10;
+    a.nap0 = 16;         // best of 6 ... 26 for this kernel at N = 8192
     a.nap = 2;
     if (const char *e = getenv("CLV_IHT_NAP0")) a.nap0 = (uint32_t)atoi(e);                             // probe only
     PersistChain chain(st);
