@@ -1070,8 +1070,12 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     {
         std::lock_guard<std::mutex> lock(attr_mutex);
         if (dev >= 0 && dev < 64 && attr_set[dev] < L.total) {
-            CLV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht4_persist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            CLV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht4_persist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            // a device that does not grant a workgroup 160 KiB of LDS does not run this kernel: the launch-per-step loop takes over
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht4_persist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht4_persist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
             attr_set[dev] = 160u * 1024u;
         }
     }
@@ -1165,7 +1169,10 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
     {
         std::lock_guard<std::mutex> lock(attr_mutex);
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            CLV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht8_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht8_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
             attr_set[dev] = true;
         }
     }
