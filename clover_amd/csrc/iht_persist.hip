@@ -20,6 +20,7 @@
 #include "rng_device.h"
 #include "thresh_device.h"
 
+#include <atomic>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
 struct Ihtp8Layout {
     uint32_t GB1, GB2;            // groups of 4 blocks of Phi's / PhiT's rows
     uint32_t offA1, offA2, offX, offT, offC1, offC2, offP1, offP2, offHist, offHsum, offWtot, offPub, total;
+    uint32_t raw1_bytes, raw2_bytes, raw1_room, raw2_room;      // stochastic: the phases' raw draws and the regions they overlay
 };
 __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2)
 {
@@ -656,16 +658,23 @@ __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint
     L.offA1 = o; o += R1 * L.GB1 * 128;                                 // [row][group][chain][4 blocks] words
     L.offA2 = o; o += R2 * L.GB2 * 128;
     L.offX = o; o += 3 * L.GB1 * 128;                                   // x: the high / carry / low nibble images, [group][chain][4 blocks]
+    // t2's images, the radix bins and their sums lie side by side: with stochastic rounding the second vector phase's raw draws overlay all
+    // three (t2 is dead behind the second row dots, the bins are cleared again in front of the threshold), the first phase's overlay x's
+    // images (dead between the first row dots and the end of the iteration): at N = 8192 there is no LDS left for buffers of their own
     L.offT = o; o += 3 * L.GB2 * 128;                                   // t2 likewise
+    L.offHist = o; o += 8 * 256 * 4;                                    // one radix level, 8 copies
+    L.offHsum = o; o += 2 * 256 * 4;
     L.offC1 = o; o += L.GB1 * 16;                                       // c_b, [group][4 blocks]
     L.offC2 = o; o += L.GB2 * 16;
     L.offP1 = o; o += L.GB1 * 16;                                       // f32(sA_b / 7)
     L.offP2 = o; o += L.GB2 * 16;
-    L.offHist = o; o += 8 * 256 * 4;                                    // one radix level, 8 copies
-    L.offHsum = o; o += 2 * 256 * 4;
     L.offWtot = o; o += 64;
     L.offPub = o; o += 64 * 4;
     L.total = o + 256;                                                  // the dot loop reads one group past an array's end
+    L.raw1_bytes = ((m / 64 + 3) / 4) * 16 * 32;
+    L.raw2_bytes = ((n / 64 + 3) / 4) * 16 * 32;
+    L.raw1_room = 3 * L.GB1 * 128;
+    L.raw2_room = 3 * L.GB2 * 128 + 8 * 256 * 4 + 2 * 256 * 4;
     return L;
 }
 __device__ __forceinline__ uint32_t dealt8(uint32_t b, uint32_t L) { return ((b >> 2) * 8 + L) * 4 + (b & 3); }
@@ -776,8 +785,13 @@ __device__ __forceinline__ void ihtp8_store_images(uint32_t *X, uint32_t xs, uin
 }
 
 // r = quantize8(d), o = quantize8(u + a r) for the thread's 8 elements (k_m4_mvm8's fused epilogue, mixed8.hip: CloverMatrix4.h:1246-1440,
-// CloverVector8.h:1089-1358); u = the thread's two words of u
-__device__ __forceinline__ void ihtp8_requant_saa(const float d[8], const uint32_t uw[2], float us, float a, int q[8], float &rs, int q2[8], float &os)
+// CloverVector8.h:1089-1358); u = the thread's two words of u.  ST: thread i of the block's 8 (elements l = 8 i + e) takes, for the mvm's
+// re-quantisation, byte i & 3 of word e of the block's draw i >> 2 (noise group g = l >> 3, word l & 7: CloverMatrix4.h:1246-1440) and,
+// for scaleAndAdd, byte e & 3 of word 2 (i & 3) + (e >> 2) of its draw i >> 2 (element l: draw l >> 5, word (l & 31) >> 2, byte l & 3:
+// CloverVector8.h:1104-1126).  Wm = the 8 words of the mvm draw, Ws = the two words of the scaleAndAdd draw.
+template <bool ST>
+__device__ __forceinline__ void ihtp8_requant_saa(const float d[8], const uint32_t uw[2], float us, float a, uint32_t i, const uint32_t Wm[8],
+                                                  const uint32_t Ws[2], int q[8], float &rs, int q2[8], float &os)
 {
     float mx = 0.0f;
 #pragma unroll
@@ -785,7 +799,7 @@ __device__ __forceinline__ void ihtp8_requant_saa(const float d[8], const uint32
     rs = fix_zero_max(group8_max(mx));
     const float k = 127.0f / rs;
 #pragma unroll
-    for (int e = 0; e < 8; e++) q[e] = quant1(d[e], k, 0.0f);
+    for (int e = 0; e < 8; e++) q[e] = quant1(d[e], k, ST ? noise_of(Wm[e], (int)(i & 3u)) : 0.0f);
     const float su127 = div127(us), sv127 = div127(rs * a);
     float val[8], m2 = 0.0f;
 #pragma unroll
@@ -797,7 +811,7 @@ __device__ __forceinline__ void ihtp8_requant_saa(const float d[8], const uint32
     os = fix_zero_max(group8_max(m2));
     const float k2 = 127.0f / os;
 #pragma unroll
-    for (int e = 0; e < 8; e++) q2[e] = quant1(val[e], k2, 0.0f);
+    for (int e = 0; e < 8; e++) q2[e] = quant1(val[e], k2, ST ? noise_of(Ws[e >> 2], e & 3) : 0.0f);
 }
 __device__ __forceinline__ uint32_t pack4_i8(const int q[4]) { return ((uint32_t)q[0] & 0xFFu) | (((uint32_t)q[1] & 0xFFu) << 8) | (((uint32_t)q[2] & 0xFFu) << 16) | ((uint32_t)q[3] << 24); }
 
@@ -890,8 +904,13 @@ struct Ihtp8Args {
     int threshold;
     u64 *g1, *g2;
     uint32_t nap0, nap;
+    u64 *rng;                     // stochastic rounding (k_iht8_persist<true>): as IhtpArgs
+    u64 seq;
+    const u64 *seg_rows;
+    u64 jump[64], jump1[64];
 };
 
+template <bool ST>
 __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -931,6 +950,23 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
     const float ys = own_m ? A.sy[tid0 >> 3] : 1.0f;
     uint32_t xw[2] = {0u, 0u};
     float xs = 1.0f;
+    // stochastic: generator lanes as in k_iht4_persist (the last 4 * segs threads of a phase, 16 draws each, one GF(2) jump per iteration); the
+    // draws of the first phase go where x's images lie (dead behind the first row dots), the second phase's where t2's images and the radix
+    // bins lie (dead behind the second row dots / cleared again in front of the threshold)
+    const uint32_t G1 = m / 64, G2 = n / 64, segs1 = (G1 + 3) / 4, segs2 = (G2 + 3) / 4;
+    const int gi1 = ST ? (int)tid0 - (int)(IHTP_THREADS - 4 * segs1) : -1, gi2 = ST ? (int)tid0 - (int)(IHTP_THREADS - 4 * segs2) : -1;
+    u64 ga = 0, gb = 0;
+    int rng_slot = 0;
+    u64 *raw1 = reinterpret_cast<u64 *>(X), *raw2 = reinterpret_cast<u64 *>(T);
+    if (ST) {
+        const u64 seq = rng_effective_seq(A.rng, A.seq);
+        rng_slot = rng_read_slot(A.rng, seq);
+        if (gi1 >= 0) ga = ihtp_rows_matvec(A.seg_rows + (size_t)(gi1 >> 2) * 64, A.rng[rng_slot * RNG_SLOT_WORDS + 4 + (gi1 & 3)]);
+        if (gi2 >= 0) {
+            gb = ihtp_rows_matvec(A.seg_rows + (size_t)((gi2 >> 2) + ((4 * G1) >> 4)) * 64, A.rng[rng_slot * RNG_SLOT_WORDS + 4 + (gi2 & 3)]);
+            for (uint32_t z = 0; z < ((4 * G1) & 15u); z++) gb = xs_T(gb);
+        }
+    }
     __syncthreads();
 
     for (uint32_t it = 0; it < A.iterations; it++) {
@@ -948,14 +984,33 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         if (has1 && tid < A.R1)
             __hip_atomic_store((gu64 *)A.g1 + unit_slot(u1 + (tid >> 4), tid & 15, m), ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        if (ST && gi1 >= 0) {                                            // behind the row dots: x's images are dead until the end of the iteration
+            ga = ihtp_gen16(ga, raw1, (uint32_t)gi1 >> 2, (uint32_t)gi1 & 3u);
+            if (last && g == 0 && gi1 < 4) {
+                u64 *next = A.rng + (rng_slot ^ 1) * RNG_SLOT_WORDS;
+                const u64 f = ihtp_cols_matvec(A.jump1, ga);
+                next[gi1] = f;
+                next[4 + gi1] = xs_T(f);
+            }
+            ga = ihtp_cols_matvec(A.jump, ga);
+        }
         // ---- E1 ----
-        if ((tid & ~63u) < m / 8) {
-            float d[8];
-            ihtp_gather8(A.g1, m, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
+        float d[8];
+        if ((tid & ~63u) < m / 8) ihtp_gather8(A.g1, m, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
+        if (ST) __syncthreads();                                         // the first phase's draws are in LDS
+        {
             if (tid < m / 8) {
                 int q1[8], q2[8];
                 float t1s, t2s;
-                ihtp8_requant_saa(d, yw, ys, -1.0f, q1, t1s, q2, t2s);
+                uint32_t Wm[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Ws[2] = {0u, 0u};
+                if (ST) {
+                    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(raw1), b = tid >> 3, i = tid & 7u;
+                    const u32x4 w0 = *reinterpret_cast<const u32x4 *>(r32 + (2 * b + (i >> 2)) * 8), w1 = *reinterpret_cast<const u32x4 *>(r32 + (2 * b + (i >> 2)) * 8 + 4);
+                    Wm[0] = w0.x; Wm[1] = w0.y; Wm[2] = w0.z; Wm[3] = w0.w; Wm[4] = w1.x; Wm[5] = w1.y; Wm[6] = w1.z; Wm[7] = w1.w;
+                    Ws[0] = r32[(2 * G1 + 2 * b + (i >> 2)) * 8 + 2 * (i & 3u)];
+                    Ws[1] = r32[(2 * G1 + 2 * b + (i >> 2)) * 8 + 2 * (i & 3u) + 1];
+                }
+                ihtp8_requant_saa<ST>(d, yw, ys, -1.0f, tid & 7u, Wm, Ws, q1, t1s, q2, t2s);
                 ihtp8_store_images(T, XS2, tid >> 3, tid & 7, q2);
                 if ((tid & 7) == 0) c2[tid >> 3] = p2[tid >> 3] * (t2s * (1.0f / 127.0f));
                 if (last && g == 0) {
@@ -981,10 +1036,31 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         float t3s = 1.0f;
 #pragma unroll
         for (int e = 0; e < 8; e++) q3[e] = qx[e] = 0;
-        if ((tid & ~63u) < n / 8) {
+        if (ST && gi2 >= 0) {                                            // behind the second row dots: t2's images and the bins are dead
+            gb = ihtp_gen16(gb, raw2, (uint32_t)gi2 >> 2, (uint32_t)gi2 & 3u);
+            gb = ihtp_cols_matvec(A.jump, gb);
+        }
+        {
             float d[8];
-            ihtp_gather8(A.g2, n, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
-            if (tid < n / 8) ihtp8_requant_saa(d, xw, xs, A.mu, q3, t3s, qx, xs);
+            if ((tid & ~63u) < n / 8) ihtp_gather8(A.g2, n, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
+            if (ST) __syncthreads();                                     // the second phase's draws are in LDS
+            if (tid < n / 8) {
+                uint32_t Wm[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Ws[2] = {0u, 0u};
+                if (ST) {
+                    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(raw2), b = tid >> 3, i = tid & 7u;
+                    const u32x4 w0 = *reinterpret_cast<const u32x4 *>(r32 + (2 * b + (i >> 2)) * 8), w1 = *reinterpret_cast<const u32x4 *>(r32 + (2 * b + (i >> 2)) * 8 + 4);
+                    Wm[0] = w0.x; Wm[1] = w0.y; Wm[2] = w0.z; Wm[3] = w0.w; Wm[4] = w1.x; Wm[5] = w1.y; Wm[6] = w1.z; Wm[7] = w1.w;
+                    Ws[0] = r32[(2 * G2 + 2 * b + (i >> 2)) * 8 + 2 * (i & 3u)];
+                    Ws[1] = r32[(2 * G2 + 2 * b + (i >> 2)) * 8 + 2 * (i & 3u) + 1];
+                }
+                ihtp8_requant_saa<ST>(d, xw, xs, A.mu, tid & 7u, Wm, Ws, q3, t3s, qx, xs);
+            }
+        }
+        if (ST) {                                                        // the draws lay over the radix bins: clear those again
+            __syncthreads();
+            hist[tid] = 0;
+            hist[IHTP_THREADS + tid] = 0;
+            __syncthreads();
         }
         if (A.threshold && A.K < A.x_len) ihtp8_threshold(qx, xs, tid, A.x_len, A.K, hist, hsum, wtot);
         if (tid < n / 8) {
@@ -1000,9 +1076,18 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         }
         __syncthreads();
     }
+    if (ST && g == 0) {                                                  // stamp the slot written in the last iteration (rng_device.h: rng_commit)
+        if (tid0 == IHTP_THREADS - 4 * segs1) {
+            __threadfence();
+            A.rng[(rng_slot ^ 1) * RNG_SLOT_WORDS + RNG_STAMP_WORD] = rng_effective_seq(A.rng, A.seq);
+        }
+    }
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_persist_launches{0};
+extern "C" uint64_t clv_iht_persistent_launches(void) { return g_persist_launches.load(std::memory_order_relaxed); }
+
 static uint32_t pow2_ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 // Persistent launches need every workgroup resident at once: two of them on one device at the same time (two streams) could each hold
@@ -1042,6 +1127,36 @@ struct PersistChain {
         return CLV_OK;
     }
 };
+
+// stochastic rounding: an iteration draws D values per generator lane; a lane that has produced its segment of 16 jumps on by T^(D - 16)
+// (T^(D - 17) towards the state the call leaves behind).  Column form, by square and multiply on the host (64 x 64 bits: microseconds)
+static int ihtp_jump_matrices(uint64_t D, const u64 **seg_rows, u64 *jump, u64 *jump1)
+{
+    RngTables T;
+    if (clv_rng_tables(&T)) return -1;
+    *seg_rows = T.seg_rows;
+    auto power = [](uint64_t e, u64 *out) {
+        u64 sq[64], tmp[64];
+        for (int i = 0; i < 64; i++) { sq[i] = xs_T(1ull << i); out[i] = 1ull << i; }
+        for (; e; e >>= 1) {
+            if (e & 1) { for (int i = 0; i < 64; i++) tmp[i] = gf2_matvec(sq, out[i]); for (int i = 0; i < 64; i++) out[i] = tmp[i]; }
+            for (int i = 0; i < 64; i++) tmp[i] = gf2_matvec(sq, sq[i]);
+            for (int i = 0; i < 64; i++) sq[i] = tmp[i];
+        }
+    };
+    static std::mutex jump_mutex;                                         // the last D's matrices are kept: ~40 us of host time per call otherwise
+    static uint64_t jump_D = 0;
+    static u64 jump_kept[2][64];
+    std::lock_guard<std::mutex> lock(jump_mutex);
+    if (jump_D != D) {
+        power(D - 16, jump_kept[0]);
+        power(D - 17, jump_kept[1]);
+        jump_D = D;
+    }
+    memcpy(jump, jump_kept[0], 64 * sizeof(u64));
+    memcpy(jump1, jump_kept[1], 64 * sizeof(u64));
+    return 0;
+}
 
 // returns 1 if the persistent kernel was launched, 0 if the problem does not qualify (the caller runs the launch-per-step loop), < 0 on error
 int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n, int8_t *x,
@@ -1097,31 +1212,7 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
     a.seq = 0;
     a.seg_rows = nullptr;
     if (rng) {
-        // T^(D - 16) and T^(D - 17), column form, by square and multiply on the host (64 x 64 bits: microseconds)
-        RngTables T;
-        if (clv_rng_tables(&T)) return -1;
-        a.seg_rows = T.seg_rows;
-        const uint64_t D = (m + n) / 64 * 4;
-        auto power = [](uint64_t e, u64 *out) {
-            u64 sq[64], tmp[64];
-            for (int i = 0; i < 64; i++) { sq[i] = xs_T(1ull << i); out[i] = 1ull << i; }
-            for (; e; e >>= 1) {
-                if (e & 1) { for (int i = 0; i < 64; i++) tmp[i] = gf2_matvec(sq, out[i]); for (int i = 0; i < 64; i++) out[i] = tmp[i]; }
-                for (int i = 0; i < 64; i++) tmp[i] = gf2_matvec(sq, sq[i]);
-                for (int i = 0; i < 64; i++) sq[i] = tmp[i];
-            }
-        };
-        static std::mutex jump_mutex;                                     // the last D's matrices are kept: ~40 us of host time per call otherwise
-        static uint64_t jump_D = 0;
-        static u64 jump_kept[2][64];
-        std::lock_guard<std::mutex> lock(jump_mutex);
-        if (jump_D != D) {
-            power(D - 16, jump_kept[0]);
-            power(D - 17, jump_kept[1]);
-            jump_D = D;
-        }
-        memcpy(a.jump, jump_kept[0], sizeof(a.jump));
-        memcpy(a.jump1, jump_kept[1], sizeof(a.jump1));
+        if (ihtp_jump_matrices((m + n) / 64 * 4, &a.seg_rows, a.jump, a.jump1)) return -1;
     }
     a.nap0 = 14;         // ~0.4 us: measured best of 0 / 6 / 10 / 14 / 18 / 22 / 26 ... 40 at N = 8192 (profiles/r06_iht_persist_notes.txt)
     a.nap = 2;
@@ -1142,6 +1233,7 @@ int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT
         clv_set_error("clm4_iht: persistent launch failed: %s", hipGetErrorString(e));
         return -1;
     }
+    g_persist_launches.fetch_add(1, std::memory_order_relaxed);
     return 1;
 }
 
@@ -1151,7 +1243,8 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
                            uint64_t iterations, uint64_t K, float mu, int threshold, uint64_t *rng, hipStream_t st)
 {
     const int mode = [] { const char *e = getenv("CLV_IHT_PERSISTENT"); return e ? atoi(e) : 1; }();
-    if (!mode || rng || threshold < 0 || threshold > 1 || !iterations || iterations >= 0x7FFFFFFFull) return 0;
+    if (!mode || threshold < 0 || threshold > 1 || !iterations || iterations >= 0x7FFFFFFFull) return 0;
+    if (rng && (m + n) / 64 * 4 < 32) return 0;
     if (m > IHTP_MAXLEN || n > IHTP_MAXLEN || m % 128 || n % 128 || !m || !n) return 0;
     const int cus = clv_cu_count();
     uint32_t R1 = pow2_ceil((uint32_t)((m + cus - 1) / cus)), R2 = pow2_ceil((uint32_t)((n + cus - 1) / cus));
@@ -1160,6 +1253,9 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
     if (R1 > 64 || R2 > 64) return 0;
     const Ihtp8Layout L = ihtp8_layout((uint32_t)m, (uint32_t)n, R1, R2);
     if (L.total > 160u * 1024u) return 0;
+    // stochastic: the raw draws overlay LDS regions that are dead while they are needed (ihtp8_layout); a shape whose draws do not fit there
+    // (the first phase's where m > 0.75 n: gradient descent's 1.5 : 1 systems) runs the launch-per-step loop
+    if (rng && (L.raw1_bytes > L.raw1_room || L.raw2_bytes > L.raw2_room)) return 0;
     const uint32_t grid = (uint32_t)((m / R1 > n / R2) ? m / R1 : n / R2);
     if ((int)grid > cus) return 0;
     static std::mutex attr_mutex;
@@ -1169,7 +1265,8 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
     {
         std::lock_guard<std::mutex> lock(attr_mutex);
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht8_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht8_persist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(k_iht8_persist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 (void)hipGetLastError();
                 return 0;
             }
@@ -1192,13 +1289,23 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
     a.nap0 = 16;         // best of 6 ... 26 for this kernel at N = 8192
     a.nap = 2;
     if (const char *e = getenv("CLV_IHT_NAP0")) a.nap0 = (uint32_t)atoi(e);                             // probe only
+    a.rng = rng;
+    a.seq = 0;
+    a.seg_rows = nullptr;
+    if (rng && ihtp_jump_matrices((m + n) / 64 * 4, &a.seg_rows, a.jump, a.jump1)) return -1;
     PersistChain chain(st);
     if (chain.rc) return -1;
-    hipLaunchKernelGGL(k_iht8_persist, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
+    if (rng) {
+        a.seq = clv_rng_seq_for(rng, st);
+        hipLaunchKernelGGL(k_iht8_persist<true>, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
+    } else {
+        hipLaunchKernelGGL(k_iht8_persist<false>, dim3(grid), dim3(IHTP_THREADS), L.total, st, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         clv_set_error("clm4_iht_v8: persistent launch failed: %s", hipGetErrorString(e));
         return -1;
     }
+    g_persist_launches.fetch_add(1, std::memory_order_relaxed);
     return 1;
 }

@@ -76,6 +76,7 @@ SIGNATURES = {
     "clv8_threshold_mode": (C.c_int, [_vp, _vp, _u64, _u64, _u64, C.c_int, _vp, _vp]),
     "clm4_mvm_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clm4_mvm_v8_scale_and_add": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clv_iht_persistent_launches": (_u64, []),
     "clm4_iht_v8": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, C.c_float,
                               C.c_int, _vp, _vp]),
     "clm4_rowdots_v8": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),

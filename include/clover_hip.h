@@ -238,6 +238,9 @@ int  clm4_iht_v8(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const
                  int8_t *x, float *sx, uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1,
                  int8_t *t2, float *st2, int8_t *t3, float *st3, uint64_t iterations, uint64_t K, float mu, int threshold,
                  uint64_t *rng_state_dev, void *stream);
+/* diagnostic: the number of clm4_iht / clm4_iht_v8 calls of this process that ran as ONE persistent launch (iht_persist.hip) rather than
+ * as the launch-per-step loop -- what a test or a benchmark reads to know which of the two it measured. */
+uint64_t clv_iht_persistent_launches(void);
 /* the fp32 row dots of that mvm before re-quantisation: d[rows] (CloverMatrix4.h:1120-1243) */
 int  clm4_rowdots_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t cols, const int8_t *x, const float *sx,
                      float *d, void *stream);

@@ -41,21 +41,28 @@ def problem8(m, n, seed):
     return mat, [vec8(n, seed + 2), vec8(m, seed + 4), vec8(m, seed + 6), vec8(m, seed + 8), vec8(n, seed + 10)]
 
 
-def run8(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent):
+def run8(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent, seed=None):
     os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
     x, y, t1, t2, t3 = vecs
+    rng = hip.new_rng(*seed) if seed else None
     for v in (x, t1, t2, t3):
         hip.check(lib.clv_memset(v[0].ptr, 0x5A, v[0].nbytes, None))
         hip.check(lib.clv_memset(v[1].ptr, 0x3C, v[1].nbytes, None))
     hip.check(lib.clm4_iht_v8(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, x_len, y[0].ptr, y[1].ptr, t1[0].ptr, t1[1].ptr,
-                              t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, mu, thr, None, None))
+                              t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, mu, thr, rng.ptr if rng else None, None))
     hip.sync()
-    return [np.concatenate([v[0].download(np.uint8, v[0].nbytes), v[1].download(np.uint8, v[1].nbytes)]) for v in (x, t1, t2, t3)]
+    out = [np.concatenate([v[0].download(np.uint8, v[0].nbytes), v[1].download(np.uint8, v[1].nbytes)]) for v in (x, t1, t2, t3)]
+    if rng:
+        k1, k2 = hip.rng_get(rng)
+        out.append(np.concatenate([np.asarray(k1, np.uint64), np.asarray(k2, np.uint64)]).view(np.uint8))
+    return out
 
 
-def check8():
+def check8(seed=None):
     bad = 0
-    cases = [(128, 128), (256, 512), (384, 640), (640, 384), (1024, 2048), (2048, 4096), (4096, 8192), (6144, 4096), (8192, 1024), (128, 8192)]
+    taken = 0
+    cases = [(128, 128), (256, 512), (384, 640), (640, 384), (1024, 2048), (2048, 4096), (4096, 8192), (6144, 4096), (8192, 1024), (128, 8192),
+             (1536, 2048), (3072, 4096), (6144, 8192), (2176, 4224), (3968, 8064), (4096, 7680), (2048, 8192)]
     for (m, n) in cases:
         mat, vecs = problem8(m, n, 300 + m + n)
         for thr in (1, 0):
@@ -63,30 +70,34 @@ def check8():
                 if thr == 0 and K != n // 4:
                     continue
                 for mu in (1e-3, 0.05):
-                    a = run8(mat, vecs, m, n, x_len, iters, K, mu, thr, True)
-                    b = run8(mat, vecs, m, n, x_len, iters, K, mu, thr, False)
+                    c0 = lib.clv_iht_persistent_launches()
+                    a = run8(mat, vecs, m, n, x_len, iters, K, mu, thr, True, seed)
+                    p = lib.clv_iht_persistent_launches() - c0
+                    taken += p
+                    b = run8(mat, vecs, m, n, x_len, iters, K, mu, thr, False, seed)
                     ok = all(np.array_equal(u, v) for u, v in zip(a, b))
                     if not ok:
                         bad += 1
-                        which = [(nm, int(np.flatnonzero(u != v)[0]), int((u != v).sum())) for nm, u, v in zip(("x", "t1", "t2", "t3"), a, b) if not np.array_equal(u, v)]
-                        print(f"MISMATCH v8 m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu}: {which}")
+                        which = [(nm, int(np.flatnonzero(u != v)[0]), int((u != v).sum())) for nm, u, v in zip(("x", "t1", "t2", "t3", "rng state"), a, b) if not np.array_equal(u, v)]
+                        print(f"MISMATCH v8 m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu} persistent={p}: {which}")
                     else:
-                        print(f"ok v8 m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu} (nonzero x bytes {int((a[0][:n] != 0).sum())})")
-    print("CHECK v8", "FAILED" if bad else "PASSED", bad)
+                        print(f"ok v8 m={m} n={n} thr={thr} x_len={x_len} K={K} iters={iters} mu={mu} persistent={p} (nonzero x bytes {int((a[0][:n] != 0).sum())})")
+    print("CHECK v8", "stochastic" if seed else "deterministic", "FAILED" if bad else "PASSED", bad, "persistent launches", taken)
     return bad
 
 
-def timing8(Ns):
+def timing8(Ns, seed=None):
     for N in Ns:
         m, n = N // 2, N
         mat, vecs = problem8(m, n, 31)
         x, y, t1, t2, t3 = vecs
+        rng = hip.new_rng(*seed) if seed else None
         for persistent in (0, 1):
             os.environ["CLV_IHT_PERSISTENT"] = str(persistent)
             for thr, K in ((1, n // 4), (0, 0)):
                 def call(iters):
                     hip.check(lib.clm4_iht_v8(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr,
-                                              t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, 1e-3, thr, None, None))
+                                              t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, iters, K, 1e-3, thr, rng.ptr if rng else None, None))
                     hip.sync()
                 call(10)
                 res = {}
@@ -97,7 +108,7 @@ def timing8(Ns):
                         call(iters)
                         best = min(best, time.perf_counter() - t0)
                     res[iters] = best
-                print(f"v8 N={N} persistent={persistent} thr={thr} K={K}: {(res[1000] - res[100]) / 900 * 1e6:.2f} us/iteration", flush=True)
+                print(f"v8 {'stochastic ' if seed else ''}N={N} persistent={persistent} thr={thr} K={K}: {(res[1000] - res[100]) / 900 * 1e6:.2f} us/iteration", flush=True)
 
 
 def run(mat, vecs, m, n, x_len, iters, K, mu, thr, persistent, seed=None):
@@ -223,8 +234,12 @@ if __name__ == "__main__":
         rc = check()
     if "check8" in args:
         rc = check8()
+    if "check8_st" in args:
+        rc = check8(seed=(2468, 1357)) or rc
     if "time8" in args:
         timing8([int(a) for a in args if a.isdigit()] or [256, 4096, 8192])
+    if "time8_st" in args:
+        timing8([int(a) for a in args if a.isdigit()] or [256, 4096, 8192], seed=(5, 6))
     if "check_st" in args:
         rc = check(seed=(12345, 67890))
     if "stamps" in args:
