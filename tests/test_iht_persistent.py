@@ -144,13 +144,19 @@ def test_persistent_threshold_on_clustered_magnitudes(hip, oracle, seed):
             assert same(a[name], b[name]), (name, K, mu)
 
 
-@pytest.mark.parametrize("shape", [(128, 128), (256, 512), (384, 640), (640, 384), (2048, 4096), (4096, 8192), (6144, 4096), (128, 8192), (8192, 128)])
-def test_persistent_v8_equals_launch_per_step(hip, oracle, shape):
+@pytest.mark.parametrize("rounding", ["deterministic", "stochastic"])
+@pytest.mark.parametrize("shape", [(128, 128), (256, 512), (384, 640), (640, 384), (2048, 4096), (4096, 8192), (6144, 4096), (128, 8192), (8192, 128),
+                                   (3072, 4096), (3968, 8064)])
+def test_persistent_v8_equals_launch_per_step(hip, oracle, shape, rounding):
     """clm4_iht_v8 -- CloverMatrix4 with CloverVector8 vectors, the reference's published "4-bit" IHT / GD (02_bit04.cpp:140) -- as one
     persistent launch (k_iht8_persist: matrix words re-dealt per fma chain, three nibble images of the int8 vector, v_dot8_i32_i4) against
     its launch-per-step loop (k_m4_mvm8 + k_thresh8_small): x, t1, t2, t3 and their scales, every bit.  (The oracle-loop comparison of
-    tests/test_mixed8.py runs through the persistent kernel as well: its sizes qualify.)"""
+    tests/test_mixed8.py runs through the persistent kernel as well: its sizes qualify.)  Stochastic: the same XORShift stream, draw for
+    draw (two draws per 64-element block for each re-quantisation, mvm's in front of scaleAndAdd's: CloverMatrix4.h:1246-1440,
+    CloverVector8.h:1104-1126), and the state the call leaves behind; the draws live in LDS that is dead while they are needed, so shapes
+    whose draws do not fit there (m > 0.75 n) take the launch-per-step loop -- the counter says which ran."""
     m, n = shape
+    seed = (777 + m, 999 + n) if rounding == "stochastic" else None
     rng = np.random.default_rng(300 + m + n)
     qPhi, _ = random_packed(rng, m * n)
     sPhi = rng.uniform(0.5, 2, size=(m // 64) * (n // 64)).astype(np.float32)
@@ -164,18 +170,31 @@ def test_persistent_v8_equals_launch_per_step(hip, oracle, shape):
 
     def run(iters, K, mu, thr, x_len, persistent):
         os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
+        rng = hip.new_rng(*seed) if seed else None
         for v in b.values():
             hip.check(hip.lib.clv_memset(v.ptr, 0x5A, v.nbytes, None))
         hip.check(hip.lib.clm4_iht_v8(d["Phi"].ptr, d["sPhi"].ptr, d["PhiT"].ptr, d["sPhiT"].ptr, m, n, b["x"].ptr, b["sx"].ptr, x_len, d["y"].ptr, d["sy"].ptr,
-                                      b["t1"].ptr, b["st1"].ptr, b["t2"].ptr, b["st2"].ptr, b["t3"].ptr, b["st3"].ptr, iters, K, float(mu), thr, None, None))
+                                      b["t1"].ptr, b["st1"].ptr, b["t2"].ptr, b["st2"].ptr, b["t3"].ptr, b["st3"].ptr, iters, K, float(mu), thr,
+                                      rng.ptr if rng else None, None))
         hip.sync()
-        return {k: b[k].download(np.uint8, sz) for k, sz in sizes.items()}
+        out = {k: b[k].download(np.uint8, sz) for k, sz in sizes.items()}
+        if rng:
+            k1, k2 = hip.rng_get(rng)
+            out["rng"] = np.concatenate([np.asarray(k1, np.uint64), np.asarray(k2, np.uint64)])
+        return out
 
-    for thr, x_len, K, iters, mu in [(1, n, n // 4, 5, 1e-3), (1, n - 37, n // 8 + 3, 3, 0.05), (1, n, 0, 2, 1e-3), (1, n, n, 2, 1e-3), (1, n, 1, 4, 0.05),
-                                     (0, n, 0, 4, 1e-3), (1, n, n // 2, 3, 0.5)]:
+    # which shapes the persistent kernel takes: everything deterministic; stochastic where both phases' draws fit their overlays
+    groups1, groups2 = -(-(n // 64) // 4), -(-(m // 64) // 4)
+    fits = (-(-(m // 64) // 4)) * 512 <= 3 * groups1 * 128 and (-(-(n // 64) // 4)) * 512 <= 3 * groups2 * 128 + 10240
+    expect_persistent = seed is None or fits
+    launches = hip.lib.clv_iht_persistent_launches()
+    cases = [(1, n, n // 4, 5, 1e-3), (1, n - 37, n // 8 + 3, 3, 0.05), (1, n, 0, 2, 1e-3), (1, n, n, 2, 1e-3), (1, n, 1, 4, 0.05), (0, n, 0, 4, 1e-3),
+             (1, n, n // 2, 3, 0.5)]
+    for thr, x_len, K, iters, mu in cases:
         a_, b_ = run(iters, K, mu, thr, x_len, True), run(iters, K, mu, thr, x_len, False)
         for name in a_:
             assert same(a_[name], b_[name]), (name, thr, x_len, K, iters, mu)
+    assert hip.lib.clv_iht_persistent_launches() - launches == (len(cases) if expect_persistent else 0)
     os.environ.pop("CLV_IHT_PERSISTENT", None)
 
 
@@ -232,3 +251,16 @@ def test_persistent_is_the_path_taken(hip, oracle):
         P.run(200, n // 4, 1e-3, 1, persistent=persistent)
         times[persistent] = time.perf_counter() - t0
     assert times[True] < 0.8 * times[False], times
+
+
+def test_persistent_launch_counter(hip, oracle):
+    """clv_iht_persistent_launches counts exactly the calls that ran as one persistent launch: qualifying calls with the switch on"""
+    P = Problem(hip, oracle, 512, 1024, 11)
+    c0 = hip.lib.clv_iht_persistent_launches()
+    P.run(3, 256, 1e-3, 1, persistent=True)
+    P.run(3, 256, 1e-3, 1, persistent=True, seed=(3, 4))
+    assert hip.lib.clv_iht_persistent_launches() == c0 + 2
+    P.run(3, 256, 1e-3, 1, persistent=False)
+    P.run(3, 256, 1e-3, 2, persistent=True)                        # REFERENCE threshold mode: the launch-per-step loop
+    assert hip.lib.clv_iht_persistent_launches() == c0 + 2
+    os.environ.pop("CLV_IHT_PERSISTENT", None)

@@ -47,7 +47,9 @@ for case in range(count):
     while (m * n) > 4096 * 8192:                               # beyond what 256 CUs hold: make it smaller rather than test the fall-back only
         m = max(128, m // 2 // 128 * 128)
     v8 = rng.random() < 0.3
-    st = (not v8) and rng.random() < 0.4
+    st = rng.random() < 0.4
+    if v8 and st and 4 * m > 3 * n and rng.random() < 0.7:    # v8 stochastic keeps its draws in dead LDS: m <= 0.75 n or the loop runs launch by launch
+        m = max(128, int(rng.integers(1, max(2, 3 * n // 4 // 128 + 1))) * 128)
     kind = str(rng.choice(["uniform", "cluster", "sparse", "scales", "equal"]))
     thr = int(rng.random() < 0.8)
     iters = int(rng.integers(1, 7))
@@ -75,6 +77,7 @@ for case in range(count):
     outs = []
     for persistent in (1, 0):
         os.environ["CLV_IHT_PERSISTENT"] = str(persistent)
+        c0 = lib.clv_iht_persistent_launches()
         rs = hip.new_rng(seed0 + case, 77) if st else None
         for v in b.values():
             hip.check(lib.clv_memset(v.ptr, 0x5A, v.nbytes, None))
@@ -86,9 +89,11 @@ for case in range(count):
             k1, k2 = hip.rng_get(rs)
             o["rng"] = np.concatenate([np.asarray(k1, np.uint64), np.asarray(k2, np.uint64)]).view(np.uint8)
         outs.append(o)
+        if persistent and lib.clv_iht_persistent_launches() == c0:
+            fell_back += 1
     diff = [k for k in outs[0] if not np.array_equal(outs[0][k], outs[1][k])]
     if diff:
         bad += 1
         print(f"MISMATCH seed={seed0 + case} m={m} n={n} v8={v8} st={st} kind={kind} thr={thr} iters={iters} x_len={x_len} K={K} mu={mu}: {diff}", flush=True)
-print(f"fuzz_iht_persist: {count} cases from seed {seed0}, {bad} mismatches")
+print(f"fuzz_iht_persist: {count} cases from seed {seed0}, {bad} mismatches, {fell_back} not eligible for the persistent kernel")
 sys.exit(1 if bad else 0)
