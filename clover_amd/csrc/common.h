@@ -45,6 +45,14 @@ int clv_cu_count();
 // grow-only per-device scratch buffer used when the caller passes workspace == NULL
 int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream);      // grow-only scratch per (device, stream)
 void clv_internal_workspace_forget(hipStream_t stream);
+// the zero-initialised hand-over memory of a (device, stream), clv_internal_sync_slots: the single-launch reductions (dot_common.h) use the
+// first 64 KiB, the large-vector threshold's control block (threshold4.hip) lies behind them; every user leaves its part all zero
+#define CLV_SYNC_SLOT_BYTES_TOTAL (128u << 10)
+#define CLV_SYNC_SLOT_THRESHOLD_OFFSET (64u << 10)
+// persistent launches (workgroups that wait for each other) run one at a time per device: enter chains the stream behind the previous such
+// launch and holds the chain's lock until leave (iht_persist.hip)
+int clv_internal_persist_enter(hipStream_t stream);
+void clv_internal_persist_leave(void);
 void clv_internal_persist_forget(hipStream_t stream);     // iht_persist.hip: the chain of persistent launches forgets a destroyed stream
 // the exact-order chain kernel of vector4.hip for other sources (mixed8.hip: CloverVector8::dot): see there for the layout of X
 uint64_t clv_internal_dot_chain_blocks_padded(uint64_t steps);

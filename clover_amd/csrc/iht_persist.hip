@@ -1158,6 +1158,15 @@ static int ihtp_jump_matrices(uint64_t D, const u64 **seg_rows, u64 *jump, u64 *
     return 0;
 }
 
+int clv_internal_persist_enter(hipStream_t stream)
+{
+    g_persist_mutex.lock();
+    const int rc = PersistChain::begin(stream);
+    if (rc) g_persist_mutex.unlock();
+    return rc;
+}
+void clv_internal_persist_leave(void) { g_persist_mutex.unlock(); }
+
 // returns 1 if the persistent kernel was launched, 0 if the problem does not qualify (the caller runs the launch-per-step loop), < 0 on error
 int clm4_iht_persistent(const int8_t *Phi, const float *sPhi, const int8_t *PhiT, const float *sPhiT, uint64_t m, uint64_t n, int8_t *x,
                         float *sx, uint64_t x_len, const int8_t *y, const float *sy, int8_t *t1, float *st1, int8_t *t2, float *st2, int8_t *t3,

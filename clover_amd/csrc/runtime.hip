@@ -118,7 +118,7 @@ int clv_internal_workspace(void **ptr, uint64_t bytes, hipStream_t stream)
 // Hand-over slots, one small buffer per (device, stream), ZERO when handed out for the first time and zero again after every kernel
 // that used them (the consumer clears what it read): single-launch reductions (clv4_dot FAST) pass their workgroup partials through
 // them without a second kernel.  Separate from the scratch above, which other calls on the stream overwrite.
-#define CLV_SYNC_SLOT_BYTES (64u << 10)
+#define CLV_SYNC_SLOT_BYTES CLV_SYNC_SLOT_BYTES_TOTAL
 static std::vector<WsEntry> g_slots;
 
 int clv_internal_sync_slots(void **ptr, uint64_t bytes, hipStream_t stream)

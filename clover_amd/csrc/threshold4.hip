@@ -554,7 +554,8 @@ struct Th4Sel {
 
 // one workgroup of 256 or more threads (the first 256 do the work, everybody takes the barriers): from the top of `hist`, the bin in
 // which the cumulative count reaches `need`
-template <int LEVEL>
+// COHERENT: the histogram was completed by other workgroups of the SAME launch (k_th4_select_persist): agent-scope loads, past this XCD's L2
+template <int LEVEL, bool COHERENT = false>
 __device__ __forceinline__ Th4Sel th4_wg_select(const uint32_t *__restrict__ hist, uint32_t need, uint32_t prev, uint32_t *sel /* LDS[2] */,
                                                 uint32_t *wsum /* LDS[4] */)
 {
@@ -565,7 +566,8 @@ __device__ __forceinline__ Th4Sel th4_wg_select(const uint32_t *__restrict__ his
     const int top = (255 - (on ? t : 0)) * per + per - 1;        // thread t owns the t-th run of `per` bins from the top
     uint32_t bins[per], sum = 0;
 #pragma unroll
-    for (int i = 0; i < per; i++) bins[i] = hist[top - i];      // unconditional (the idle threads read thread 0's bins): the loads go out together
+    for (int i = 0; i < per; i++)                                // unconditional (the idle threads read thread 0's bins): the loads go out together
+        bins[i] = COHERENT ? __hip_atomic_load(&hist[top - i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hist[top - i];
 #pragma unroll
     for (int i = 0; i < per; i++) { if (!on) bins[i] = 0u; sum += bins[i]; }
     uint32_t v = wave_scan_incl(sum);
@@ -628,6 +630,27 @@ __global__ __launch_bounds__(256) void k_th4_count6(const u32x4 *__restrict__ q,
     }
 }
 
+// one block's nine weighted candidates into the bins of radix level LEVEL (lh: LDS), those under `prefix` only (LEVEL > 0)
+template <int LEVEL>
+__device__ __forceinline__ void th4_add_block(uint32_t *lh, unsigned long long c, float sc, uint32_t prefix, uint32_t m0)
+{
+    const float s7 = div7(sc);
+    uint32_t m = m0;
+#pragma unroll
+    for (int it = 0; it <= 8; it++) {
+        const uint32_t wgt = (uint32_t)(c >> (7 * m)) & 0x7Fu;
+        if (wgt) {
+            const uint32_t key = __float_as_uint(__builtin_fabsf(s7 * (float)m));        // cand_key(s7, m)
+            if (LEVEL == 0) atomicAdd(&lh[key >> 20], wgt);
+            else if (LEVEL == 1) { if ((key >> 20) == prefix) atomicAdd(&lh[(key >> 8) & 0xFFF], wgt); }
+            else if (LEVEL == 2) { if ((key >> 8) == prefix) atomicAdd(&lh[key & 0xFF], wgt); }
+            else if (LEVEL == 3) { if ((key >> 20) == prefix) atomicAdd(&lh[(key >> 12) & 0xFF], wgt); }      // the 12 + 8 + 12 split of
+            else { if ((key >> 12) == prefix) atomicAdd(&lh[key & 0xFFF], wgt); }                              // k_th4_select_persist
+        }
+        m = m == 8 ? 0 : m + 1;
+    }
+}
+
 #ifndef TH4_HU
 #define TH4_HU 4             // blocks per thread and step of a histogram level (8 with half the workgroups: 30-37 us per level at n = 2^28, this: 20-25)
 #endif
@@ -650,21 +673,7 @@ __global__ __launch_bounds__(1024) void k_th4_hist6(const unsigned long long *__
     // So the lanes walk the nine magnitudes in rotated order, lane l starting at m = l mod 9: one instruction then spreads over nine
     // bins.  Sums are order-free: same histogram.
     const uint32_t m0 = (threadIdx.x & 63) % 9u;
-    auto add_block = [&](unsigned long long c, float sc) {
-        const float s7 = div7(sc);
-        uint32_t m = m0;
-#pragma unroll
-        for (int it = 0; it <= 8; it++) {
-            const uint32_t wgt = (uint32_t)(c >> (7 * m)) & 0x7Fu;
-            if (wgt) {
-                const uint32_t key = __float_as_uint(__builtin_fabsf(s7 * (float)m));        // cand_key(s7, m)
-                if (LEVEL == 0) atomicAdd(&lh[key >> 20], wgt);
-                else if (LEVEL == 1) { if ((key >> 20) == prefix) atomicAdd(&lh[(key >> 8) & 0xFFF], wgt); }
-                else { if ((key >> 8) == prefix) atomicAdd(&lh[key & 0xFF], wgt); }
-            }
-            m = m == 8 ? 0 : m + 1;
-        }
-    };
+    auto add_block = [&](unsigned long long c, float sc) { th4_add_block<LEVEL>(lh, c, sc, prefix, m0); };
     // TH4_HU blocks per thread and step, all loads first: a thread walks only a handful of steps, so the level is as long as its
     // chain of load latencies (a block whose table is all zero adds nothing: the tail needs no branch)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -749,9 +758,13 @@ __global__ __launch_bounds__(256) void k_th4_ties6(const unsigned long long *__r
 // the chunk's first tie is computed here: ties of all groups in front + the chunk's prefix inside its group
 __global__ __launch_bounds__(256) void k_th4_apply6(u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n, uint64_t nblocks,
                                                     const unsigned long long *__restrict__ cnt, const ThreshState *__restrict__ ts,
-                                                    const uint32_t *__restrict__ chunk_ties, const uint32_t *__restrict__ group_ties, uint32_t cpg)
+                                                    const uint32_t *__restrict__ chunk_ties, const uint32_t *__restrict__ group_ties, uint32_t cpg,
+                                                    uint32_t *__restrict__ clean, uint32_t clean_words)
 {
     __shared__ uint32_t wsum[4], gsum[4];
+    // the three-launch form: the library's control block (level histograms, arrival counters) is handed back all zero for the next call
+    if (clean && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < clean_words; i += 256) clean[i] = 0;
     const uint32_t tau = ts->tau, keep = ts->ties_keep;
     const uint32_t group = blockIdx.x / cpg;
     uint32_t before = 0;
@@ -795,6 +808,286 @@ __global__ __launch_bounds__(256) void k_th4_apply6(u32x4 *__restrict__ q, const
     q[2 * b + 1] = u32x4{w[4], w[5], w[6], w[7]};
 }
 
+
+// ---- round 6: the same call in THREE launches -------------------------------------------------------------------------------------
+//   k_th4_count_hist0     the pass over the nibbles writes the per-block tables AND bins their nine candidates for radix level 0 (the LDS
+//                         atomics run beside the streaming loads);
+//   k_th4_select_persist  ONE workgroup per CU, all resident: level 1, level 2 and the tie prefixes with two grid-wide arrivals in between
+//                         (an agent-scope counter per arrival; what crosses workgroups -- the level histograms -- is written with agent-
+//                         scope atomics and read back with agent-scope loads, so no L2 write-back is needed: a wave waits for its own
+//                         atomics' acknowledgements, the workgroup's barrier collects the waves, one lane arrives).
+//                         Once level 0 has chosen a bin of NORMAL numbers (12 bits = sign, exponent, 3 mantissa bits: a bin spans a
+//                         factor <= 9/8), at most ONE of a block's magnitudes m = 1 .. 8 can lie in it (consecutive magnitudes are a factor
+//                         >= 8/7 apart; m = 0 has key 0), so the block shrinks to one word {its 20 low key bits, its weight}: level 1
+//                         costs 8 multiplies per block instead of 9 binned candidates, level 2 and the tie counts read 4 bytes per
+//                         block.  A level-0 bin of zeros / subnormals (tau = 0: k beyond the non-zero elements) can hold several
+//                         magnitudes of one block: that case -- uniform over the grid -- takes the general loops of k_th4_hist6;
+//   k_th4_apply6          as before (reads tau and the tie ranks), and clears the control block for the next call.
+// Same keys, same selection, same tie rule as the six-launch form: the results are the same bit for bit (tests/test_threshold_large3.py).
+#define TH4_CTL_WORDS (4096u + 4096u + 256u + 16u)     // hist0, hist1, hist2, arrival counters: library-owned, all zero between calls
+#define TH4_P_MAX_CPG 2048u                            // chunks (of 256 blocks) per workgroup of the persistent kernel at most
+
+__global__ __launch_bounds__(1024) void k_th4_count_hist0(const u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n,
+                                                          unsigned long long *__restrict__ cnt, uint64_t nblocks, uint32_t *__restrict__ hist0)
+{
+    __shared__ uint32_t lh[4096];
+    for (int i = threadIdx.x; i < 4096; i += 1024) lh[i] = 0;
+    __syncthreads();
+    const uint32_t m0 = (threadIdx.x & 63) % 9u;
+    const uint64_t stride = (uint64_t)gridDim.x * 1024;
+    for (uint64_t b = (uint64_t)blockIdx.x * 1024 + threadIdx.x; b < nblocks; b += 2 * stride) {
+        u32x4 lo[2], hi[2];
+        float sc[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {                            // clamped addresses, unconditional loads: all six go out together
+            const uint64_t bu = b + u * stride, bc = bu < nblocks ? bu : b;
+            lo[u] = q[2 * bc];
+            hi[u] = q[2 * bc + 1];
+            sc[u] = s[bc];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint64_t bu = b + u * stride;
+            if (bu >= nblocks) continue;
+            const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            unsigned long long c = 0;
+            if (bu * 64 + 64 <= n) {
+                c = th4_count_full_block(w);
+            } else {                                             // the block that n cuts: element by element, the first n - 64 b of them
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t ab = abs_nibbles(swap_nibbles(w[j]));
+                    const uint64_t first = bu * 64 + 8 * j;
+                    const uint32_t valid = first >= n ? 0u : (n - first < 8 ? (uint32_t)(n - first) : 8u);
+#pragma unroll
+                    for (uint32_t e = 0; e < 8; e++)
+                        if (e < valid) c += 1ull << (7u * ((ab >> (4 * e)) & 0xFu));
+                }
+            }
+            cnt[bu] = c;
+            th4_add_block<0>(lh, c, sc[u], 0u, m0);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 1024)
+        if (lh[i]) atomicAdd(&hist0[i], lh[i]);
+}
+
+// One radix level's hand-over.  Every wave's agent-scope atomics into `hist` have been acknowledged -> the workgroup arrives (one atomic
+// whose return value tells the LAST workgroup that it is the last) -> that workgroup alone selects the bin from the finished histogram and
+// publishes {prefix, remaining} as one 64-bit word (never zero: remaining >= 1) -> the others, who poll that word, take it from there.
+// (Every workgroup re-reading the histogram past its L2 -- 256 x 16 KiB of agent-scope loads of the same 128 lines -- cost 5 us a level.)
+template <int SELLEVEL>
+__device__ __forceinline__ Th4Sel th4_grid_select(uint32_t *bar, unsigned long long *result, const uint32_t *hist, uint32_t need, uint32_t prev,
+                                                  uint32_t *sel /* LDS[4] */, uint32_t *wsum)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) sel[2] = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (sel[2]) {                                                // uniform over the workgroup
+        const Th4Sel r = th4_wg_select<SELLEVEL, true>(hist, need, prev, sel, wsum);
+        if (threadIdx.x == 0)
+            __hip_atomic_store(result, ((unsigned long long)r.prefix << 32) | r.remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return r;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t spins = 0;
+        unsigned long long t_start = 0, v;
+        while ((v = __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0) {                        // bounded: 4 s on the 100 MHz wall clock, then a trap
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (!t_start) t_start = now;
+                else if (now - t_start > 400000000ull) __builtin_trap();
+            }
+        }
+        sel[0] = (uint32_t)(v >> 32);
+        sel[1] = (uint32_t)v;
+    }
+    __syncthreads();
+    return Th4Sel{sel[0], sel[1]};
+}
+
+// REG: a workgroup's range is at most 16 x 1024 blocks (n <= 2^28 on 256 CUs): thread t owns blocks b0 + t + 1024 u and keeps their candidate
+// words in registers from level 1 to the tie counts -- no load sits between the grid-wide hand-overs; otherwise the words go through `cand`.
+// Radix split behind level 0's 12 bits: 8 bits, then 12 (the six-launch form takes 12, then 8).  Every workgroup flushes its non-empty bins
+// with agent-scope atomics: at level 1 a workgroup's ~5000 candidates fill whatever bins there are (256 of them: 65 K atomics over the grid,
+// 4096 would be a million); at level 2 only the ~20 candidates of the chosen bin are left per workgroup.  The selection is the same.
+template <bool REG>
+__global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
+                                                             uint32_t *__restrict__ ctl, uint32_t k, ThreshState *__restrict__ ts,
+                                                             uint32_t *__restrict__ chunk_ties, uint32_t *__restrict__ group_ties, uint32_t nchunks,
+                                                             uint32_t cpg, uint32_t *__restrict__ cand, unsigned long long *dbg)
+{
+#define TH4_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    TH4_STAMP(0);
+    __shared__ uint32_t lh[4096];
+    __shared__ uint32_t tot[TH4_P_MAX_CPG];
+    __shared__ uint32_t sel[4], wsum[4], wtot[16];
+    uint32_t *hist0 = ctl, *hist1 = ctl + 4096, *hist2 = ctl + 4352, *bar = ctl + 8448;
+    unsigned long long *result = reinterpret_cast<unsigned long long *>(ctl + 8452);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c0 = blockIdx.x * cpg, c1 = c0 + cpg < nchunks ? c0 + cpg : nchunks;
+    const uint64_t b0 = (uint64_t)c0 * 256, b1 = (uint64_t)c1 * 256 < nblocks ? (uint64_t)c1 * 256 : nblocks;
+    const uint32_t m0 = lane % 9u;
+    for (int i = tid; i < 4096; i += 1024) lh[i] = 0;
+    for (uint32_t i = tid; i < TH4_P_MAX_CPG; i += 1024) tot[i] = 0;
+    // level 0 was finished by the launch in front: ordinary loads
+    const Th4Sel s0 = th4_wg_select<0>(hist0, k, 0, sel, wsum);                   // ends with a barrier: lh is clear for everybody
+    TH4_STAMP(1);
+    // a bin of finite normal numbers holds one candidate per block at most (subnormals: linear bins; the bin of inf / NaN: every magnitude
+    // of a block with such a scale)
+    const uint32_t bexp = (s0.prefix >> 3) & 0xFFu;
+    const bool one = bexp != 0 && bexp != 0xFFu;
+    const float lo = __uint_as_float(s0.prefix << 20);                             // the bin's lower edge
+    // The block's candidate in the bin, {20 low key bits, weight << 20}, or 0.  Keys grow with m, so it can only be m* = the first m whose key
+    // reaches `lo`, and m* is floor or ceil of lo / |s7|: three magnitudes around round(lo * rcp(|s7|)) are tried with the exact key
+    // expression (rcp's last-bit error moves the quotient by 1e-6 at most).  Subnormal scales (where rcp is not to be trusted): all eight.
+    auto candidate = [&](unsigned long long c, float sc) -> uint32_t {
+        const float s7 = div7(sc), a = __builtin_fabsf(s7);
+        uint32_t cw = 0;
+        if (a < 1.17549435e-38f) {
+            if (a == 0.0f) return 0u;
+#pragma unroll
+            for (int m = 1; m <= 8; m++) {
+                const uint32_t key = cand_key(s7, m), wgt = (uint32_t)(c >> (7 * m)) & 0x7Fu;
+                if ((key >> 20) == s0.prefix && wgt) cw = (key & 0xFFFFFu) | (wgt << 20);
+            }
+            return cw;
+        }
+        const float mid = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(lo * __builtin_amdgcn_rcpf(a)), 2.0f), 7.0f);
+#pragma unroll
+        for (int d = -1; d <= 1; d++) {
+            const float mf = mid + (float)d;
+            const uint32_t key = __float_as_uint(__builtin_fabsf(s7 * mf)), wgt = (uint32_t)(c >> (7u * (uint32_t)mf)) & 0x7Fu;
+            if ((key >> 20) == s0.prefix && wgt) cw = (key & 0xFFFFFu) | (wgt << 20);
+        }
+        return cw;
+    };
+    uint32_t cwr[REG ? 16 : 1];
+    // ---- level 1: the 8 bits behind level 0's 12 (and the blocks' candidate words) ----
+    if (REG) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                             // sixteen loads in flight, twice
+            unsigned long long c[8];
+            float sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t bu = b0 + tid + 1024u * (8 * h + u), bc = bu < b1 ? bu : b0;
+                c[u] = cnt[bc];
+                sc[u] = s[bc];
+                if (bu >= b1) c[u] = 0ull;                        // an all-zero table has no candidate
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                cwr[REG ? 8 * h + u : 0] = 0;
+                if (b0 + 1024u * (8 * h + u) >= b1) continue;     // uniform: a short range (small n) skips the arithmetic
+                if (one) {
+                    const uint32_t cw = candidate(c[u], sc[u]);
+                    cwr[REG ? 8 * h + u : 0] = cw;
+                    if (cw) atomicAdd(&lh[(cw >> 12) & 0xFFu], cw >> 20);
+                } else {
+                    th4_add_block<3>(lh, c[u], sc[u], s0.prefix, m0);
+                }
+            }
+        }
+    } else {
+        for (uint64_t b = b0 + tid; b < b1; b += 4 * 1024) {
+            unsigned long long c[4];
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t bu = b + 1024 * u, bc = bu < b1 ? bu : b;
+                c[u] = cnt[bc];
+                sc[u] = s[bc];
+                if (bu >= b1) c[u] = 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!one) { th4_add_block<3>(lh, c[u], sc[u], s0.prefix, m0); continue; }
+                const uint32_t cw = candidate(c[u], sc[u]);
+                if (b + 1024 * u < b1) cand[b + 1024 * u] = cw;
+                if (cw) atomicAdd(&lh[(cw >> 12) & 0xFFu], cw >> 20);
+            }
+        }
+    }
+    __syncthreads();
+    TH4_STAMP(2);
+    if (tid < 256 && lh[tid]) { __hip_atomic_fetch_add(&hist1[tid], lh[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lh[tid] = 0; }
+    TH4_STAMP(3);
+    const Th4Sel s1 = th4_grid_select<2>(bar, result, hist1, s0.remaining, s0.prefix, sel, wsum);     // 256 bins: prefix = 20 bits
+    TH4_STAMP(4);
+    // ---- level 2: the last 12 bits ----
+    if (REG && one) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const uint32_t cw = cwr[REG ? u : 0];
+            if (cw && ((cw >> 12) & 0xFFu) == (s1.prefix & 0xFFu)) atomicAdd(&lh[cw & 0xFFFu], cw >> 20);
+        }
+    } else {
+        for (uint64_t b = b0 + tid; b < b1; b += 4 * 1024) {
+            if (one) {
+                uint32_t cw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint64_t bu = b + 1024 * u; cw[u] = cand[bu < b1 ? bu : b]; if (bu >= b1) cw[u] = 0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (cw[u] && ((cw[u] >> 12) & 0xFFu) == (s1.prefix & 0xFFu)) atomicAdd(&lh[cw[u] & 0xFFFu], cw[u] >> 20);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint64_t bu = b + 1024 * u;
+                    if (bu < b1) th4_add_block<4>(lh, cnt[bu], s[bu], s1.prefix, m0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    TH4_STAMP(5);
+    for (int i = tid; i < 4096; i += 1024)
+        if (lh[i]) __hip_atomic_fetch_add(&hist2[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TH4_STAMP(6);
+    const Th4Sel s2 = th4_grid_select<1>(bar + 1, result + 1, hist2, s1.remaining, s1.prefix, sel, wsum);      // 4096 bins: all 32 bits
+    TH4_STAMP(7);
+    const uint32_t tau = s2.prefix, keep = s2.remaining;
+    if (blockIdx.x == 0 && tid == 0) *ts = ThreshState{tau, keep, tau, keep};
+    // ---- the ties: per chunk of 256 blocks (one workgroup of the apply kernel) the number in front of it inside this workgroup's range ----
+    if (REG && one) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {                            // block b0 + tid + 1024 u lies in chunk c0 + 4 u + (tid >> 8)
+            const uint32_t cw = cwr[REG ? u : 0];
+            uint32_t t = (cw && (cw & 0xFFFFFu) == (tau & 0xFFFFFu)) ? cw >> 20 : 0u;
+            t = wave_scan_incl(t);
+            if (lane == 63 && t) atomicAdd(&tot[4 * u + (tid >> 8)], t);
+        }
+    } else {
+        for (uint32_t c = c0 + (tid >> 8); c < c1; c += 4) {
+            const uint64_t b = (uint64_t)c * 256 + (tid & 255);
+            uint32_t t = 0;
+            if (b < b1) {
+                if (one) { const uint32_t cw = cand[b]; t = (cw && (cw & 0xFFFFFu) == (tau & 0xFFFFFu)) ? cw >> 20 : 0u; }
+                else t = th4_block_ties(cnt[b], div7(s[b]), tau);
+            }
+            t = wave_scan_incl(t);
+            if (lane == 63 && t) atomicAdd(&tot[c - c0], t);
+        }
+    }
+    __syncthreads();
+    TH4_STAMP(8);
+    const uint32_t i0 = 2 * tid, n_here = c1 > c0 ? c1 - c0 : 0;
+    const uint32_t a = i0 < n_here ? tot[i0] : 0u, a2 = i0 + 1 < n_here ? tot[i0 + 1] : 0u;
+    const uint32_t incl = wave_scan_incl(a + a2);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - (a + a2), total = 0;
+    for (uint32_t w = 0; w < 16; w++) { if (w < wave) before += wtot[w]; total += wtot[w]; }
+    if (i0 < n_here) chunk_ties[c0 + i0] = before;
+    if (i0 + 1 < n_here) chunk_ties[c0 + i0 + 1] = before + a;
+    if (tid == 0) group_ties[blockIdx.x] = total;
+    TH4_STAMP(9);
+}
+
 // (TH4_GROUPS / TH4_MAX_CPG are defined in front of k_th4_ties6)
 
 // workspace layout: [3 histograms of 4096 u32][ThreshState, 256 B][group_ties: 512 u32][chunk_ties: nblocks/256 + 1 u32, padded to
@@ -808,6 +1101,43 @@ static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_
     uint32_t *group_ties = (uint32_t *)((char *)ts + 256);
     uint32_t *chunk_ties = group_ties + TH4_GROUPS;
     unsigned long long *cnt = (unsigned long long *)((char *)chunk_ties + (((uint64_t)(n_pad / 64 / 256 + 1) * 4 + 255) & ~255ull));
+    // the three-launch form (round 6): k != 0, a zeroed control block on this stream, at most TH4_P_MAX_CPG chunks per CU
+    const int three = [] { const char *e = getenv("CLV_THRESHOLD_THREE_LAUNCH"); return e ? atoi(e) : 1; }();      // read per call: A/B runs flip it
+    if (three && k != 0) {
+        const uint32_t cus = (uint32_t)clv_cu_count();
+        const uint32_t grid2 = nchunks < cus ? nchunks : cus, cpg2 = (nchunks + grid2 - 1) / grid2, groups2 = (nchunks + cpg2 - 1) / cpg2;
+        void *slots = nullptr;
+        if (cpg2 <= TH4_P_MAX_CPG && groups2 <= TH4_GROUPS && clv_internal_sync_slots(&slots, CLV_SYNC_SLOT_BYTES_TOTAL, st) == CLV_OK) {
+            uint32_t *ctl = (uint32_t *)((char *)slots + CLV_SYNC_SLOT_THRESHOLD_OFFSET);
+            uint32_t *cand = (uint32_t *)(cnt + n_pad / 64);
+            const uint64_t want1 = (nblocks + 2047) / 2048, cap1 = (uint64_t)cus * 2;
+            hipLaunchKernelGGL(k_th4_count_hist0, dim3((unsigned)(want1 < cap1 ? want1 : cap1)), dim3(1024), 0, st, (const u32x4 *)q, s, n, cnt, nblocks, ctl);
+            int rc = clv_internal_persist_enter(st);                      // resident workgroups that wait for each other: one such launch at a time
+            if (rc) {
+                (void)hipMemsetAsync(ctl, 0, TH4_CTL_WORDS * sizeof(uint32_t), st);
+                return rc;
+            }
+            const bool in_regs = cpg2 <= 64 && !getenv("CLV_THRESHOLD_FORCE_CAND");      // (the variable: tests run the other form at small sizes)
+            unsigned long long *dbg = nullptr;
+            if (const char *e = getenv("CLV_THRESHOLD_DEBUG_STAMPS")) dbg = (unsigned long long *)strtoull(e, nullptr, 0);   // probe only: groups x 16 words
+            if (in_regs)
+                hipLaunchKernelGGL(k_th4_select_persist<true>, dim3(groups2), dim3(1024), 0, st, cnt, s, nblocks, ctl, (uint32_t)k, ts, chunk_ties,
+                                   group_ties, nchunks, cpg2, cand, dbg);
+            else
+                hipLaunchKernelGGL(k_th4_select_persist<false>, dim3(groups2), dim3(1024), 0, st, cnt, s, nblocks, ctl, (uint32_t)k, ts, chunk_ties,
+                                   group_ties, nchunks, cpg2, cand, dbg);
+            clv_internal_persist_leave();
+            hipLaunchKernelGGL(k_th4_apply6, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties, group_ties, cpg2, ctl,
+                               TH4_CTL_WORDS);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                (void)hipMemsetAsync(ctl, 0, TH4_CTL_WORDS * sizeof(uint32_t), st);     // whatever ran: the next call finds the block clean
+                clv_set_error("clv4_threshold: launch failed: %s", hipGetErrorString(e));
+                return CLV_ERR_HIP;
+            }
+            return CLV_OK;
+        }
+    }
     const uint64_t want = (nblocks + 255) / 256, cap = (uint64_t)clv_cu_count() * 8;
     hipLaunchKernelGGL(k_th4_count6, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const u32x4 *)q, n, cnt, nblocks, hists);
     if (k != 0) {
@@ -830,7 +1160,7 @@ static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_
     const uint32_t cpg = (nchunks + TH4_GROUPS - 1) / TH4_GROUPS;
     const uint32_t groups = (nchunks + cpg - 1) / cpg;
     hipLaunchKernelGGL(k_th4_ties6, dim3(groups), dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k, ts, chunk_ties, group_ties, nchunks, cpg);
-    hipLaunchKernelGGL(k_th4_apply6, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties, group_ties, cpg);
+    hipLaunchKernelGGL(k_th4_apply6, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties, group_ties, cpg, (uint32_t *)nullptr, 0u);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }
@@ -870,7 +1200,8 @@ static int threshold_large(uint32_t *q, const float *s, uint64_t n, uint64_t k, 
 extern "C" uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad)
 {
     const uint64_t chunk_bytes = ((n_pad / 64 / 256 + 1) * 4 + 255) & ~255ull;
-    return 3 * 4096 * sizeof(uint32_t) + 256 + TH4_GROUPS * sizeof(uint32_t) + chunk_bytes + (n_pad / 64) * sizeof(unsigned long long) + 256;
+    return 3 * 4096 * sizeof(uint32_t) + 256 + TH4_GROUPS * sizeof(uint32_t) + chunk_bytes + (n_pad / 64) * sizeof(unsigned long long) +
+           (n_pad / 64) * sizeof(uint32_t) /* the blocks' candidate words */ + 256;
 }
 
 extern "C" uint64_t clv8_threshold_workspace_bytes(uint64_t n_pad)
