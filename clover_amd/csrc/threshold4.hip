@@ -758,13 +758,9 @@ __global__ __launch_bounds__(256) void k_th4_ties6(const unsigned long long *__r
 // the chunk's first tie is computed here: ties of all groups in front + the chunk's prefix inside its group
 __global__ __launch_bounds__(256) void k_th4_apply6(u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n, uint64_t nblocks,
                                                     const unsigned long long *__restrict__ cnt, const ThreshState *__restrict__ ts,
-                                                    const uint32_t *__restrict__ chunk_ties, const uint32_t *__restrict__ group_ties, uint32_t cpg,
-                                                    uint32_t *__restrict__ clean, uint32_t clean_words)
+                                                    const uint32_t *__restrict__ chunk_ties, const uint32_t *__restrict__ group_ties, uint32_t cpg)
 {
     __shared__ uint32_t wsum[4], gsum[4];
-    // the three-launch form: the library's control block (level histograms, arrival counters) is handed back all zero for the next call
-    if (clean && blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < clean_words; i += 256) clean[i] = 0;
     const uint32_t tau = ts->tau, keep = ts->ties_keep;
     const uint32_t group = blockIdx.x / cpg;
     uint32_t before = 0;
@@ -1088,6 +1084,115 @@ __global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long
     TH4_STAMP(9);
 }
 
+// ---- the apply pass of the three-launch form --------------------------------------------------------------------------------------
+// What k_th4_apply6 does, with a third of its arithmetic (that kernel is VALU-bound: ~400 operations per block at 5.3 TB/s):
+//  * a block's ties are counted on its own nibbles, which the pass holds anyway, not on its table (8 bytes per block less to read);
+//  * FULL blocks are handled on bit planes, as the count pass does: two 4 x 4 bit transposes turn the block into the planes of its 64
+//    nibbles, |v| is taken on the planes, "magnitude >= t" is a 4-bit comparator against the lane's constants (13 boolean operations for
+//    32 nibbles), survivors are an AND on the planes, and the same transpose brings the words back;
+//  * only a block whose ties are cut by the budget (the ONE block where the running rank crosses `keep`) and the block that n cuts take
+//    the word-by-word walk of k_th4_apply6 (the order of the elements inside a word matters there only).
+// mag >= t on planes (t in 0 .. 9; T[i] = all ones where bit i of t is set): from the lowest bit up
+__device__ __forceinline__ uint32_t th4_planes_ge(const uint32_t A[4], const uint32_t T[4])
+{
+    uint32_t g = A[0] | ~T[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) g = (A[i] & ~T[i]) | (~(A[i] ^ T[i]) & g);
+    return g;
+}
+
+// word-by-word: the block's words with everything but its survivors cleared; `rank` = ties in front of the block
+__device__ __forceinline__ void th4_apply_block_words(uint32_t w[8], uint64_t b, uint64_t n, uint32_t lo_t, uint32_t hi_t, uint32_t rank, uint32_t keep)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t ab = abs_nibbles(swap_nibbles(w[j]));
+        const uint64_t first = b * 64 + 8 * j;
+        const uint32_t valid = first_nibbles(first >= n ? 0u : (n - first < 8 ? (uint32_t)(n - first) : 8u));
+        const uint32_t above = ge_nibbles(ab, hi_t);
+        uint32_t kb = above | (0x88888888u & ~valid);              // padding is left alone
+        uint32_t t = ge_nibbles(ab, lo_t) & ~above & valid;
+        const uint32_t nt = __popc(t), room = keep > rank ? keep - rank : 0;
+        if (room >= nt) kb |= t;
+        else for (uint32_t r = 0; r < room; r++) { kb |= t & (0u - t); t &= t - 1; }
+        rank += nt;
+        w[j] &= swap_nibbles((kb >> 3) * 0xFu);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_th4_apply3(u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n, uint64_t nblocks,
+                                                    const ThreshState *__restrict__ ts, const uint32_t *__restrict__ chunk_ties,
+                                                    const uint32_t *__restrict__ group_ties, uint32_t cpg, uint32_t *__restrict__ clean,
+                                                    uint32_t clean_words)
+{
+    __shared__ uint32_t wsum[4], gsum[4];
+    if (blockIdx.x == 0)                                           // the control block goes back all zero for the next call
+        for (uint32_t i = threadIdx.x; i < clean_words; i += 256) clean[i] = 0;
+    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = b < nblocks, full = b * 64 + 64 <= n;
+    const uint64_t bc = in ? b : nblocks - 1;
+    const u32x4 lo = q[2 * bc], hi = q[2 * bc + 1];                  // clamped, unconditional: the loads go out first
+    const float sc = s[bc];
+    const uint32_t tau = ts->tau, keep = ts->ties_keep;
+    const uint32_t group = blockIdx.x / cpg;
+    uint32_t before = 0;
+    for (uint32_t g = threadIdx.x; g < group; g += 256) before += group_ties[g];
+    before = wave_scan_incl(before);
+    if ((threadIdx.x & 63) == 63) gsum[threadIdx.x >> 6] = before;
+    const float s7 = div7(sc);
+    uint32_t lo_t = 0, hi_t = 0;                                   // magnitudes >= hi_t are above tau, [lo_t, hi_t) equal it
+#pragma unroll
+    for (int m = 0; m <= 8; m++) {
+        const uint32_t key = cand_key(s7, m);
+        lo_t += key < tau;
+        hi_t += key <= tau;
+    }
+    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t V[2][4], above[2], tie[2], mine = 0;
+    if (full) {
+        uint32_t TH[4], TL[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { TH[i] = 0u - ((hi_t >> i) & 1u); TL[i] = 0u - ((lo_t >> i) & 1u); }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            th4_planes(w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3], V[h]);
+            const uint32_t low = V[h][1] | V[h][0];
+            const uint32_t A[4] = {V[h][0], V[h][1] ^ (V[h][3] & V[h][0]), V[h][2] ^ (V[h][3] & low), V[h][3] & ~(V[h][2] | low)};
+            above[h] = th4_planes_ge(A, TH);
+            tie[h] = th4_planes_ge(A, TL) & ~above[h];
+            mine += __popc(tie[h]);
+        }
+    } else if (in) {                                               // the block that n cuts
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t ab = abs_nibbles(swap_nibbles(w[j]));
+            const uint64_t first = b * 64 + 8 * j;
+            const uint32_t valid = first_nibbles(first >= n ? 0u : (n - first < 8 ? (uint32_t)(n - first) : 8u));
+            mine += __popc(ge_nibbles(ab, lo_t) & ~ge_nibbles(ab, hi_t) & valid);
+        }
+    }
+    const uint32_t incl = wave_scan_incl(mine);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t rank = gsum[0] + gsum[1] + gsum[2] + gsum[3] + chunk_ties[blockIdx.x] + incl - mine;
+    for (int wv = 0; wv < (int)(threadIdx.x >> 6); wv++) rank += wsum[wv];
+    if (!in) return;
+    const uint32_t room = keep > rank ? keep - rank : 0;
+    if (full && (room >= mine || room == 0)) {                     // all of the block's ties survive, or none
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t K = room ? above[h] | tie[h] : above[h];
+            uint32_t P[4];
+            th4_planes(V[h][0] & K, V[h][1] & K, V[h][2] & K, V[h][3] & K, P);        // the transpose is its own inverse
+            w[4 * h] = P[0]; w[4 * h + 1] = P[1]; w[4 * h + 2] = P[2]; w[4 * h + 3] = P[3];
+        }
+    } else {
+        th4_apply_block_words(w, b, n, lo_t, hi_t, rank, keep);
+    }
+    q[2 * b] = u32x4{w[0], w[1], w[2], w[3]};
+    q[2 * b + 1] = u32x4{w[4], w[5], w[6], w[7]};
+}
+
 // (TH4_GROUPS / TH4_MAX_CPG are defined in front of k_th4_ties6)
 
 // workspace layout: [3 histograms of 4096 u32][ThreshState, 256 B][group_ties: 512 u32][chunk_ties: nblocks/256 + 1 u32, padded to
@@ -1127,7 +1232,7 @@ static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_
                 hipLaunchKernelGGL(k_th4_select_persist<false>, dim3(groups2), dim3(1024), 0, st, cnt, s, nblocks, ctl, (uint32_t)k, ts, chunk_ties,
                                    group_ties, nchunks, cpg2, cand, dbg);
             clv_internal_persist_leave();
-            hipLaunchKernelGGL(k_th4_apply6, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties, group_ties, cpg2, ctl,
+            hipLaunchKernelGGL(k_th4_apply3, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, ts, chunk_ties, group_ties, cpg2, ctl,
                                TH4_CTL_WORDS);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
@@ -1160,7 +1265,7 @@ static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_
     const uint32_t cpg = (nchunks + TH4_GROUPS - 1) / TH4_GROUPS;
     const uint32_t groups = (nchunks + cpg - 1) / cpg;
     hipLaunchKernelGGL(k_th4_ties6, dim3(groups), dim3(256), 0, st, cnt, s, nblocks, hists, (uint32_t)k, ts, chunk_ties, group_ties, nchunks, cpg);
-    hipLaunchKernelGGL(k_th4_apply6, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties, group_ties, cpg, (uint32_t *)nullptr, 0u);
+    hipLaunchKernelGGL(k_th4_apply6, dim3(nchunks), dim3(256), 0, st, (u32x4 *)q, s, n, nblocks, cnt, ts, chunk_ties, group_ties, cpg);
     CLV_LAUNCH_CHECK();
     return CLV_OK;
 }

@@ -7,7 +7,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from clover_amd.lib_binding import CloverHip  # noqa: E402
 
-hip = CloverHip()
+hip = CloverHip(path=os.environ.get("CLV_LIB"))      # CLV_LIB: another build of the library, for same-box A/B runs
 lib = hip.lib
 for logn in [int(v) for v in os.environ.get("TP_LOGN", "24,28").split(",")]:
     n = 1 << logn
