@@ -550,52 +550,69 @@ __device__ __forceinline__ uint32_t th4_block_ties(unsigned long long c, float s
 // histogram, zeroed by the first kernel.  Same keys, same selection, same tie rule: results are unchanged bit for bit.
 struct Th4Sel {
     uint32_t prefix, remaining;
+    uint32_t size;       // elements in the selected bin (what the next level's histogram must add up to)
 };
 
 // one workgroup of 256 or more threads (the first 256 do the work, everybody takes the barriers): from the top of `hist`, the bin in
 // which the cumulative count reaches `need`
-// COHERENT: the histogram was completed by other workgroups of the SAME launch (k_th4_select_persist): agent-scope loads, past this XCD's L2
-template <int LEVEL, bool COHERENT = false>
-__device__ __forceinline__ Th4Sel th4_wg_select(const uint32_t *__restrict__ hist, uint32_t need, uint32_t prev, uint32_t *sel /* LDS[2] */,
+// (two halves, so that a caller can put other loads between the histogram's loads and the first use of the bins)
+template <int LEVEL>
+struct Th4Bins {
+    static constexpr int nb = LEVEL == 2 ? 256 : 4096;
+    static constexpr int per = nb / 256;
+    uint32_t bins[per];
+    int top;
+    bool on;
+    __device__ __forceinline__ void load(const uint32_t *__restrict__ hist)
+    {
+        const int t = threadIdx.x;
+        on = t < 256;
+        top = (255 - (on ? t : 0)) * per + per - 1;              // thread t owns the t-th run of `per` bins from the top
+#pragma unroll
+        for (int i = 0; i < per; i++) bins[i] = hist[top - i];  // unconditional (the idle threads read thread 0's bins): the loads go out together
+    }
+    __device__ __forceinline__ Th4Sel select(uint32_t need, uint32_t prev, uint32_t *sel /* LDS[4] */, uint32_t *wsum /* LDS[4] */)
+    {
+        const int t = threadIdx.x;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < per; i++) { if (!on) bins[i] = 0u; sum += bins[i]; }
+        uint32_t v = wave_scan_incl(sum);
+        __syncthreads();                                         // sel / wsum of an earlier call have been read
+        if (on && (t & 63) == 63) wsum[t >> 6] = v;
+        __syncthreads();
+        if (on) {
+            for (int w = 0; w < (t >> 6); w++) v += wsum[w];
+            if (v >= need && v - sum < need) {
+                uint32_t above = v - sum, size = bins[0];
+                int i = 0;
+#pragma unroll
+                for (int j = 0; j < per - 1; j++)
+                    if (i == j && above + bins[j] < need) { above += bins[j]; i = j + 1; size = bins[j + 1]; }
+                const uint32_t bin = (uint32_t)(top - i);
+                sel[0] = LEVEL == 0 ? bin : (LEVEL == 1 ? (prev << 12) | bin : (prev << 8) | bin);
+                sel[1] = need - above;
+                sel[2] = size;
+            }
+        }
+        __syncthreads();
+        return Th4Sel{sel[0], sel[1], sel[2]};
+    }
+};
+template <int LEVEL>
+__device__ __forceinline__ Th4Sel th4_wg_select(const uint32_t *__restrict__ hist, uint32_t need, uint32_t prev, uint32_t *sel /* LDS[4] */,
                                                 uint32_t *wsum /* LDS[4] */)
 {
-    constexpr int nb = LEVEL == 2 ? 256 : 4096;
-    constexpr int per = nb / 256;
-    const int t = threadIdx.x;
-    const bool on = t < 256;
-    const int top = (255 - (on ? t : 0)) * per + per - 1;        // thread t owns the t-th run of `per` bins from the top
-    uint32_t bins[per], sum = 0;
-#pragma unroll
-    for (int i = 0; i < per; i++)                                // unconditional (the idle threads read thread 0's bins): the loads go out together
-        bins[i] = COHERENT ? __hip_atomic_load(&hist[top - i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hist[top - i];
-#pragma unroll
-    for (int i = 0; i < per; i++) { if (!on) bins[i] = 0u; sum += bins[i]; }
-    uint32_t v = wave_scan_incl(sum);
-    __syncthreads();                                             // sel / wsum of an earlier call have been read
-    if (on && (t & 63) == 63) wsum[t >> 6] = v;
-    __syncthreads();
-    if (on) {
-        for (int w = 0; w < (t >> 6); w++) v += wsum[w];
-        if (v >= need && v - sum < need) {
-            uint32_t above = v - sum;
-            int i = 0;
-#pragma unroll
-            for (int j = 0; j < per - 1; j++)
-                if (i == j && above + bins[j] < need) { above += bins[j]; i = j + 1; }
-            const uint32_t bin = (uint32_t)(top - i);
-            sel[0] = LEVEL == 0 ? bin : (LEVEL == 1 ? (prev << 12) | bin : (prev << 8) | bin);
-            sel[1] = need - above;
-        }
-    }
-    __syncthreads();
-    return Th4Sel{sel[0], sel[1]};
+    Th4Bins<LEVEL> b;
+    b.load(hist);
+    return b.select(need, prev, sel, wsum);
 }
 
 // the selections of levels 0 .. UPTO-1 (what level UPTO's histogram, or the tie count, needs)
 template <int UPTO>
 __device__ __forceinline__ Th4Sel th4_selected(const uint32_t *__restrict__ hists, uint32_t k, uint32_t *sel, uint32_t *wsum)
 {
-    Th4Sel r{0, k};
+    Th4Sel r{0, k, 0};
     if (UPTO >= 1) r = th4_wg_select<0>(hists, k, 0, sel, wsum);
     if (UPTO >= 2) r = th4_wg_select<1>(hists + 4096, r.remaining, r.prefix, sel, wsum);
     if (UPTO >= 3) r = th4_wg_select<2>(hists + 8192, r.remaining, r.prefix, sel, wsum);
@@ -663,7 +680,7 @@ __global__ __launch_bounds__(1024) void k_th4_hist6(const unsigned long long *__
                                                     uint32_t *__restrict__ hists, uint32_t k)
 {
     __shared__ uint32_t lh[4096];
-    __shared__ uint32_t sel[2], wsum[4];
+    __shared__ uint32_t sel[4], wsum[4];
     constexpr int NB = LEVEL == 2 ? 256 : 4096;
     for (int i = threadIdx.x; i < NB; i += blockDim.x) lh[i] = 0;
     const uint32_t prefix = th4_selected<LEVEL>(hists, k, sel, wsum).prefix;       // ends with a barrier: lh is clear for everybody
@@ -708,8 +725,8 @@ __global__ __launch_bounds__(256) void k_th4_ties6(const unsigned long long *__r
                                                    const uint32_t *__restrict__ hists, uint32_t k, ThreshState *__restrict__ ts,
                                                    uint32_t *__restrict__ chunk_ties, uint32_t *__restrict__ group_ties, uint32_t nchunks, uint32_t cpg)
 {
-    __shared__ uint32_t sel[2], wsum[4];
-    Th4Sel r{0x7F800000u, 0};
+    __shared__ uint32_t sel[4], wsum[4];
+    Th4Sel r{0x7F800000u, 0, 0};
     if (k != 0) r = th4_selected<3>(hists, k, sel, wsum);
     const uint32_t tau = r.prefix, keep = r.remaining;
     if (blockIdx.x == 0 && threadIdx.x == 0) *ts = ThreshState{tau, keep, tau, keep};
@@ -820,10 +837,16 @@ __global__ __launch_bounds__(256) void k_th4_apply6(u32x4 *__restrict__ q, const
 //                         magnitudes of one block: that case -- uniform over the grid -- takes the general loops of k_th4_hist6;
 //   k_th4_apply6          as before (reads tau and the tie ranks), and clears the control block for the next call.
 // Same keys, same selection, same tie rule as the six-launch form: the results are the same bit for bit (tests/test_threshold_large3.py).
-#define TH4_CTL_WORDS (4096u + 4096u + 256u + 16u)     // hist0, hist1, hist2, arrival counters: library-owned, all zero between calls
+#define TH4_CTL_WORDS (3u * 4096u + 16u)               // hist0, hist1 (16 copies of 256 bins), hist2, two result words: library-owned, all zero between calls
 #define TH4_P_MAX_CPG 2048u                            // chunks (of 256 blocks) per workgroup of the persistent kernel at most
 
-__global__ __launch_bounds__(1024) void k_th4_count_hist0(const u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n,
+#ifndef TH4_K1_U
+#define TH4_K1_U 2           // blocks per thread and step
+#endif
+#ifndef TH4_K1_WAVES
+#define TH4_K1_WAVES 4       // waves per SIMD the register budget allows (8: two workgroups of 1024 per CU)
+#endif
+__global__ __launch_bounds__(1024, TH4_K1_WAVES) void k_th4_count_hist0(const u32x4 *__restrict__ q, const float *__restrict__ s, uint64_t n,
                                                           unsigned long long *__restrict__ cnt, uint64_t nblocks, uint32_t *__restrict__ hist0)
 {
     __shared__ uint32_t lh[4096];
@@ -831,18 +854,18 @@ __global__ __launch_bounds__(1024) void k_th4_count_hist0(const u32x4 *__restric
     __syncthreads();
     const uint32_t m0 = (threadIdx.x & 63) % 9u;
     const uint64_t stride = (uint64_t)gridDim.x * 1024;
-    for (uint64_t b = (uint64_t)blockIdx.x * 1024 + threadIdx.x; b < nblocks; b += 2 * stride) {
-        u32x4 lo[2], hi[2];
-        float sc[2];
+    for (uint64_t b = (uint64_t)blockIdx.x * 1024 + threadIdx.x; b < nblocks; b += TH4_K1_U * stride) {
+        u32x4 lo[TH4_K1_U], hi[TH4_K1_U];
+        float sc[TH4_K1_U];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {                            // clamped addresses, unconditional loads: all six go out together
+        for (int u = 0; u < TH4_K1_U; u++) {                     // clamped addresses, unconditional loads: all six go out together
             const uint64_t bu = b + u * stride, bc = bu < nblocks ? bu : b;
             lo[u] = q[2 * bc];
             hi[u] = q[2 * bc + 1];
             sc[u] = s[bc];
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < TH4_K1_U; u++) {
             const uint64_t bu = b + u * stride;
             if (bu >= nblocks) continue;
             const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
@@ -869,30 +892,66 @@ __global__ __launch_bounds__(1024) void k_th4_count_hist0(const u32x4 *__restric
         if (lh[i]) atomicAdd(&hist0[i], lh[i]);
 }
 
-// One radix level's hand-over.  Every wave's agent-scope atomics into `hist` have been acknowledged -> the workgroup arrives (one atomic
-// whose return value tells the LAST workgroup that it is the last) -> that workgroup alone selects the bin from the finished histogram and
-// publishes {prefix, remaining} as one 64-bit word (never zero: remaining >= 1) -> the others, who poll that word, take it from there.
-// (Every workgroup re-reading the histogram past its L2 -- 256 x 16 KiB of agent-scope loads of the same 128 lines -- cost 5 us a level.)
-template <int SELLEVEL>
-__device__ __forceinline__ Th4Sel th4_grid_select(uint32_t *bar, unsigned long long *result, const uint32_t *hist, uint32_t need, uint32_t prev,
-                                                  uint32_t *sel /* LDS[4] */, uint32_t *wsum)
+// One radix level's hand-over.  Every workgroup flushes its non-empty bins with agent-scope atomics and goes on to poll the level's result
+// word; nobody counts arrivals.  Workgroup 0 instead reads the histogram (agent-scope loads, past its L2) until its bins ADD UP to the
+// number of elements the level distributes -- the size of the bin chosen one level up, known from that level's histogram -- which they do
+// exactly when every flush has landed (bins only grow).  It then selects the level's bin and publishes {prefix, remaining} as one 64-bit
+// word (never zero: remaining >= 1).  Two memory round trips per level on the critical path (flush -> visible, result -> visible) where an
+// arrival counter and a re-read of the histogram by every workgroup took four and a hot spot of 256 x 16 KiB on the same 128 lines.
+// LEVEL 1: TH4_L1_COPIES copies of 256 bins, workgroup g flushes into copy g mod TH4_L1_COPIES (atomics on ONE address serialise at
+// ~40 ns each: 256 workgroups on one copy cost 10 us); LEVEL 2: 4096 bins, one copy (a workgroup has ~20 candidates left).
+#define TH4_L1_COPIES 16u
+template <int LEVEL>
+__device__ __forceinline__ Th4Sel th4_handover(const uint32_t *hist, unsigned long long *result, uint32_t expected, uint32_t need, uint32_t prev,
+                                               uint32_t *lh /* LDS[4096]: level 1: bins 0..255 zero on entry */, uint32_t *sel, uint32_t *wsum,
+                                               uint32_t *wtot /* LDS[16] */)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) sel[2] = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    __syncthreads();
-    if (sel[2]) {                                                // uniform over the workgroup
-        const Th4Sel r = th4_wg_select<SELLEVEL, true>(hist, need, prev, sel, wsum);
-        if (threadIdx.x == 0)
-            __hip_atomic_store(result, ((unsigned long long)r.prefix << 32) | r.remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(hist), 0, 4096 * 4, 0x00020000);
+        u32x4 v;
+        uint32_t spins = 0;
+        unsigned long long t_start = 0;
+        while (true) {
+            v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 16u * tid, 0, /*sc1*/ 16);
+            const uint32_t part = wave_scan_incl(v.x + v.y + v.z + v.w);
+            if (lane == 63) wtot[wave] = part;
+            __syncthreads();
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) total += wtot[w];
+            __syncthreads();                                     // wtot has been read: the next round may overwrite it
+            if (total == expected) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0) {                        // bounded: 4 s on the 100 MHz wall clock, then a trap
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (!t_start) t_start = now;
+                else if (now - t_start > 400000000ull) __builtin_trap();
+            }
+        }
+        if (LEVEL == 1) {                                        // thread = copy tid >> 6, bins 4 (tid & 63) ..: add the copies up
+            if (v.x) atomicAdd(&lh[4 * lane], v.x);
+            if (v.y) atomicAdd(&lh[4 * lane + 1], v.y);
+            if (v.z) atomicAdd(&lh[4 * lane + 2], v.z);
+            if (v.w) atomicAdd(&lh[4 * lane + 3], v.w);
+        } else {
+            *reinterpret_cast<u32x4 *>(lh + 4 * tid) = v;
+        }
+        __syncthreads();
+        const Th4Sel r = LEVEL == 1 ? th4_wg_select<2>(lh, need, prev, sel, wsum) : th4_wg_select<1>(lh, need, prev, sel, wsum);
+        if (tid == 0) __hip_atomic_store(result, ((unsigned long long)r.prefix << 32) | r.remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (LEVEL == 1) {                                        // the bins go back to zero for level 2
+            if (tid < 256) lh[tid] = 0;
+            __syncthreads();
+        }
         return r;
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         uint32_t spins = 0;
         unsigned long long t_start = 0, v;
         while ((v = __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 1023u) == 0) {                        // bounded: 4 s on the 100 MHz wall clock, then a trap
+            if ((++spins & 1023u) == 0) {
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (!t_start) t_start = now;
                 else if (now - t_start > 400000000ull) __builtin_trap();
@@ -902,14 +961,15 @@ __device__ __forceinline__ Th4Sel th4_grid_select(uint32_t *bar, unsigned long l
         sel[1] = (uint32_t)v;
     }
     __syncthreads();
-    return Th4Sel{sel[0], sel[1]};
+    return Th4Sel{sel[0], sel[1], 0u};
 }
 
-// REG: a workgroup's range is at most 16 x 1024 blocks (n <= 2^28 on 256 CUs): thread t owns blocks b0 + t + 1024 u and keeps their candidate
-// words in registers from level 1 to the tie counts -- no load sits between the grid-wide hand-overs; otherwise the words go through `cand`.
-// Radix split behind level 0's 12 bits: 8 bits, then 12 (the six-launch form takes 12, then 8).  Every workgroup flushes its non-empty bins
-// with agent-scope atomics: at level 1 a workgroup's ~5000 candidates fill whatever bins there are (256 of them: 65 K atomics over the grid,
-// 4096 would be a million); at level 2 only the ~20 candidates of the chosen bin are left per workgroup.  The selection is the same.
+// REG: a workgroup's range is at most 16 x 1024 blocks (n <= 2^28 on 256 CUs): thread t owns blocks b0 + t + 1024 u, loads their tables and
+// scales in one go in front of everything else, and keeps their candidate words in registers from level 1 to the tie counts -- no load sits
+// between the hand-overs; otherwise the words go through `cand`.
+// Radix split behind level 0's 12 bits: 8 bits, then 12 (the six-launch form takes 12, then 8): at level 1 a workgroup's ~5000 candidates
+// fill whatever bins there are, and every non-empty bin is one agent-scope atomic per workgroup; at level 2 only the ~20 candidates of the
+// chosen bin are left per workgroup.  The selection is the same.
 template <bool REG>
 __global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long long *__restrict__ cnt, const float *__restrict__ s, uint64_t nblocks,
                                                              uint32_t *__restrict__ ctl, uint32_t k, ThreshState *__restrict__ ts,
@@ -918,19 +978,35 @@ __global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long
 {
 #define TH4_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TH4_STAMP(0);
-    __shared__ uint32_t lh[4096];
+    __shared__ __attribute__((aligned(16))) uint32_t lh[4096];
     __shared__ uint32_t tot[TH4_P_MAX_CPG];
     __shared__ uint32_t sel[4], wsum[4], wtot[16];
-    uint32_t *hist0 = ctl, *hist1 = ctl + 4096, *hist2 = ctl + 4352, *bar = ctl + 8448;
-    unsigned long long *result = reinterpret_cast<unsigned long long *>(ctl + 8452);
+    uint32_t *hist0 = ctl, *hist1 = ctl + 4096, *hist2 = ctl + 8192;
+    unsigned long long *result = reinterpret_cast<unsigned long long *>(ctl + 12288);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c0 = blockIdx.x * cpg, c1 = c0 + cpg < nchunks ? c0 + cpg : nchunks;
     const uint64_t b0 = (uint64_t)c0 * 256, b1 = (uint64_t)c1 * 256 < nblocks ? (uint64_t)c1 * 256 : nblocks;
     const uint32_t m0 = lane % 9u;
+    unsigned long long cr[REG ? 16 : 1];
+    float scr[REG ? 16 : 1];
+    auto load_batch = [&](int bt) {                               // four blocks: eight loads
+#pragma unroll
+        for (int u = 4 * bt; u < 4 * bt + 4; u++) {
+            const uint64_t bu = b0 + tid + 1024u * u, bc = bu < b1 ? bu : b0;
+            cr[REG ? u : 0] = cnt[bc];
+            scr[REG ? u : 0] = s[bc];
+        }
+    };
+    // level 0 was finished by the launch in front: ordinary loads.  The first two batches of tables go out behind them and arrive under the
+    // selection (a workgroup's 192 KiB are 8 us of HBM time for the grid: every batch is loaded two batches ahead of its arithmetic)
+    Th4Bins<0> bins0;
+    bins0.load(hist0);
+    asm volatile("" ::: "memory");
+    if (REG) { load_batch(0); load_batch(1); }
+    asm volatile("" ::: "memory");
     for (int i = tid; i < 4096; i += 1024) lh[i] = 0;
     for (uint32_t i = tid; i < TH4_P_MAX_CPG; i += 1024) tot[i] = 0;
-    // level 0 was finished by the launch in front: ordinary loads
-    const Th4Sel s0 = th4_wg_select<0>(hist0, k, 0, sel, wsum);                   // ends with a barrier: lh is clear for everybody
+    const Th4Sel s0 = bins0.select(k, 0, sel, wsum);                                // ends with a barrier: lh is clear for everybody
     TH4_STAMP(1);
     // a bin of finite normal numbers holds one candidate per block at most (subnormals: linear bins; the bin of inf / NaN: every magnitude
     // of a block with such a scale)
@@ -965,26 +1041,20 @@ __global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long
     // ---- level 1: the 8 bits behind level 0's 12 (and the blocks' candidate words) ----
     if (REG) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {                             // sixteen loads in flight, twice
-            unsigned long long c[8];
-            float sc[8];
+        for (int bt = 0; bt < 4; bt++) {
+            if (bt + 2 < 4) load_batch(bt + 2);
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint64_t bu = b0 + tid + 1024u * (8 * h + u), bc = bu < b1 ? bu : b0;
-                c[u] = cnt[bc];
-                sc[u] = s[bc];
-                if (bu >= b1) c[u] = 0ull;                        // an all-zero table has no candidate
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                cwr[REG ? 8 * h + u : 0] = 0;
-                if (b0 + 1024u * (8 * h + u) >= b1) continue;     // uniform: a short range (small n) skips the arithmetic
+            for (int u = 4 * bt; u < 4 * bt + 4; u++) {
+                cwr[REG ? u : 0] = 0;
+                if (b0 + 1024u * u >= b1) continue;               // uniform: a short range (small n) skips the arithmetic
+                const unsigned long long c = b0 + tid + 1024u * u < b1 ? cr[REG ? u : 0] : 0ull;   // an all-zero table has no candidate
                 if (one) {
-                    const uint32_t cw = candidate(c[u], sc[u]);
-                    cwr[REG ? 8 * h + u : 0] = cw;
+                    const uint32_t cw = candidate(c, scr[REG ? u : 0]);
+                    cwr[REG ? u : 0] = cw;
                     if (cw) atomicAdd(&lh[(cw >> 12) & 0xFFu], cw >> 20);
                 } else {
-                    th4_add_block<3>(lh, c[u], sc[u], s0.prefix, m0);
+                    th4_add_block<3>(lh, c, scr[REG ? u : 0], s0.prefix, m0);
                 }
             }
         }
@@ -1010,9 +1080,13 @@ __global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long
     }
     __syncthreads();
     TH4_STAMP(2);
-    if (tid < 256 && lh[tid]) { __hip_atomic_fetch_add(&hist1[tid], lh[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lh[tid] = 0; }
+    if (tid < 256 && lh[tid]) {
+        __hip_atomic_fetch_add(&hist1[(blockIdx.x % TH4_L1_COPIES) * 256u + tid], lh[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lh[tid] = 0;
+    }
+    __syncthreads();
     TH4_STAMP(3);
-    const Th4Sel s1 = th4_grid_select<2>(bar, result, hist1, s0.remaining, s0.prefix, sel, wsum);     // 256 bins: prefix = 20 bits
+    const Th4Sel s1 = th4_handover<1>(hist1, result, s0.size, s0.remaining, s0.prefix, lh, sel, wsum, wtot);     // 256 bins: prefix = 20 bits
     TH4_STAMP(4);
     // ---- level 2: the last 12 bits ----
     if (REG && one) {
@@ -1043,8 +1117,9 @@ __global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long
     TH4_STAMP(5);
     for (int i = tid; i < 4096; i += 1024)
         if (lh[i]) __hip_atomic_fetch_add(&hist2[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                              // workgroup 0 writes the whole histogram over lh next
     TH4_STAMP(6);
-    const Th4Sel s2 = th4_grid_select<1>(bar + 1, result + 1, hist2, s1.remaining, s1.prefix, sel, wsum);      // 4096 bins: all 32 bits
+    const Th4Sel s2 = th4_handover<2>(hist2, result + 1, s1.size, s1.remaining, s1.prefix, lh, sel, wsum, wtot);   // 4096 bins: all 32 bits
     TH4_STAMP(7);
     const uint32_t tau = s2.prefix, keep = s2.remaining;
     if (blockIdx.x == 0 && tid == 0) *ts = ThreshState{tau, keep, tau, keep};
@@ -1215,7 +1290,7 @@ static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_
         if (cpg2 <= TH4_P_MAX_CPG && groups2 <= TH4_GROUPS && clv_internal_sync_slots(&slots, CLV_SYNC_SLOT_BYTES_TOTAL, st) == CLV_OK) {
             uint32_t *ctl = (uint32_t *)((char *)slots + CLV_SYNC_SLOT_THRESHOLD_OFFSET);
             uint32_t *cand = (uint32_t *)(cnt + n_pad / 64);
-            const uint64_t want1 = (nblocks + 2047) / 2048, cap1 = (uint64_t)cus * 2;
+            const uint64_t want1 = (nblocks + 1024 * TH4_K1_U - 1) / (1024 * TH4_K1_U), cap1 = (uint64_t)cus * 2;
             hipLaunchKernelGGL(k_th4_count_hist0, dim3((unsigned)(want1 < cap1 ? want1 : cap1)), dim3(1024), 0, st, (const u32x4 *)q, s, n, cnt, nblocks, ctl);
             int rc = clv_internal_persist_enter(st);                      // resident workgroups that wait for each other: one such launch at a time
             if (rc) {
