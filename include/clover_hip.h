@@ -246,7 +246,12 @@ int  clm4_rowdots_v8(const int8_t *A, const float *sA, uint64_t rows, uint64_t c
                      float *d, void *stream);
 /* CloverVector4::threshold(K) (CloverVector4.h:1913-2060): keep the K largest |value| among the first n
  * elements, zero the other nibbles in place.  The surviving multiset of magnitudes equals the reference's;
- * among EQUAL magnitudes the lowest indices survive (the reference's choice depends on its heap order). */
+ * among EQUAL magnitudes the lowest indices survive (the reference's choice depends on its heap order).
+ * Vectors beyond one workgroup (n_pad > 131072) take three launches, the middle one a persistent kernel (one resident workgroup per CU)
+ * that hands its radix levels over through a zero-initialised control block of the (device, stream), allocated -- like the hand-over
+ * slots of the single-launch dots -- by the first such call there: a FIRST call made inside a stream capture runs the older six-launch
+ * form instead (same result); after one ordinary call the three launches capture and replay (tests/test_threshold_large3.py).
+ * `workspace` (or NULL: library scratch of the stream) needs clv4_threshold_workspace_bytes(n_pad) bytes and no initialisation. */
 uint64_t clv4_threshold_workspace_bytes(uint64_t n_pad);
 int  clv4_threshold(int8_t *q, const float *s, uint64_t n, uint64_t n_pad, uint64_t k, void *workspace, void *stream);
 /* The same with the tie rule chosen by `mode` (the threshold counterpart of clv4_dot's CLV_DOT_EXACT / CLV_DOT_FAST):

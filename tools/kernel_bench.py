@@ -77,7 +77,7 @@ for logn in (24, 30):
         k = n // 4
         hip.check(lib.clv_memcpy_d2d(q3.ptr, q.ptr, n // 2, None))
         rec(f"threshold_k25pct_n2^{logn}", 0.5625 * n * 5, lambda: hip.check(lib.clv4_threshold(q3.ptr, s.ptr, n, n, k, None, None)), reps=3,
-            extra={"note": "six kernels: one pass over the nibbles builds per-block magnitude tables, three radix levels + the tie counts run over the tables, one pass applies (threshold4_large, threshold4.hip); launch-bound at this size"})
+            extra={"note": "three launches (round 6): the pass over the nibbles builds per-block magnitude tables and radix level 0, one persistent launch runs levels 1-2 and the tie prefixes over the tables, one pass applies on bit planes (threshold4_large, threshold4.hip)"})
         rec(f"dot_exact_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2)
     q8b = hip.alloc(n)
     hip.check(lib.clv8_quantize(x.ptr, n, q8.ptr, s3.ptr, None, None))
