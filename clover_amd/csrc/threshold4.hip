@@ -1127,6 +1127,7 @@ __global__ __launch_bounds__(1024) void k_th4_select_persist(const unsigned long
     if (REG && one) {
 #pragma unroll
         for (int u = 0; u < 16; u++) {                            // block b0 + tid + 1024 u lies in chunk c0 + 4 u + (tid >> 8)
+            if (b0 + 1024u * u >= b1) continue;                   // uniform: a short range has no such blocks
             const uint32_t cw = cwr[REG ? u : 0];
             uint32_t t = (cw && (cw & 0xFFFFFu) == (tau & 0xFFFFFu)) ? cw >> 20 : 0u;
             t = wave_scan_incl(t);
