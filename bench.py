@@ -1516,16 +1516,33 @@ def extras(hip, torch, dev, stream) -> dict:
     side8 = C.c_void_p()
     hip.check(lib.clv_stream_create(C.byref(side8)))
 
-    def iht8_call():
+    def iht8_call(K=m // 4, iters=100, rs=None):
         hip.check(lib.clm4_iht_v8(Phi.data_ptr(), sPhi.data_ptr(), PhiT.data_ptr(), sPhiT.data_ptr(), m, nn, x8q.data_ptr(), x8s.data_ptr(), nn,
                                   y8q.data_ptr(), y8s.data_ptr(), a8q.data_ptr(), a8s.data_ptr(), b8q.data_ptr(), b8s.data_ptr(),
-                                  c8q.data_ptr(), c8s.data_ptr(), 100, m // 4, 1e-3, 1, None, side8))
+                                  c8q.data_ptr(), c8s.data_ptr(), iters, K, 1e-3, 1, rs, side8))
         hip.check(lib.clv_stream_sync(side8))
-    iht8_call()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        iht8_call()
-    g8_ms = (time.perf_counter() - t0) / 3 / 100 * 1e3
+
+    def iht8_time(K, persistent, rs=None):                            # as iht_time: by difference of two call lengths
+        os.environ["CLV_IHT_PERSISTENT"] = "1" if persistent else "0"
+        try:
+            iht8_call(K, 100, rs)
+            best = {}
+            for iters in (100, 1100):
+                best[iters] = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    iht8_call(K, iters, rs)
+                    best[iters] = min(best[iters], time.perf_counter() - t0)
+            return (best[1100] - best[100]) / 1000 * 1e3
+        finally:
+            os.environ.pop("CLV_IHT_PERSISTENT", None)
+    launches0 = lib.clv_iht_persistent_launches()
+    g8_ms = iht8_time(m // 4, True)
+    g8_25_ms = iht8_time(nn // 4, True)
+    g8st_ms = iht8_time(nn // 4, True, rng_state.ptr)
+    g8_persistent_calls = lib.clv_iht_persistent_launches() - launches0      # 21 if every one of these calls ran as one launch
+    g8l_ms = iht8_time(nn // 4, False)
+    g8lst_ms = iht8_time(nn // 4, False, rng_state.ptr)
     hip.check(lib.clv_stream_destroy(side8))
     iht8_bytes = 2 * (m * nn // 2 + 4 * (m // 64) * (nn // 64)) + (2 * nn + 3 * m) * 17 // 16
     iht_bytes = 2 * (m * nn // 2 + 4 * (m // 64) * (nn // 64)) + (2 * nn + 3 * m) * 9 // 16
@@ -1540,6 +1557,12 @@ def extras(hip, torch, dev, stream) -> dict:
                                                  "ms_per_call_100_iterations": round(gl_call100_ms, 4)},
                         "method": "difference of a 1100- and a 100-iteration call, best of 3 each"},
            "ms_per_iteration_clm4_iht_v8": round(g8_ms, 5), "GB/s_clm4_iht_v8": round(iht8_bytes / g8_ms / 1e6, 1),
+           "clm4_iht_v8": {"path": "one persistent launch (k_iht8_persist<ST>, iht_persist.hip)", "calls_that_ran_persistent_of_21": int(g8_persistent_calls),
+                           "us_per_iteration_K1024": round(g8_ms * 1e3, 2), "us_per_iteration_K2048_reference_ratio": round(g8_25_ms * 1e3, 2),
+                           "us_per_iteration_stochastic_K2048": round(g8st_ms * 1e3, 2),
+                           "launch_per_step_loop": {"us_per_iteration_K2048": round(g8l_ms * 1e3, 2),
+                                                    "us_per_iteration_stochastic_K2048": round(g8lst_ms * 1e3, 2)},
+                           "method": "difference of a 1100- and a 100-iteration call, best of 3 each"},
            "note": "Q_IHT step sequence (mvm, scaleAndAdd, mvm^T, scaleAndAdd, threshold) at N=8192 (4096x8192), bytes counted like "
                    "01_measure.h:1117-1125; _v8 = the published configuration (4-bit matrix, 8-bit vectors); reference published "
                    "19.5 GB/s with 4 threads (performance.txt:581)"}
