@@ -646,7 +646,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
 // FAST (k_thresh8_small's algorithm: element keys, four 8-bit levels, 8 copies of the bins) or none; otherwise clm4_iht_v8 keeps its loop.
 struct Ihtp8Layout {
     uint32_t GB1, GB2;            // groups of 4 blocks of Phi's / PhiT's rows
-    uint32_t offA1, offA2, offX, offT, offC1, offC2, offP1, offP2, offHist, offHsum, offWtot, offPub, total;
+    uint32_t offA1, offA2, offX, offT, offC1, offC2, offP1, offP2, offHist, offHsum, offWtot, offPub, offChain, total;
     uint32_t raw1_bytes, raw2_bytes, raw1_room, raw2_room;      // stochastic: the phases' raw draws and the regions they overlay
 };
 __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2)
@@ -670,6 +670,7 @@ __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint
     L.offP2 = o; o += L.GB2 * 16;
     L.offWtot = o; o += 64;
     L.offPub = o; o += 64 * 4;
+    L.offChain = o; o += (R1 > R2 ? R1 : R2) * 8 * 4;                    // the 8 chain sums of every local row, on their way to the row's tree
     L.total = o + 256;                                                  // the dot loop reads one group past an array's end
     L.raw1_bytes = ((m / 64 + 3) / 4) * 16 * 32;
     L.raw2_bytes = ((n / 64 + 3) / 4) * 16 * 32;
@@ -753,6 +754,58 @@ __device__ __forceinline__ float ihtp8_row_dot(const uint32_t *Arow, const uint3
     const float h = acc + __int_as_float(o);
     const float x2 = h + IHTP_DPP_F(h, 0x4E);                            // h0 + h2 | h1 + h3
     return x2 + IHTP_DPP_F(x2, 0xB1);
+}
+
+// The row dots with ALL 1024 threads (late r6; the lane-per-chain form above keeps 128 or 256 lanes busy for n / 64 dependent steps: 4.5 +
+// 2.6 us of the iteration at N = 8192).  A chain is dealt over H = 128 / R consecutive lanes ("helpers"): helper h forms the exact
+// integers (and their floats) of its four groups of four blocks -- the part that does not depend on the chain -- and then the fp32 chain
+// itself walks through the helpers in block order: H stages of 16 dependent fmas, the running sum handed to the next lane by one DPP
+// shift after each stage.  Every lane computes in every stage (what it computes outside its own stage is never used), so a wave issues
+// 16 H fmas -- as many as one lane of the old form -- but 64 lanes' worth of chains at once, and the integer work is spread over all of
+// them.  Same integers, same factors, same order of the fmas: the same bits.  A helper's slots beyond the row's blocks hold factor 0 and
+// integer 0: fma(0, 0, acc) = acc (acc is never -0: it starts at +0 and x + (-x) rounds to +0).  Requires GB <= 4 H.
+template <int H>
+__device__ __forceinline__ void ihtp8_row_dots_par(const uint32_t *Abase, uint32_t GB, const uint32_t *X, uint32_t xs, const float *cf, uint32_t NB,
+                                                   uint32_t tid, float *chain /* LDS [R][8] */)
+{
+    const uint32_t h = tid & (H - 1), L = (tid / H) & 7u, r = tid / (8 * H);
+    const uint32_t gph = (GB + H - 1) / H;                               // groups per helper, 1 .. 4
+    const u32x4 *Ap = reinterpret_cast<const u32x4 *>(Abase + (size_t)r * GB * 32) + L;
+    const u32x4 *Hp = reinterpret_cast<const u32x4 *>(X) + L, *Cp = Hp + xs / 4, *Lp = Cp + xs / 4;
+    const f32x4 *Fp = reinterpret_cast<const f32x4 *>(cf);
+    float fi[16], ff[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t g = h * gph + k;
+        const bool on = (uint32_t)k < gph && g < GB;
+        const uint32_t gc = on ? g : 0u;                                 // clamped address, unconditional LDS reads
+        const u32x4 a = Ap[gc * 8], xh = Hp[gc * 8], xc = Cp[gc * 8], xl = Lp[gc * 8];
+        const f32x4 f = Fp[gc];
+        const int i0 = sdot8(a.x, xl.x, sdot8(a.x, xc.x, sdot8z(a.x, xh.x)) << 4), i1 = sdot8(a.y, xl.y, sdot8(a.y, xc.y, sdot8z(a.y, xh.y)) << 4);
+        const int i2 = sdot8(a.z, xl.z, sdot8(a.z, xc.z, sdot8z(a.z, xh.z)) << 4), i3 = sdot8(a.w, xl.w, sdot8(a.w, xc.w, sdot8z(a.w, xh.w)) << 4);
+        // blocks beyond the row's NB (the partial last group) are skipped by the lane-per-chain form: factor and integer 0 here
+        const uint32_t b0 = 4 * g;
+        fi[4 * k] = on && b0 < NB ? (float)i0 : 0.0f;         ff[4 * k] = on && b0 < NB ? f.x : 0.0f;
+        fi[4 * k + 1] = on && b0 + 1 < NB ? (float)i1 : 0.0f; ff[4 * k + 1] = on && b0 + 1 < NB ? f.y : 0.0f;
+        fi[4 * k + 2] = on && b0 + 2 < NB ? (float)i2 : 0.0f; ff[4 * k + 2] = on && b0 + 2 < NB ? f.z : 0.0f;
+        fi[4 * k + 3] = on && b0 + 3 < NB ? (float)i3 : 0.0f; ff[4 * k + 3] = on && b0 + 3 < NB ? f.w : 0.0f;
+    }
+    float in = 0.0f, acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        acc = in;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc = __builtin_fmaf(ff[i], fi[i], acc);
+        in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+    }
+    if (h == H - 1) chain[r * 8 + L] = acc;                              // the last helper's last stage = the whole chain
+}
+// the reference's tree over a row's 8 chain sums (CloverMatrix4.h:1229-1234): ((a0 + a4) + (a2 + a6)) + ((a1 + a5) + (a3 + a7))
+__device__ __forceinline__ float ihtp8_row_tree(const float *chain)
+{
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(chain), hi = *reinterpret_cast<const f32x4 *>(chain + 4);
+    const float h0 = lo.x + hi.x, h1 = lo.y + hi.y, h2 = lo.z + hi.z, h3 = lo.w + hi.w;
+    return (h0 + h2) + (h1 + h3);
 }
 
 // the three nibble images of 4 int8 values (one chain's half word): x = 16 (xh + xc) + xl
@@ -904,6 +957,7 @@ struct Ihtp8Args {
     int threshold;
     u64 *g1, *g2;
     uint32_t nap0, nap;
+    u64 *dbg;                     // probe only: phase stamps, as IhtpArgs
     u64 *rng;                     // stochastic rounding (k_iht8_persist<true>): as IhtpArgs
     u64 seq;
     const u64 *seg_rows;
@@ -921,7 +975,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
     float *p1 = reinterpret_cast<float *>(smem + L.offP1), *p2 = reinterpret_cast<float *>(smem + L.offP2);
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + L.offHist), *hsum = reinterpret_cast<uint32_t *>(smem + L.offHsum);
     uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + L.offWtot);
-    float *pub = reinterpret_cast<float *>(smem + L.offPub);
+    float *pub = reinterpret_cast<float *>(smem + L.offPub), *chain = reinterpret_cast<float *>(smem + L.offChain);
 
     const uint32_t tid0 = threadIdx.x, g = blockIdx.x;
     const uint32_t m = A.m, n = A.n, NB1 = n / 64, NB2 = m / 64, XS1 = L.GB1 * 32, XS2 = L.GB2 * 32;      // words per nibble image
@@ -974,16 +1028,23 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const bool last = it + 1 == A.iterations;
+        IHTP_STAMP(0);
         // ---- P1 ----
-        if (has1 && tid < 8 * A.R1) {
+        const bool par1 = 8u * A.R1 * L.GB1 <= 4u * IHTP_THREADS, par2 = 8u * A.R2 * L.GB2 <= 4u * IHTP_THREADS;     // GB <= 4 H
+        if (has1 && par1) {
+            if (A.R1 == 16) ihtp8_row_dots_par<8>(A1, L.GB1, X, XS1, c1, NB1, tid, chain);
+            else if (A.R1 == 32) ihtp8_row_dots_par<4>(A1, L.GB1, X, XS1, c1, NB1, tid, chain);
+            else ihtp8_row_dots_par<2>(A1, L.GB1, X, XS1, c1, NB1, tid, chain);
+        } else if (has1 && tid < 8 * A.R1) {
             const uint32_t lr = tid >> 3;
             const float dot = ihtp8_row_dot(A1 + (size_t)lr * L.GB1 * 32, X, XS1, c1, NB1, tid & 7);
             if ((tid & 7) == 0) pub[lr] = dot;
         }
+        IHTP_STAMP(1);
         __syncthreads();
         if (has1 && tid < A.R1)
-            __hip_atomic_store((gu64 *)A.g1 + unit_slot(u1 + (tid >> 4), tid & 15, m), ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu64 *)A.g1 + unit_slot(u1 + (tid >> 4), tid & 15, m),
+                               ((u64)epoch << 32) | __float_as_uint(par1 ? ihtp8_row_tree(chain + 8 * tid) : pub[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ST && gi1 >= 0) {                                            // behind the row dots: x's images are dead until the end of the iteration
             ga = ihtp_gen16(ga, raw1, (uint32_t)gi1 >> 2, (uint32_t)gi1 & 3u);
             if (last && g == 0 && gi1 < 4) {
@@ -997,6 +1058,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         // ---- E1 ----
         float d[8];
         if ((tid & ~63u) < m / 8) ihtp_gather8(A.g1, m, tid, epoch, tid < m / 8, A.nap0, A.nap, d);
+        IHTP_STAMP(2);
         if (ST) __syncthreads();                                         // the first phase's draws are in LDS
         {
             if (tid < m / 8) {
@@ -1020,17 +1082,24 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
                 }
             }
         }
+        IHTP_STAMP(3);
         __syncthreads();
         // ---- P2 ----
-        if (has2 && tid < 8 * A.R2) {
+        IHTP_STAMP(4);
+        if (has2 && par2) {
+            if (A.R2 == 16) ihtp8_row_dots_par<8>(A2, L.GB2, T, XS2, c2, NB2, tid, chain);
+            else if (A.R2 == 32) ihtp8_row_dots_par<4>(A2, L.GB2, T, XS2, c2, NB2, tid, chain);
+            else ihtp8_row_dots_par<2>(A2, L.GB2, T, XS2, c2, NB2, tid, chain);
+        } else if (has2 && tid < 8 * A.R2) {
             const uint32_t lr = tid >> 3;
             const float dot = ihtp8_row_dot(A2 + (size_t)lr * L.GB2 * 32, T, XS2, c2, NB2, tid & 7);
             if ((tid & 7) == 0) pub[lr] = dot;
         }
+        IHTP_STAMP(5);
         __syncthreads();
         if (has2 && tid < A.R2)
-            __hip_atomic_store((gu64 *)A.g2 + unit_slot(u2 + (tid >> 4), tid & 15, n), ((u64)epoch << 32) | __float_as_uint(pub[tid]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu64 *)A.g2 + unit_slot(u2 + (tid >> 4), tid & 15, n),
+                               ((u64)epoch << 32) | __float_as_uint(par2 ? ihtp8_row_tree(chain + 8 * tid) : pub[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- E2 ----
         int q3[8], qx[8];
         float t3s = 1.0f;
@@ -1043,6 +1112,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         {
             float d[8];
             if ((tid & ~63u) < n / 8) ihtp_gather8(A.g2, n, tid, epoch, tid < n / 8, A.nap0, A.nap, d);
+            IHTP_STAMP(6);
             if (ST) __syncthreads();                                     // the second phase's draws are in LDS
             if (tid < n / 8) {
                 uint32_t Wm[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Ws[2] = {0u, 0u};
@@ -1056,6 +1126,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
                 ihtp8_requant_saa<ST>(d, xw, xs, A.mu, tid & 7u, Wm, Ws, q3, t3s, qx, xs);
             }
         }
+        IHTP_STAMP(7);
         if (ST) {                                                        // the draws lay over the radix bins: clear those again
             __syncthreads();
             hist[tid] = 0;
@@ -1063,6 +1134,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
             __syncthreads();
         }
         if (A.threshold && A.K < A.x_len) ihtp8_threshold(qx, xs, tid, A.x_len, A.K, hist, hsum, wtot);
+        IHTP_STAMP(8);
         if (tid < n / 8) {
             xw[0] = pack4_i8(qx);
             xw[1] = pack4_i8(qx + 4);
@@ -1075,6 +1147,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
             }
         }
         __syncthreads();
+        IHTP_STAMP(9);
     }
     if (ST && g == 0) {                                                  // stamp the slot written in the last iteration (rng_device.h: rng_commit)
         if (tid0 == IHTP_THREADS - 4 * segs1) {
@@ -1298,6 +1371,8 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
     a.nap0 = 16;         // best of 6 ... 26 for this kernel at N = 8192
     a.nap = 2;
     if (const char *e = getenv("CLV_IHT_NAP0")) a.nap0 = (uint32_t)atoi(e);                             // probe only
+    a.dbg = nullptr;
+    if (const char *e = getenv("CLV_IHT_DEBUG_STAMPS")) a.dbg = (u64 *)strtoull(e, nullptr, 0);      // probe only: a device buffer of grid * 16 * 32 words
     a.rng = rng;
     a.seq = 0;
     a.seg_rows = nullptr;

@@ -227,6 +227,35 @@ def stamps(N, thr=1):
     print(f"  first stamp spread over workgroups: {(start.max() - start.min()) / 100.0:.2f} us")
 
 
+def stamps8(N, thr=1, seed=None):
+    """phase stamps of k_iht8_persist (CloverVector8 vectors), as stamps()"""
+    m, n = N // 2, N
+    mat, vecs = problem8(m, n, 31)
+    x, y, t1, t2, t3 = vecs
+    G = 256
+    buf = hip.alloc(G * 16 * 32 * 8)
+    hip.check(lib.clv_memset(buf.ptr, 0, buf.nbytes, None))
+    rng = hip.new_rng(*seed) if seed else None
+    os.environ["CLV_IHT_PERSISTENT"] = "1"
+    os.environ["CLV_IHT_DEBUG_STAMPS"] = hex(buf.ptr)
+    hip.check(lib.clm4_iht_v8(mat[0].ptr, mat[1].ptr, mat[2].ptr, mat[3].ptr, m, n, x[0].ptr, x[1].ptr, n, y[0].ptr, y[1].ptr, t1[0].ptr,
+                              t1[1].ptr, t2[0].ptr, t2[1].ptr, t3[0].ptr, t3[1].ptr, 16, n // 4, 1e-3, thr, rng.ptr if rng else None, None))
+    hip.sync()
+    del os.environ["CLV_IHT_DEBUG_STAMPS"]
+    full = buf.download(np.uint64, G * 16 * 32).reshape(G, 16, 32).astype(np.int64)
+    st = full[:, :, :16]
+    names = ["P1", "publish+gather1", "requant1+images", "barrier", "P2", "publish+gather2", "requant2", "threshold", "images+barrier"]
+    used = st[:, 0, 0] != 0
+    print(f"v8 N={N} thr={thr} {'stochastic' if seed else 'deterministic'}: {int(used.sum())} workgroups; per-phase mean / max over workgroups, "
+          f"iterations 4..15, in us (wave 0's view)")
+    seg = (st[used][:, 4:, 1:10] - st[used][:, 4:, 0:9]) / 100.0
+    for k, nm in enumerate(names):
+        print(f"  {nm:18s} mean {seg[:, :, k].mean():6.2f}  max {seg[:, :, k].max():6.2f}  min {seg[:, :, k].min():6.2f}")
+    u = st[used]
+    per_it = (u[:, 5:, 0] - u[:, 4:-1, 0]) / 100.0
+    print(f"  iteration period (stamp 0 to stamp 0): mean {per_it.mean():6.2f}")
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     rc = 0
@@ -242,6 +271,11 @@ if __name__ == "__main__":
         timing8([int(a) for a in args if a.isdigit()] or [256, 4096, 8192], seed=(5, 6))
     if "check_st" in args:
         rc = check(seed=(12345, 67890))
+    if "stamps8" in args:
+        for N in [int(a) for a in args if a.isdigit()] or [8192]:
+            stamps8(N, 1)
+            stamps8(N, 0)
+            stamps8(N, 1, seed=(5, 6))
     if "stamps" in args:
         for N in [int(a) for a in args if a.isdigit()] or [256, 8192]:
             stamps(N, 1)
