@@ -873,8 +873,9 @@ __device__ __forceinline__ uint32_t pack4_i8(const int q[4]) { return ((uint32_t
 // (Measured and dropped: counting the keys that share the bin of the thread's first key in a register and adding them up over the block's 8
 // lanes before ONE atomic -- the upper levels' bins are few -- changed nothing: 18.0 against 17.5 us per iteration at N = 8192.  Late r6,
 // with phase stamps (5.2 us of the iteration): one pre-cleared pair of bin copies per level and ONE barrier per level instead of two --
-// 6.2 us, two copies take the conflicts eight spread; a wave-wide single atomic for level 0's common top byte -- 5.7 us.  What a level
-// costs is its 16 redundant wave scans and the atomics' instructions, not its barriers.)
+// 6.2 us, two copies take the conflicts eight spread; a wave-wide single atomic for level 0's common top byte -- 5.7 us.  one scanning
+// wave that also adds the copies up and hands {bin, rest} over through LDS -- 16.2 against 15.9 us per iteration.  None of the three parts
+// of a level (atomics, barriers, scans) stands out; the kernel keeps the form below.)
 __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_, uint32_t n, uint32_t k, uint32_t *hist, uint32_t *hsum, uint32_t *wtot)
 {
     const int tid = (int)tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

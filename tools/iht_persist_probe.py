@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from clover_amd.lib_binding import CloverHip  # noqa: E402
 
-hip = CloverHip()
+hip = CloverHip(path=os.environ.get("CLV_LIB"))      # CLV_LIB: another build of the library, for same-box A/B runs
 lib = hip.lib
 
 
