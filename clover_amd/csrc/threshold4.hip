@@ -1346,6 +1346,8 @@ static int threshold4_large(uint32_t *q, const float *s, uint64_t n, uint64_t n_
     return CLV_OK;
 }
 
+__global__ void k_thresh_state_none(ThreshState *ts) { *ts = ThreshState{0, 0, 0x7F800000u, 0}; }
+
 template <int BITS>
 static int threshold_large(uint32_t *q, const float *s, uint64_t n, uint64_t k, void *workspace, hipStream_t st)
 {
@@ -1356,10 +1358,8 @@ static int threshold_large(uint32_t *q, const float *s, uint64_t n, uint64_t k, 
     const uint32_t nblocks = (uint32_t)((nwords + TH_WORDS_PER_BLOCK - 1) / TH_WORDS_PER_BLOCK);
     CLV_HIP(hipMemsetAsync(hist, 0, 4096 * sizeof(uint32_t) + 256, st));
     if (k == 0) {
-        // keep nothing: tau = +inf pattern beyond any finite magnitude, no ties kept
-        const ThreshState none = {0, 0, 0x7F800000u, 0};
-        CLV_HIP(hipMemcpyAsync(ts, &none, sizeof none, hipMemcpyHostToDevice, st));
-        CLV_HIP(hipStreamSynchronize(st));
+        // keep nothing: tau = +inf pattern beyond any finite magnitude, no ties kept (written by a one-thread kernel: the call only enqueues)
+        hipLaunchKernelGGL(k_thresh_state_none, dim3(1), dim3(1), 0, st, ts);
     } else {
         const uint64_t want = (nwords + 255) / 256, cap = (uint64_t)clv_cu_count() * 4;
         const dim3 grid((unsigned)(want < cap ? want : cap));

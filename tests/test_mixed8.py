@@ -275,7 +275,8 @@ def test_gpu_v8_scale_and_add_stochastic_every_kernel_shape(hip, oracle, segment
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(128, 128, 64), (1000, 1024, 64), (2047, 2048, 300), (8192, 8192, 2048), (32768 - 3, 32768, 5000),
-                                  (32768 + 128, 32768 + 128, 999), ((1 << 20) + 77, (1 << 20) + 128, 262144), (512, 512, 0), (512, 512, 511)])
+                                  (32768 + 128, 32768 + 128, 999), ((1 << 20) + 77, (1 << 20) + 128, 262144), (512, 512, 0), (512, 512, 511),
+                                  ((1 << 18) + 128, (1 << 18) + 128, 0)])
 def test_gpu_v8_threshold_top_k(hip, oracle, case):
     n, npad, k = case
     rng = np.random.default_rng(n + k)
