@@ -652,8 +652,8 @@ struct Ihtp8Layout {
 __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2)
 {
     Ihtp8Layout L;
-    L.GB1 = (n / 64 + 3) / 4;
-    L.GB2 = (m / 64 + 3) / 4;
+    L.GB1 = ((n / 64 + 3) / 4 + 1) & ~1u;                                // an even number of groups: swz8 moves a slot to its neighbour group's
+    L.GB2 = ((m / 64 + 3) / 4 + 1) & ~1u;
     uint32_t o = 0;
     L.offA1 = o; o += R1 * L.GB1 * 128;                                 // [row][group][chain][4 blocks] words
     L.offA2 = o; o += R2 * L.GB2 * 128;
@@ -678,11 +678,17 @@ __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint
     L.raw2_room = 3 * L.GB2 * 128 + 8 * 256 * 4 + 2 * 256 * 4;
     return L;
 }
-__device__ __forceinline__ uint32_t dealt8(uint32_t b, uint32_t L) { return ((b >> 2) * 8 + L) * 4 + (b & 3); }
+// The 16-byte slot of (group g, chain L) inside a row / an image: g * 8 + L, with bits 2..3 flipped by the low two bits of the group's
+// helper (g >> gl; ihtp8_row_dots_par: helper h reads groups (h << gl) + k with lanes ordered chain-major, helper-minor).  A ds_read_b128
+// serves 16 lanes per LDS cycle from 64 banks (16 slots of 16 bytes per 256 bytes); unswizzled, the 4 helpers of a chain that fall into one
+// such lane group read slots 32 apart -- the same banks, four cycles instead of one for four of a step's five reads.  With the flip the 16
+// lanes of a group (4 chains x 4 helpers) hit 16 different slots mod 16.
+__device__ __forceinline__ uint32_t swz8(uint32_t slot, uint32_t gl) { return slot ^ ((((slot >> 3) >> gl) & 3u) << 2); }
+__device__ __forceinline__ uint32_t dealt8(uint32_t b, uint32_t L, uint32_t gl) { return swz8((b >> 2) * 8 + L, gl) * 4 + (b & 3); }
 
 // this workgroup's R rows into LDS, re-dealt per (block, chain): work item = (local row, group of 4 blocks, word pair k): words k and
 // 4 + k of four blocks -> chains 2k (their low halves) and 2k + 1 (their high halves), two ds_write_b128
-__device__ __forceinline__ void ihtp8_load_rows(const uint8_t *__restrict__ A, uint32_t u0, uint32_t R, uint32_t NB, uint32_t GB, uint32_t *lds)
+__device__ __forceinline__ void ihtp8_load_rows(const uint8_t *__restrict__ A, uint32_t u0, uint32_t R, uint32_t NB, uint32_t GB, uint32_t gl, uint32_t *lds)
 {
     const uint32_t items = R * GB * 4;
     for (uint32_t it = threadIdx.x; it < items; it += IHTP_THREADS) {
@@ -697,63 +703,10 @@ __device__ __forceinline__ void ihtp8_load_rows(const uint8_t *__restrict__ A, u
             ev[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);           // elements 8k..8k+3 | 32+8k..32+8k+3: chain 2k
             od[i] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);           // elements 8k+4..8k+7 | 36+8k..39+8k: chain 2k + 1
         }
-        u32x4 *dst = reinterpret_cast<u32x4 *>(lds + ((size_t)(lr * GB + g) * 8 + 2 * k) * 4);
-        dst[0] = u32x4{ev[0], ev[1], ev[2], ev[3]};
-        dst[1] = u32x4{od[0], od[1], od[2], od[3]};
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lds + (size_t)lr * GB * 32);
+        dst[swz8(g * 8 + 2 * k, gl)] = u32x4{ev[0], ev[1], ev[2], ev[3]};
+        dst[swz8(g * 8 + 2 * k + 1, gl)] = u32x4{od[0], od[1], od[2], od[3]};
     }
-}
-
-struct Ihtp8Regs { u32x4 a, h, c, l; f32x4 f; };
-__device__ __forceinline__ float ihtp8_step(uint32_t a, uint32_t xh, uint32_t xc, uint32_t xl, float f, float acc)
-{
-    const int hi = sdot8(a, xc, sdot8z(a, xh));
-    return __builtin_fmaf(f, (float)sdot8(a, xl, hi << 4), acc);
-}
-// the row dot of lane (row, chain L) and the reference's tree over the row's 8 lanes (CloverMatrix4.h:1229-1234); every lane returns it
-__device__ __forceinline__ float ihtp8_row_dot(const uint32_t *Arow, const uint32_t *X, uint32_t xs /* words per nibble image */, const float *cf,
-                                               uint32_t NB, int L)
-{
-    const u32x4 *Ap = reinterpret_cast<const u32x4 *>(Arow) + L;
-    const u32x4 *Hp = reinterpret_cast<const u32x4 *>(X) + L, *Cp = Hp + xs / 4, *Lp = Cp + xs / 4;
-    const f32x4 *Fp = reinterpret_cast<const f32x4 *>(cf);
-    float acc = 0.0f;
-    const uint32_t full = NB >> 2;
-#define IHTP8_LOAD(R, G) do { R.a = Ap[(G) * 8]; R.h = Hp[(G) * 8]; R.c = Cp[(G) * 8]; R.l = Lp[(G) * 8]; R.f = Fp[(G)]; } while (0)
-#define IHTP8_GROUP(R)                                                                                              \
-    do {                                                                                                            \
-        acc = ihtp8_step(R.a.x, R.h.x, R.c.x, R.l.x, R.f.x, acc);                                                   \
-        acc = ihtp8_step(R.a.y, R.h.y, R.c.y, R.l.y, R.f.y, acc);                                                   \
-        acc = ihtp8_step(R.a.z, R.h.z, R.c.z, R.l.z, R.f.z, acc);                                                   \
-        acc = ihtp8_step(R.a.w, R.h.w, R.c.w, R.l.w, R.f.w, acc);                                                   \
-    } while (0)
-    Ihtp8Regs r0, r1;
-    IHTP8_LOAD(r0, 0);
-    uint32_t g = 0;
-    for (; g + 2 <= full; g += 2) {                                      // r0 = group g; the next group is read while this one is used
-        IHTP8_LOAD(r1, g + 1);
-        IHTP8_GROUP(r0);
-        IHTP8_LOAD(r0, g + 2);
-        IHTP8_GROUP(r1);
-    }
-    if (g < full) {
-        IHTP8_LOAD(r1, g + 1);
-        IHTP8_GROUP(r0);
-        r0 = r1;
-    }
-    if (NB & 3) {                                                      // the partial group (cols % 256 != 0)
-        const uint32_t rem = NB & 3;
-        acc = ihtp8_step(r0.a.x, r0.h.x, r0.c.x, r0.l.x, r0.f.x, acc);
-        if (rem > 1) acc = ihtp8_step(r0.a.y, r0.h.y, r0.c.y, r0.l.y, r0.f.y, acc);
-        if (rem > 2) acc = ihtp8_step(r0.a.z, r0.h.z, r0.c.z, r0.l.z, r0.f.z, acc);
-    }
-#undef IHTP8_LOAD
-#undef IHTP8_GROUP
-    // h[L & 3] = a[L] + a[L ^ 4] (lanes 4..7 of the group take lane - 4: row_shr:4 on banks 1, 3; lanes 0..3 lane + 4: row_shl:4 on banks 0, 2)
-    int o = __builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x114, 0xF, 0xA, false);
-    o = __builtin_amdgcn_update_dpp(o, __float_as_int(acc), 0x104, 0xF, 0x5, false);
-    const float h = acc + __int_as_float(o);
-    const float x2 = h + IHTP_DPP_F(h, 0x4E);                            // h0 + h2 | h1 + h3
-    return x2 + IHTP_DPP_F(x2, 0xB1);
 }
 
 // The row dots with ALL 1024 threads (late r6; the lane-per-chain form above keeps 128 or 256 lanes busy for n / 64 dependent steps: 4.5 +
@@ -763,27 +716,27 @@ __device__ __forceinline__ float ihtp8_row_dot(const uint32_t *Arow, const uint3
 // shift after each stage.  Every lane computes in every stage (what it computes outside its own stage is never used), so a wave issues
 // 16 H fmas -- as many as one lane of the old form -- but 64 lanes' worth of chains at once, and the integer work is spread over all of
 // them.  Same integers, same factors, same order of the fmas: the same bits.  A helper's slots beyond the row's blocks hold factor 0 and
-// integer 0: fma(0, 0, acc) = acc (acc is never -0: it starts at +0 and x + (-x) rounds to +0).  Requires GB <= 4 H.
+// integer 0: fma(0, 0, acc) = acc (acc is never -0: it starts at +0 and x + (-x) rounds to +0).  A helper takes 2^gl <= 4 groups:
+// GB <= 4 H (clm4_iht_v8_persistent checks; LDS bounds R GB to ~300, i.e. GB / H to 2.4).
 template <int H>
-__device__ __forceinline__ void ihtp8_row_dots_par(const uint32_t *Abase, uint32_t GB, const uint32_t *X, uint32_t xs, const float *cf, uint32_t NB,
-                                                   uint32_t tid, float *chain /* LDS [R][8] */)
+__device__ __forceinline__ void ihtp8_row_dots_par(const uint32_t *Abase, uint32_t GB, uint32_t gl, const uint32_t *X, uint32_t xs, const float *cf,
+                                                   uint32_t NB, uint32_t tid, float *chain /* LDS [R][8] */)
 {
     const uint32_t h = tid & (H - 1), L = (tid / H) & 7u, r = tid / (8 * H);
-    const uint32_t gph = (GB + H - 1) / H;                               // groups per helper, 1 .. 4
-    const u32x4 *Ap = reinterpret_cast<const u32x4 *>(Abase + (size_t)r * GB * 32) + L;
-    const u32x4 *Hp = reinterpret_cast<const u32x4 *>(X) + L, *Cp = Hp + xs / 4, *Lp = Cp + xs / 4;
+    const u32x4 *Ap = reinterpret_cast<const u32x4 *>(Abase + (size_t)r * GB * 32);
+    const u32x4 *Hp = reinterpret_cast<const u32x4 *>(X), *Cp = Hp + xs / 4, *Lp = Cp + xs / 4;
     const f32x4 *Fp = reinterpret_cast<const f32x4 *>(cf);
     float fi[16], ff[16];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t g = h * gph + k;
-        const bool on = (uint32_t)k < gph && g < GB;
-        const uint32_t gc = on ? g : 0u;                                 // clamped address, unconditional LDS reads
-        const u32x4 a = Ap[gc * 8], xh = Hp[gc * 8], xc = Cp[gc * 8], xl = Lp[gc * 8];
+        const uint32_t g = (h << gl) + k;                                // helper h: groups (h << gl) .. + 2^gl - 1
+        const bool on = (uint32_t)k < (1u << gl) && g < GB;
+        const uint32_t gc = on ? g : 0u, slot = swz8(gc * 8 + L, gl);    // clamped address, unconditional LDS reads
+        const u32x4 a = Ap[slot], xh = Hp[slot], xc = Cp[slot], xl = Lp[slot];
         const f32x4 f = Fp[gc];
         const int i0 = sdot8(a.x, xl.x, sdot8(a.x, xc.x, sdot8z(a.x, xh.x)) << 4), i1 = sdot8(a.y, xl.y, sdot8(a.y, xc.y, sdot8z(a.y, xh.y)) << 4);
         const int i2 = sdot8(a.z, xl.z, sdot8(a.z, xc.z, sdot8z(a.z, xh.z)) << 4), i3 = sdot8(a.w, xl.w, sdot8(a.w, xc.w, sdot8z(a.w, xh.w)) << 4);
-        // blocks beyond the row's NB (the partial last group) are skipped by the lane-per-chain form: factor and integer 0 here
+        // blocks beyond the row's NB (the partial last group) take no step in the reference: factor and integer 0 here
         const uint32_t b0 = 4 * g;
         fi[4 * k] = on && b0 < NB ? (float)i0 : 0.0f;         ff[4 * k] = on && b0 < NB ? f.x : 0.0f;
         fi[4 * k + 1] = on && b0 + 1 < NB ? (float)i1 : 0.0f; ff[4 * k + 1] = on && b0 + 1 < NB ? f.y : 0.0f;
@@ -823,14 +776,14 @@ __device__ __forceinline__ void ihtp8_split4(const int q[4], uint32_t &h, uint32
 }
 // thread (block b, position i) writes its 8 elements' images: elements 8i..8i+3 -> chain 2 (i & 3), 8i+4..8i+7 -> the next chain, low half
 // word for i < 4 (elements 0..31 of the block), high half word for i >= 4
-__device__ __forceinline__ void ihtp8_store_images(uint32_t *X, uint32_t xs, uint32_t b, uint32_t i, const int q[8])
+__device__ __forceinline__ void ihtp8_store_images(uint32_t *X, uint32_t xs, uint32_t gl, uint32_t b, uint32_t i, const int q[8])
 {
     uint16_t *X16 = reinterpret_cast<uint16_t *>(X);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         uint32_t h, c, l;
         ihtp8_split4(q + 4 * half, h, c, l);
-        const uint32_t w = dealt8(b, 2 * (i & 3) + half) * 2 + (i >> 2);       // 16-bit index
+        const uint32_t w = dealt8(b, 2 * (i & 3) + half, gl) * 2 + (i >> 2);   // 16-bit index
         X16[w] = (uint16_t)h;
         X16[w + 2 * xs] = (uint16_t)c;
         X16[w + 4 * xs] = (uint16_t)l;
@@ -986,8 +939,11 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
     const uint32_t u1 = g * (A.R1 >> 4), u2 = g * (A.R2 >> 4);
     const bool has1 = u1 < m / 16, has2 = u2 < n / 16;
 
-    if (has1) ihtp8_load_rows(A.Phi, u1, A.R1, NB1, L.GB1, A1);
-    if (has2) ihtp8_load_rows(A.PhiT, u2, A.R2, NB2, L.GB2, A2);
+    // groups per helper lane of the row dots, as a power of two (H = 128 / R helpers per chain): 2^gl >= GB / H
+    const uint32_t H1 = 128u / A.R1, H2 = 128u / A.R2;
+    const uint32_t gl1 = L.GB1 <= H1 ? 0u : (L.GB1 <= 2 * H1 ? 1u : 2u), gl2 = L.GB2 <= H2 ? 0u : (L.GB2 <= 2 * H2 ? 1u : 2u);
+    if (has1) ihtp8_load_rows(A.Phi, u1, A.R1, NB1, L.GB1, gl1, A1);
+    if (has2) ihtp8_load_rows(A.PhiT, u2, A.R2, NB2, L.GB2, gl2, A2);
     for (uint32_t i = tid0; i < 3 * XS1; i += IHTP_THREADS) X[i] = 0;                          // x.clear(): every image of 0 is 0 ...
     for (uint32_t i = tid0; i < 3 * XS2; i += IHTP_THREADS) T[i] = 0;
     for (uint32_t i = tid0; i < L.GB1 * 4; i += IHTP_THREADS) { c1[i] = 0.0f; p1[i] = 0.0f; }
@@ -1034,21 +990,16 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         const bool last = it + 1 == A.iterations;
         IHTP_STAMP(0);
         // ---- P1 ----
-        const bool par1 = 8u * A.R1 * L.GB1 <= 4u * IHTP_THREADS, par2 = 8u * A.R2 * L.GB2 <= 4u * IHTP_THREADS;     // GB <= 4 H
-        if (has1 && par1) {
-            if (A.R1 == 16) ihtp8_row_dots_par<8>(A1, L.GB1, X, XS1, c1, NB1, tid, chain);
-            else if (A.R1 == 32) ihtp8_row_dots_par<4>(A1, L.GB1, X, XS1, c1, NB1, tid, chain);
-            else ihtp8_row_dots_par<2>(A1, L.GB1, X, XS1, c1, NB1, tid, chain);
-        } else if (has1 && tid < 8 * A.R1) {
-            const uint32_t lr = tid >> 3;
-            const float dot = ihtp8_row_dot(A1 + (size_t)lr * L.GB1 * 32, X, XS1, c1, NB1, tid & 7);
-            if ((tid & 7) == 0) pub[lr] = dot;
+        if (has1) {                                                      // all 1024 threads (the host has checked GB <= 4 H)
+            if (A.R1 == 16) ihtp8_row_dots_par<8>(A1, L.GB1, gl1, X, XS1, c1, NB1, tid, chain);
+            else if (A.R1 == 32) ihtp8_row_dots_par<4>(A1, L.GB1, gl1, X, XS1, c1, NB1, tid, chain);
+            else ihtp8_row_dots_par<2>(A1, L.GB1, gl1, X, XS1, c1, NB1, tid, chain);
         }
         IHTP_STAMP(1);
         __syncthreads();
         if (has1 && tid < A.R1)
             __hip_atomic_store((gu64 *)A.g1 + unit_slot(u1 + (tid >> 4), tid & 15, m),
-                               ((u64)epoch << 32) | __float_as_uint(par1 ? ihtp8_row_tree(chain + 8 * tid) : pub[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                               ((u64)epoch << 32) | __float_as_uint(ihtp8_row_tree(chain + 8 * tid)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ST && gi1 >= 0) {                                            // behind the row dots: x's images are dead until the end of the iteration
             ga = ihtp_gen16(ga, raw1, (uint32_t)gi1 >> 2, (uint32_t)gi1 & 3u);
             if (last && g == 0 && gi1 < 4) {
@@ -1077,7 +1028,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
                     Ws[1] = r32[(2 * G1 + 2 * b + (i >> 2)) * 8 + 2 * (i & 3u) + 1];
                 }
                 ihtp8_requant_saa<ST>(d, yw, ys, -1.0f, tid & 7u, Wm, Ws, q1, t1s, q2, t2s);
-                ihtp8_store_images(T, XS2, tid >> 3, tid & 7, q2);
+                ihtp8_store_images(T, XS2, gl2, tid >> 3, tid & 7, q2);
                 if ((tid & 7) == 0) c2[tid >> 3] = p2[tid >> 3] * (t2s * (1.0f / 127.0f));
                 if (last && g == 0) {
                     A.t1[2 * tid] = pack4_i8(q1); A.t1[2 * tid + 1] = pack4_i8(q1 + 4);
@@ -1090,20 +1041,16 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         __syncthreads();
         // ---- P2 ----
         IHTP_STAMP(4);
-        if (has2 && par2) {
-            if (A.R2 == 16) ihtp8_row_dots_par<8>(A2, L.GB2, T, XS2, c2, NB2, tid, chain);
-            else if (A.R2 == 32) ihtp8_row_dots_par<4>(A2, L.GB2, T, XS2, c2, NB2, tid, chain);
-            else ihtp8_row_dots_par<2>(A2, L.GB2, T, XS2, c2, NB2, tid, chain);
-        } else if (has2 && tid < 8 * A.R2) {
-            const uint32_t lr = tid >> 3;
-            const float dot = ihtp8_row_dot(A2 + (size_t)lr * L.GB2 * 32, T, XS2, c2, NB2, tid & 7);
-            if ((tid & 7) == 0) pub[lr] = dot;
+        if (has2) {
+            if (A.R2 == 16) ihtp8_row_dots_par<8>(A2, L.GB2, gl2, T, XS2, c2, NB2, tid, chain);
+            else if (A.R2 == 32) ihtp8_row_dots_par<4>(A2, L.GB2, gl2, T, XS2, c2, NB2, tid, chain);
+            else ihtp8_row_dots_par<2>(A2, L.GB2, gl2, T, XS2, c2, NB2, tid, chain);
         }
         IHTP_STAMP(5);
         __syncthreads();
         if (has2 && tid < A.R2)
             __hip_atomic_store((gu64 *)A.g2 + unit_slot(u2 + (tid >> 4), tid & 15, n),
-                               ((u64)epoch << 32) | __float_as_uint(par2 ? ihtp8_row_tree(chain + 8 * tid) : pub[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                               ((u64)epoch << 32) | __float_as_uint(ihtp8_row_tree(chain + 8 * tid)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- E2 ----
         int q3[8], qx[8];
         float t3s = 1.0f;
@@ -1142,7 +1089,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         if (tid < n / 8) {
             xw[0] = pack4_i8(qx);
             xw[1] = pack4_i8(qx + 4);
-            ihtp8_store_images(X, XS1, tid >> 3, tid & 7, qx);
+            ihtp8_store_images(X, XS1, gl1, tid >> 3, tid & 7, qx);
             if ((tid & 7) == 0) c1[tid >> 3] = p1[tid >> 3] * (xs * (1.0f / 127.0f));
             if (last && g == 0) {
                 A.t3[2 * tid] = pack4_i8(q3); A.t3[2 * tid + 1] = pack4_i8(q3 + 4);
@@ -1339,6 +1286,7 @@ int clm4_iht_v8_persistent(const int8_t *Phi, const float *sPhi, const int8_t *P
     if (R1 > 64 || R2 > 64) return 0;
     const Ihtp8Layout L = ihtp8_layout((uint32_t)m, (uint32_t)n, R1, R2);
     if (L.total > 160u * 1024u) return 0;
+    if (L.GB1 * R1 > 512u || L.GB2 * R2 > 512u) return 0;               // the row dots deal a chain over 128 / R lanes, 4 groups each at most
     // stochastic: the raw draws overlay LDS regions that are dead while they are needed (ihtp8_layout); a shape whose draws do not fit there
     // (the first phase's where m > 0.75 n: gradient descent's 1.5 : 1 systems) runs the launch-per-step loop
     if (rng && (L.raw1_bytes > L.raw1_room || L.raw2_bytes > L.raw2_room)) return 0;
