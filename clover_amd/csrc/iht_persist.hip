@@ -664,8 +664,8 @@ __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint
     L.offT = o; o += 3 * L.GB2 * 128;                                   // t2 likewise
     L.offHist = o; o += 8 * 256 * 4;                                    // one radix level, 8 copies
     L.offHsum = o; o += 2 * 256 * 4;
-    L.offC1 = o; o += L.GB1 * 16;                                       // c_b, [group][4 blocks]
-    L.offC2 = o; o += L.GB2 * 16;
+    L.offC1 = o; o += L.GB1 * 16 + 16;                                  // c_b, [group][4 blocks], and one group of zeros behind them (what a
+    L.offC2 = o; o += L.GB2 * 16 + 16;                                  // helper lane's unused slots read)
     L.offP1 = o; o += L.GB1 * 16;                                       // f32(sA_b / 7)
     L.offP2 = o; o += L.GB2 * 16;
     L.offWtot = o; o += 64;
@@ -716,7 +716,7 @@ __device__ __forceinline__ void ihtp8_load_rows(const uint8_t *__restrict__ A, u
 // shift after each stage.  Every lane computes in every stage (what it computes outside its own stage is never used), so a wave issues
 // 16 H fmas -- as many as one lane of the old form -- but 64 lanes' worth of chains at once, and the integer work is spread over all of
 // them.  Same integers, same factors, same order of the fmas: the same bits.  A helper's slots beyond the row's blocks hold factor 0 and
-// integer 0: fma(0, 0, acc) = acc (acc is never -0: it starts at +0 and x + (-x) rounds to +0).  A helper takes 2^gl <= 4 groups:
+// factor 0: fma(0, i, acc) = acc for any finite i (acc is never -0: it starts at +0 and x + (-x) rounds to +0).  A helper takes 2^gl <= 4 groups:
 // GB <= 4 H (clm4_iht_v8_persistent checks; LDS bounds R GB to ~300, i.e. GB / H to 2.4).
 template <int H>
 __device__ __forceinline__ void ihtp8_row_dots_par(const uint32_t *Abase, uint32_t GB, uint32_t gl, const uint32_t *X, uint32_t xs, const float *cf,
@@ -731,17 +731,16 @@ __device__ __forceinline__ void ihtp8_row_dots_par(const uint32_t *Abase, uint32
     for (int k = 0; k < 4; k++) {
         const uint32_t g = (h << gl) + k;                                // helper h: groups (h << gl) .. + 2^gl - 1
         const bool on = (uint32_t)k < (1u << gl) && g < GB;
-        const uint32_t gc = on ? g : 0u, slot = swz8(gc * 8 + L, gl);    // clamped address, unconditional LDS reads
+        // an unused slot reads group 0's words (any finite integer will do) and the factors of group GB: four zeros.  Blocks beyond the
+        // row's NB inside its last groups hold zero words and zero factors already (the reference takes no step there)
+        const uint32_t slot = swz8((on ? g : 0u) * 8 + L, gl);
         const u32x4 a = Ap[slot], xh = Hp[slot], xc = Cp[slot], xl = Lp[slot];
-        const f32x4 f = Fp[gc];
-        const int i0 = sdot8(a.x, xl.x, sdot8(a.x, xc.x, sdot8z(a.x, xh.x)) << 4), i1 = sdot8(a.y, xl.y, sdot8(a.y, xc.y, sdot8z(a.y, xh.y)) << 4);
-        const int i2 = sdot8(a.z, xl.z, sdot8(a.z, xc.z, sdot8z(a.z, xh.z)) << 4), i3 = sdot8(a.w, xl.w, sdot8(a.w, xc.w, sdot8z(a.w, xh.w)) << 4);
-        // blocks beyond the row's NB (the partial last group) take no step in the reference: factor and integer 0 here
-        const uint32_t b0 = 4 * g;
-        fi[4 * k] = on && b0 < NB ? (float)i0 : 0.0f;         ff[4 * k] = on && b0 < NB ? f.x : 0.0f;
-        fi[4 * k + 1] = on && b0 + 1 < NB ? (float)i1 : 0.0f; ff[4 * k + 1] = on && b0 + 1 < NB ? f.y : 0.0f;
-        fi[4 * k + 2] = on && b0 + 2 < NB ? (float)i2 : 0.0f; ff[4 * k + 2] = on && b0 + 2 < NB ? f.z : 0.0f;
-        fi[4 * k + 3] = on && b0 + 3 < NB ? (float)i3 : 0.0f; ff[4 * k + 3] = on && b0 + 3 < NB ? f.w : 0.0f;
+        const f32x4 f = Fp[on ? g : GB];
+        fi[4 * k] = (float)sdot8(a.x, xl.x, sdot8(a.x, xc.x, sdot8z(a.x, xh.x)) << 4);
+        fi[4 * k + 1] = (float)sdot8(a.y, xl.y, sdot8(a.y, xc.y, sdot8z(a.y, xh.y)) << 4);
+        fi[4 * k + 2] = (float)sdot8(a.z, xl.z, sdot8(a.z, xc.z, sdot8z(a.z, xh.z)) << 4);
+        fi[4 * k + 3] = (float)sdot8(a.w, xl.w, sdot8(a.w, xc.w, sdot8z(a.w, xh.w)) << 4);
+        ff[4 * k] = f.x; ff[4 * k + 1] = f.y; ff[4 * k + 2] = f.z; ff[4 * k + 3] = f.w;
     }
     float in = 0.0f, acc = 0.0f;
 #pragma unroll
@@ -948,6 +947,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
     for (uint32_t i = tid0; i < 3 * XS2; i += IHTP_THREADS) T[i] = 0;
     for (uint32_t i = tid0; i < L.GB1 * 4; i += IHTP_THREADS) { c1[i] = 0.0f; p1[i] = 0.0f; }
     for (uint32_t i = tid0; i < L.GB2 * 4; i += IHTP_THREADS) { c2[i] = 0.0f; p2[i] = 0.0f; }
+    if (tid0 < 4) { c1[L.GB1 * 4 + tid0] = 0.0f; c2[L.GB2 * 4 + tid0] = 0.0f; }
     hist[tid0] = 0;
     hist[tid0 + 1024] = 0;
     __syncthreads();
