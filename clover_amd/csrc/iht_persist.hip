@@ -644,6 +644,11 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
 //     operations per half word of the launch-per-step kernel (k_m4_mvm8).
 // Everything else is the 4-bit kernel's: units, granules, gathers, one re-quantisation per consumer.  Deterministic rounding, threshold
 // FAST (k_thresh8_small's algorithm: element keys, four 8-bit levels, 8 copies of the bins) or none; otherwise clm4_iht_v8 keeps its loop.
+// words between two copies of the threshold's 256 bins: the eight lanes of a block add to eight copies, and the same bin of two copies must
+// not share an LDS bank (256 would put all eight on one)
+#ifndef IHTP8_HSTRIDE
+#define IHTP8_HSTRIDE 260
+#endif
 struct Ihtp8Layout {
     uint32_t GB1, GB2;            // groups of 4 blocks of Phi's / PhiT's rows
     uint32_t offA1, offA2, offX, offT, offC1, offC2, offP1, offP2, offHist, offHsum, offWtot, offPub, offChain, total;
@@ -662,7 +667,7 @@ __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint
     // three (t2 is dead behind the second row dots, the bins are cleared again in front of the threshold), the first phase's overlay x's
     // images (dead between the first row dots and the end of the iteration): at N = 8192 there is no LDS left for buffers of their own
     L.offT = o; o += 3 * L.GB2 * 128;                                   // t2 likewise
-    L.offHist = o; o += 8 * 256 * 4;                                    // one radix level, 8 copies
+    L.offHist = o; o += 8 * IHTP8_HSTRIDE * 4;                          // one radix level, 8 copies
     L.offHsum = o; o += 2 * 256 * 4;
     L.offC1 = o; o += L.GB1 * 16 + 16;                                  // c_b, [group][4 blocks], and one group of zeros behind them (what a
     L.offC2 = o; o += L.GB2 * 16 + 16;                                  // helper lane's unused slots read)
@@ -675,7 +680,7 @@ __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint
     L.raw1_bytes = ((m / 64 + 3) / 4) * 16 * 32;
     L.raw2_bytes = ((n / 64 + 3) / 4) * 16 * 32;
     L.raw1_room = 3 * L.GB1 * 128;
-    L.raw2_room = 3 * L.GB2 * 128 + 8 * 256 * 4 + 2 * 256 * 4;
+    L.raw2_room = 3 * L.GB2 * 128 + 8 * IHTP8_HSTRIDE * 4 + 2 * 256 * 4;
     return L;
 }
 // The 16-byte slot of (group g, chain L) inside a row / an image: g * 8 + L, with bits 2..3 flipped by the low two bits of the group's
@@ -840,7 +845,7 @@ __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_
     uint32_t tau = 0x7F800000u, keep = 0;
     if (k != 0) {
         uint32_t prefix = 0, need = k;
-        uint32_t *hp = hist + 256 * (tid & 7);
+        uint32_t *hp = hist + IHTP8_HSTRIDE * (tid & 7);
 #pragma unroll
         for (int level = 0; level < 4; level++) {
             const int shift = 24 - 8 * level;
@@ -851,7 +856,7 @@ __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_
             if (tid < 256) {                                             // the copies are added up once, and cleared for the next level / call
                 uint32_t mine = 0;
 #pragma unroll
-                for (int cpy = 0; cpy < 8; cpy++) { mine += hist[256 * cpy + tid]; hist[256 * cpy + tid] = 0; }
+                for (int cpy = 0; cpy < 8; cpy++) { mine += hist[IHTP8_HSTRIDE * cpy + tid]; hist[IHTP8_HSTRIDE * cpy + tid] = 0; }
                 hsum[256 * (level & 1) + tid] = mine;
             }
             __syncthreads();
@@ -950,6 +955,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
     if (tid0 < 4) { c1[L.GB1 * 4 + tid0] = 0.0f; c2[L.GB2 * 4 + tid0] = 0.0f; }
     hist[tid0] = 0;
     hist[tid0 + 1024] = 0;
+    if (tid0 < 8 * IHTP8_HSTRIDE - 2048) hist[2048 + tid0] = 0;
     __syncthreads();
     if (has1)
         for (uint32_t b = tid0; b < NB1; b += IHTP_THREADS) {
@@ -1082,6 +1088,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
             __syncthreads();
             hist[tid] = 0;
             hist[IHTP_THREADS + tid] = 0;
+            if (tid < 8 * IHTP8_HSTRIDE - 2048) hist[2048 + tid] = 0;
             __syncthreads();
         }
         if (A.threshold && A.K < A.x_len) ihtp8_threshold(qx, xs, tid, A.x_len, A.K, hist, hsum, wtot);
