@@ -428,7 +428,8 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
 {
     typedef ThreshElems<8> E;
     constexpr int COPIES = 8;                      // private histograms by lane & 7: the keys of a vector crowd into a few bins
-    __shared__ __attribute__((aligned(16))) uint32_t hist[4 * COPIES * 256];
+    constexpr int CS = 260;                        // words between two copies: the same bin of two copies must not share an LDS bank (r6)
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4 * COPIES * CS];
     __shared__ __attribute__((aligned(16))) uint32_t hsum[2 * 256];    // per-level sums over the copies (two buffers: a fast wave may already
     __shared__ uint32_t wsum[16];                                       // write the next level's while a slow one still reads this level's)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -450,7 +451,8 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4 * COPIES * 256 / TS_THREADS; i++) hist[tid + TS_THREADS * i] = 0;
+    for (int i = 0; i < (4 * COPIES * CS + TS_THREADS - 1) / TS_THREADS; i++)
+        if (tid + TS_THREADS * i < 4 * COPIES * CS) hist[tid + TS_THREADS * i] = 0;
     __syncthreads();
 
     uint32_t tau = 0x7F800000u, keep = 0;
@@ -458,8 +460,8 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
         uint32_t prefix = 0, need = k;
         for (int level = 0; level < 4; level++) {
             const int shift = 24 - 8 * level;
-            uint32_t *h = hist + COPIES * 256 * level;
-            uint32_t *hp = h + 256 * (tid & (COPIES - 1));
+            uint32_t *h = hist + COPIES * CS * level;
+            uint32_t *hp = h + CS * (tid & (COPIES - 1));
 #pragma unroll
             for (uint32_t j = 0; j < TS8_W; j++)
 #pragma unroll
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh8_small(uint32_t *__restri
             if (tid < 256) {
                 uint32_t mine = 0;
 #pragma unroll
-                for (int cpy = 0; cpy < COPIES; cpy++) mine += h[256 * cpy + tid];
+                for (int cpy = 0; cpy < COPIES; cpy++) mine += h[CS * cpy + tid];
                 hsum[256 * (level & 1) + tid] = mine;
             }
             __syncthreads();
