@@ -2,7 +2,7 @@
 """Per-kernel achieved bandwidth at HBM-resident sizes (operands >> 256 MiB Infinity Cache), printed as JSON.
 
 Algorithmic bytes per element follow SURVEY 8(d): quantize/restore 4.5625, dot 1.125, scaleAndAdd 1.6875,
-threshold 0.5625 read per pass (reported as time only), transpose 2 x (1/2 + 4/4096), matrix quantize 4.5625."""
+threshold 1.125 (nibbles + scales read and written once each), transpose 2 x (1/2 + 4/4096), matrix quantize 4.5625."""
 import ctypes as C
 import json
 import os
@@ -76,8 +76,19 @@ for logn in (24, 30):
     if logn == 24:
         k = n // 4
         hip.check(lib.clv_memcpy_d2d(q3.ptr, q.ptr, n // 2, None))
-        rec(f"threshold_k25pct_n2^{logn}", 0.5625 * n * 5, lambda: hip.check(lib.clv4_threshold(q3.ptr, s.ptr, n, n, k, None, None)), reps=3,
-            extra={"note": "three launches (round 6): the pass over the nibbles builds per-block magnitude tables and radix level 0, one persistent launch runs levels 1-2 and the tie prefixes over the tables, one pass applies on bit planes (threshold4_large, threshold4.hip)"})
+        thr_note = ("three launches (round 6): the pass over the nibbles builds per-block magnitude tables and radix level 0, one persistent launch "
+                    "runs levels 1-2 and the tie prefixes over the tables, one pass applies on bit planes (threshold4_large, threshold4.hip); bytes = "
+                    "nibbles + scales read and written once each (1.125 n; rounds 3-5 counted five passes here), time = calls back to back on one "
+                    "stream incl. launch gaps (kernel time alone: profiles/r06_threshold_three_launch.txt)")
+        rec(f"threshold_k25pct_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_threshold(q3.ptr, s.ptr, n, n, k, None, None)), reps=3,
+            extra={"note": thr_note})
+        nb = 1 << 28
+        qb, sb = hip.alloc(nb // 2), hip.alloc(nb // 16)
+        hip.check(lib.clv_fill_random_nibbles(qb.ptr, qb.nbytes, 7, 0, None))
+        hip.check(lib.clv_fill_random_scales(sb.ptr, nb // 64, 8, 0, None))
+        rec("threshold_k25pct_n2^28", 1.125 * nb, lambda: hip.check(lib.clv4_threshold(qb.ptr, sb.ptr, nb, nb, nb // 4, None, None)), reps=3,
+            extra={"note": thr_note + "; the vector is thresholded in place, so every call after the first finds it already thresholded (same passes, same time)"})
+        del qb, sb
         rec(f"dot_exact_n2^{logn}", 1.125 * n, lambda: hip.check(lib.clv4_dot(q.ptr, s.ptr, q2.ptr, s2.ptr, n, DOT_EXACT, out.ptr, None, None)), reps=2)
     q8b = hip.alloc(n)
     hip.check(lib.clv8_quantize(x.ptr, n, q8.ptr, s3.ptr, None, None))
