@@ -285,12 +285,18 @@ __device__ __forceinline__ unsigned long long th4_count_full_block(const uint32_
 //  * the per-block cut-offs are computed by each thread for its own words' blocks (9 products): no table, no barrier;
 //  * the tie ranks need one barrier (16 wave totals), not two.
 // Same keys, same selection, same lowest-index tie rule: results are bit-identical (all threshold and IHT tests).
+#ifndef TS4_COPIES
+#define TS4_COPIES 4           // 1 / 2 / 4 / 8 copies: n = 131072 33.9 / 30.4 / 28.7 / 29.1 us, n = 32768 10.6 / 9.8 / 9.5 / 10.3, n = 8192 6.1 / 6.4 / 6.0 / 6.5 (r6, same box)
+#endif
+#define TS4_CS (TS4_COPIES == 1 ? 256 : 260)
 template <int W>
 __global__ __launch_bounds__(TS_THREADS) void k_thresh_small(uint32_t *__restrict__ q, const float *__restrict__ s, uint32_t n, uint32_t k)
 {
     constexpr int MAXB = TS_THREADS * TS_MAXW / 8;                       // 2048 blocks at most
     constexpr int NC = (9 * W + 7) / 8 + 1;                              // candidates per thread at most
-    __shared__ __attribute__((aligned(16))) uint32_t hist[4 * 256];
+    // TS4_COPIES copies of a level's bins, TS4_CS words apart (a bin's copies on different banks), chosen by the lane: the candidates of
+    // a vector crowd into a few bins, and LDS atomics on one address serialise
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4 * TS4_COPIES * TS4_CS];
     __shared__ unsigned long long cnt[MAXB];                             // per block: 9 fields of 7 bits, field m = #(|nibble| == m)
     __shared__ float s7[MAXB];
     __shared__ uint32_t wtot[16];
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh_small(uint32_t *__restric
 #pragma unroll
     for (int j = 0; j < W; j++) w[j] = q[w0 + j < nwords ? w0 + j : 0];
     for (uint32_t i = tid; i < nblocks; i += TS_THREADS) { s7[i] = div7(s[i]); if (W < 8) cnt[i] = 0ull; }
-    hist[tid] = 0;
+    for (int i = tid; i < 4 * TS4_COPIES * TS4_CS; i += TS_THREADS) hist[i] = 0;
     __syncthreads();                                                     // tables zero before anybody adds to them; s7 visible (also for k = 0)
 
     uint32_t tau = 0x7F800000u, keep = 0;
@@ -347,14 +353,18 @@ __global__ __launch_bounds__(TS_THREADS) void k_thresh_small(uint32_t *__restric
 #pragma unroll
         for (int level = 0; level < 4; level++) {
             const int shift = 24 - 8 * level;
-            uint32_t *h = hist + 256 * level;
+            uint32_t *h = hist + TS4_COPIES * TS4_CS * level, *hc = h + TS4_CS * (lane & (TS4_COPIES - 1));
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                if (cwgt[c] && (level == 0 || (ckey[c] >> (shift + 8)) == prefix)) atomicAdd(&h[(ckey[c] >> shift) & 0xFFu], cwgt[c]);
+                if (cwgt[c] && (level == 0 || (ckey[c] >> (shift + 8)) == prefix)) atomicAdd(&hc[(ckey[c] >> shift) & 0xFFu], cwgt[c]);
             __syncthreads();
-            // every wave selects for itself: lane l owns bins 255 - 4 l ... 252 - 4 l (from the top)
-            const u32x4 h4 = *reinterpret_cast<const u32x4 *>(h + 252 - 4 * lane);
-            const uint32_t t0 = h4.w, t1 = h4.z, t2 = h4.y, t3 = h4.x;
+            // every wave selects for itself: lane l owns bins 255 - 4 l ... 252 - 4 l (from the top), added up over the copies
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+            for (int cpy = 0; cpy < TS4_COPIES; cpy++) {
+                const u32x4 h4 = *reinterpret_cast<const u32x4 *>(h + TS4_CS * cpy + 252 - 4 * lane);
+                t0 += h4.w; t1 += h4.z; t2 += h4.y; t3 += h4.x;
+            }
             const uint32_t sum = t0 + t1 + t2 + t3;
             const uint32_t incl = wave_scan_incl(sum);
             const unsigned long long hit = __ballot(incl >= need && incl - sum < need);

@@ -7,7 +7,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from clover_amd.lib_binding import CloverHip  # noqa: E402
 
-hip = CloverHip()
+hip = CloverHip(path=os.environ.get("CLV_LIB"))      # CLV_LIB: another build of the library, for same-box A/B runs
 lib = hip.lib
 for n in [int(v) for v in os.environ.get("TP_N", "8192,32768,131072").split(",")]:
     q, s = hip.alloc(n // 2), hip.alloc(n // 16)
