@@ -765,28 +765,28 @@ __device__ __forceinline__ float ihtp8_row_tree(const float *chain)
     return (h0 + h2) + (h1 + h3);
 }
 
-// the three nibble images of 4 int8 values (one chain's half word): x = 16 (xh + xc) + xl
-__device__ __forceinline__ void ihtp8_split4(const int q[4], uint32_t &h, uint32_t &c, uint32_t &l)
+// the three nibble images of 4 int8 values (one chain's half word, packed one per byte): x = 16 (xh + xc) + xl with xl the signed low nibble,
+// xh + xc = (x + 8) >> 4 in [-8, 8] and xc = 1 where that is 8 (x >= 120).  All four bytes at once: biased to unsigned (u = x + 128), u + 8
+// is added per byte without carries between bytes; the byte's own carry out IS xc, and the high nibble of the sum, re-biased (^ 8), minus xc
+// is xh.  Each image's four nibbles go into 16 bits, even elements in the high nibble of their byte as the matrix stores them.
+// (Element by element this was ~150 instructions per thread and store: 1.2 us of an iteration for x's images alone.)
+__device__ __forceinline__ uint32_t ihtp8_pack16(uint32_t x) { const uint32_t y = (x >> 8) | (x << 4); return (y & 0xFFu) | ((y >> 8) & 0xFF00u); }
+__device__ __forceinline__ void ihtp8_split4(uint32_t P, uint32_t &h, uint32_t &c, uint32_t &l)
 {
-    h = c = l = 0;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int xl = ((q[e] & 15) ^ 8) - 8, rem = (q[e] - xl) >> 4, cy = rem == 8 ? 1 : 0;
-        const int sh = 8 * (e >> 1) + ((e & 1) ? 0 : 4);               // even elements in the high nibble of their byte, as the matrix stores them
-        h |= (uint32_t)((rem - cy) & 15) << sh;
-        c |= (uint32_t)cy << sh;
-        l |= (uint32_t)(xl & 15) << sh;
-    }
+    const uint32_t U = P ^ 0x80808080u, A = (U & 0x7F7F7F7Fu) + 0x08080808u, S = A ^ (U & 0x80808080u);
+    const uint32_t cyb = (U & A & 0x80808080u) >> 7;
+    h = ihtp8_pack16(((((S >> 4) & 0x0F0F0F0Fu) ^ 0x08080808u) - cyb) & 0x0F0F0F0Fu);
+    c = ihtp8_pack16(cyb);
+    l = ihtp8_pack16(P & 0x0F0F0F0Fu);
 }
-// thread (block b, position i) writes its 8 elements' images: elements 8i..8i+3 -> chain 2 (i & 3), 8i+4..8i+7 -> the next chain, low half
-// word for i < 4 (elements 0..31 of the block), high half word for i >= 4
-__device__ __forceinline__ void ihtp8_store_images(uint32_t *X, uint32_t xs, uint32_t gl, uint32_t b, uint32_t i, const int q[8])
+// p0 / p1: the thread's elements 0..3 / 4..7, one int8 per byte
+__device__ __forceinline__ void ihtp8_store_images(uint32_t *X, uint32_t xs, uint32_t gl, uint32_t b, uint32_t i, uint32_t p0, uint32_t p1)
 {
     uint16_t *X16 = reinterpret_cast<uint16_t *>(X);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         uint32_t h, c, l;
-        ihtp8_split4(q + 4 * half, h, c, l);
+        ihtp8_split4(half ? p1 : p0, h, c, l);
         const uint32_t w = dealt8(b, 2 * (i & 3) + half, gl) * 2 + (i >> 2);   // 16-bit index
         X16[w] = (uint16_t)h;
         X16[w + 2 * xs] = (uint16_t)c;
@@ -1034,11 +1034,12 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
                     Ws[1] = r32[(2 * G1 + 2 * b + (i >> 2)) * 8 + 2 * (i & 3u) + 1];
                 }
                 ihtp8_requant_saa<ST>(d, yw, ys, -1.0f, tid & 7u, Wm, Ws, q1, t1s, q2, t2s);
-                ihtp8_store_images(T, XS2, gl2, tid >> 3, tid & 7, q2);
+                const uint32_t t2w0 = pack4_i8(q2), t2w1 = pack4_i8(q2 + 4);
+                ihtp8_store_images(T, XS2, gl2, tid >> 3, tid & 7, t2w0, t2w1);
                 if ((tid & 7) == 0) c2[tid >> 3] = p2[tid >> 3] * (t2s * (1.0f / 127.0f));
                 if (last && g == 0) {
                     A.t1[2 * tid] = pack4_i8(q1); A.t1[2 * tid + 1] = pack4_i8(q1 + 4);
-                    A.t2[2 * tid] = pack4_i8(q2); A.t2[2 * tid + 1] = pack4_i8(q2 + 4);
+                    A.t2[2 * tid] = t2w0; A.t2[2 * tid + 1] = t2w1;
                     if ((tid & 7) == 0) { A.st1[tid >> 3] = t1s; A.st2[tid >> 3] = t2s; }
                 }
             }
@@ -1096,7 +1097,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         if (tid < n / 8) {
             xw[0] = pack4_i8(qx);
             xw[1] = pack4_i8(qx + 4);
-            ihtp8_store_images(X, XS1, gl1, tid >> 3, tid & 7, qx);
+            ihtp8_store_images(X, XS1, gl1, tid >> 3, tid & 7, xw[0], xw[1]);
             if ((tid & 7) == 0) c1[tid >> 3] = p1[tid >> 3] * (xs * (1.0f / 127.0f));
             if (last && g == 0) {
                 A.t3[2 * tid] = pack4_i8(q3); A.t3[2 * tid + 1] = pack4_i8(q3 + 4);
