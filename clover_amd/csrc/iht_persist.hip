@@ -714,48 +714,53 @@ __device__ __forceinline__ void ihtp8_load_rows(const uint8_t *__restrict__ A, u
     }
 }
 
-// The row dots with ALL 1024 threads (late r6; the lane-per-chain form above keeps 128 or 256 lanes busy for n / 64 dependent steps: 4.5 +
-// 2.6 us of the iteration at N = 8192).  A chain is dealt over H = 128 / R consecutive lanes ("helpers"): helper h forms the exact
+// The row dots with helper lanes (late r6; a lane per chain kept 128 or 256 lanes busy for n / 64 dependent steps: 4.5 + 2.6 us of the
+// iteration at N = 8192).  A chain is dealt over H = 128 / R consecutive lanes ("helpers"): helper h forms the exact
 // integers (and their floats) of its four groups of four blocks -- the part that does not depend on the chain -- and then the fp32 chain
 // itself walks through the helpers in block order: H stages of 16 dependent fmas, the running sum handed to the next lane by one DPP
 // shift after each stage.  Every lane computes in every stage (what it computes outside its own stage is never used), so a wave issues
 // 16 H fmas -- as many as one lane of the old form -- but 64 lanes' worth of chains at once, and the integer work is spread over all of
-// them.  Same integers, same factors, same order of the fmas: the same bits.  A helper's slots beyond the row's blocks hold factor 0 and
-// factor 0: fma(0, i, acc) = acc for any finite i (acc is never -0: it starts at +0 and x + (-x) rounds to +0).  A helper takes 2^gl <= 4 groups:
+// them.  Same integers, same factors, same order of the fmas: the same bits.  A helper's slots beyond the row's blocks read a group of
+// zero factors: fma(0, i, acc) = acc for any finite i (acc is never -0: it starts at +0 and x + (-x) rounds to +0).  A helper takes 2^gl <= 4 groups:
 // GB <= 4 H (clm4_iht_v8_persistent checks; LDS bounds R GB to ~300, i.e. GB / H to 2.4).
+// A lane carries TWO rows (rows 2 rp, 2 rp + 1 of the workgroup; 512 lanes work): the rows share the vector's nibble images and the
+// factors, and their two chains advance in one v_pk_fma_f32 per step -- the H stages, which every lane of the wave walks for the one
+// helper whose turn it is, are the larger half of the phase's instructions, and this halves them per row (14.1 -> 13.2 us per iteration
+// at N = 8192 against one row per lane on all 1024).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int H>
-__device__ __forceinline__ void ihtp8_row_dots_par(const uint32_t *Abase, uint32_t GB, uint32_t gl, const uint32_t *X, uint32_t xs, const float *cf,
-                                                   uint32_t NB, uint32_t tid, float *chain /* LDS [R][8] */)
+__device__ __forceinline__ void ihtp8_row_dots_par2(const uint32_t *Abase, uint32_t GB, uint32_t gl, const uint32_t *X, uint32_t xs, const float *cf,
+                                                    uint32_t tid, float *chain /* LDS [R][8] */)
 {
-    const uint32_t h = tid & (H - 1), L = (tid / H) & 7u, r = tid / (8 * H);
-    const u32x4 *Ap = reinterpret_cast<const u32x4 *>(Abase + (size_t)r * GB * 32);
+    const uint32_t h = tid & (H - 1), L = (tid / H) & 7u, rp = tid / (8 * H);
+    const u32x4 *Ap0 = reinterpret_cast<const u32x4 *>(Abase + (size_t)(2 * rp) * GB * 32), *Ap1 = Ap0 + GB * 8;
     const u32x4 *Hp = reinterpret_cast<const u32x4 *>(X), *Cp = Hp + xs / 4, *Lp = Cp + xs / 4;
     const f32x4 *Fp = reinterpret_cast<const f32x4 *>(cf);
-    float fi[16], ff[16];
+    f32x2 fi[16];
+    float ff[16];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t g = (h << gl) + k;                                // helper h: groups (h << gl) .. + 2^gl - 1
+        const uint32_t g = (h << gl) + k;
         const bool on = (uint32_t)k < (1u << gl) && g < GB;
-        // an unused slot reads group 0's words (any finite integer will do) and the factors of group GB: four zeros.  Blocks beyond the
-        // row's NB inside its last groups hold zero words and zero factors already (the reference takes no step there)
         const uint32_t slot = swz8((on ? g : 0u) * 8 + L, gl);
-        const u32x4 a = Ap[slot], xh = Hp[slot], xc = Cp[slot], xl = Lp[slot];
+        const u32x4 a = Ap0[slot], b = Ap1[slot], xh = Hp[slot], xc = Cp[slot], xl = Lp[slot];
         const f32x4 f = Fp[on ? g : GB];
-        fi[4 * k] = (float)sdot8(a.x, xl.x, sdot8(a.x, xc.x, sdot8z(a.x, xh.x)) << 4);
-        fi[4 * k + 1] = (float)sdot8(a.y, xl.y, sdot8(a.y, xc.y, sdot8z(a.y, xh.y)) << 4);
-        fi[4 * k + 2] = (float)sdot8(a.z, xl.z, sdot8(a.z, xc.z, sdot8z(a.z, xh.z)) << 4);
-        fi[4 * k + 3] = (float)sdot8(a.w, xl.w, sdot8(a.w, xc.w, sdot8z(a.w, xh.w)) << 4);
+        fi[4 * k] = f32x2{(float)sdot8(a.x, xl.x, sdot8(a.x, xc.x, sdot8z(a.x, xh.x)) << 4), (float)sdot8(b.x, xl.x, sdot8(b.x, xc.x, sdot8z(b.x, xh.x)) << 4)};
+        fi[4 * k + 1] = f32x2{(float)sdot8(a.y, xl.y, sdot8(a.y, xc.y, sdot8z(a.y, xh.y)) << 4), (float)sdot8(b.y, xl.y, sdot8(b.y, xc.y, sdot8z(b.y, xh.y)) << 4)};
+        fi[4 * k + 2] = f32x2{(float)sdot8(a.z, xl.z, sdot8(a.z, xc.z, sdot8z(a.z, xh.z)) << 4), (float)sdot8(b.z, xl.z, sdot8(b.z, xc.z, sdot8z(b.z, xh.z)) << 4)};
+        fi[4 * k + 3] = f32x2{(float)sdot8(a.w, xl.w, sdot8(a.w, xc.w, sdot8z(a.w, xh.w)) << 4), (float)sdot8(b.w, xl.w, sdot8(b.w, xc.w, sdot8z(b.w, xh.w)) << 4)};
         ff[4 * k] = f.x; ff[4 * k + 1] = f.y; ff[4 * k + 2] = f.z; ff[4 * k + 3] = f.w;
     }
-    float in = 0.0f, acc = 0.0f;
+    f32x2 in = {0.0f, 0.0f}, acc = {0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < H; j++) {
         acc = in;
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc = __builtin_fmaf(ff[i], fi[i], acc);
-        in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+        for (int i = 0; i < 16; i++) acc = __builtin_elementwise_fma(f32x2{ff[i], ff[i]}, fi[i], acc);
+        in.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc.x), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+        in.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc.y), 0x111, 0xF, 0xF, false));
     }
-    if (h == H - 1) chain[r * 8 + L] = acc;                              // the last helper's last stage = the whole chain
+    if (h == H - 1) { chain[(2 * rp) * 8 + L] = acc.x; chain[(2 * rp + 1) * 8 + L] = acc.y; }
 }
 // the reference's tree over a row's 8 chain sums (CloverMatrix4.h:1229-1234): ((a0 + a4) + (a2 + a6)) + ((a1 + a5) + (a3 + a7))
 __device__ __forceinline__ float ihtp8_row_tree(const float *chain)
@@ -996,10 +1001,10 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         const bool last = it + 1 == A.iterations;
         IHTP_STAMP(0);
         // ---- P1 ----
-        if (has1) {                                                      // all 1024 threads (the host has checked GB <= 4 H)
-            if (A.R1 == 16) ihtp8_row_dots_par<8>(A1, L.GB1, gl1, X, XS1, c1, NB1, tid, chain);
-            else if (A.R1 == 32) ihtp8_row_dots_par<4>(A1, L.GB1, gl1, X, XS1, c1, NB1, tid, chain);
-            else ihtp8_row_dots_par<2>(A1, L.GB1, gl1, X, XS1, c1, NB1, tid, chain);
+        if (has1 && tid < IHTP_THREADS / 2) {                            // two rows per lane (the host has checked GB <= 4 H)
+            if (A.R1 == 16) ihtp8_row_dots_par2<8>(A1, L.GB1, gl1, X, XS1, c1, tid, chain);
+            else if (A.R1 == 32) ihtp8_row_dots_par2<4>(A1, L.GB1, gl1, X, XS1, c1, tid, chain);
+            else ihtp8_row_dots_par2<2>(A1, L.GB1, gl1, X, XS1, c1, tid, chain);
         }
         IHTP_STAMP(1);
         __syncthreads();
@@ -1048,10 +1053,10 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
         __syncthreads();
         // ---- P2 ----
         IHTP_STAMP(4);
-        if (has2) {
-            if (A.R2 == 16) ihtp8_row_dots_par<8>(A2, L.GB2, gl2, T, XS2, c2, NB2, tid, chain);
-            else if (A.R2 == 32) ihtp8_row_dots_par<4>(A2, L.GB2, gl2, T, XS2, c2, NB2, tid, chain);
-            else ihtp8_row_dots_par<2>(A2, L.GB2, gl2, T, XS2, c2, NB2, tid, chain);
+        if (has2 && tid < IHTP_THREADS / 2) {
+            if (A.R2 == 16) ihtp8_row_dots_par2<8>(A2, L.GB2, gl2, T, XS2, c2, tid, chain);
+            else if (A.R2 == 32) ihtp8_row_dots_par2<4>(A2, L.GB2, gl2, T, XS2, c2, tid, chain);
+            else ihtp8_row_dots_par2<2>(A2, L.GB2, gl2, T, XS2, c2, tid, chain);
         }
         IHTP_STAMP(5);
         __syncthreads();
