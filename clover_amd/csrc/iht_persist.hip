@@ -837,9 +837,13 @@ __device__ __forceinline__ uint32_t pack4_i8(const int q[4]) { return ((uint32_t
 // with phase stamps (5.2 us of the iteration): one pre-cleared pair of bin copies per level and ONE barrier per level instead of two --
 // 6.2 us, two copies take the conflicts eight spread; a wave-wide single atomic for level 0's common top byte -- 5.7 us.  one scanning
 // wave that also adds the copies up and hands {bin, rest} over through LDS -- 16.2 against 15.9 us per iteration.  None of the three parts
-// of a level (atomics, barriers, scans) stands out; the kernel keeps the form below.)
-__device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_, uint32_t n, uint32_t k, uint32_t *hist, uint32_t *hsum, uint32_t *wtot)
+// of a level (atomics, barriers, scans) stands out; the kernel keeps the form below.  By the stamps: level 0 2.1 us -- mostly the wait for the
+// workgroup's slowest wave to come out of the gather --, levels 1-3 0.8 us each, ranks and apply 0.8.  Listing the keys that are left after
+// two levels (a dozen) and ranking them in one wave instead of levels 2 and 3: 1.4 against 1.6 us, not kept.)
+__device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_, uint32_t n, uint32_t k, uint32_t *hist, uint32_t *hsum, uint32_t *wtot,
+                                                u64 *dbg = nullptr)
 {
+#define THR8_STAMP(k_) do { if (dbg && threadIdx.x == 0) dbg[k_] = __builtin_amdgcn_s_memrealtime(); } while (0)
     const int tid = (int)tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t keys[8], valid = 0;
 #pragma unroll
@@ -848,6 +852,7 @@ __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_
         if (8u * tid + e < n) valid |= 1u << e;
     }
     uint32_t tau = 0x7F800000u, keep = 0;
+    THR8_STAMP(10);
     if (k != 0) {
         uint32_t prefix = 0, need = k;
         uint32_t *hp = hist + IHTP8_HSTRIDE * (tid & 7);
@@ -880,6 +885,7 @@ __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_
                     if (above + T2 < need) { above += T2; pick = 3; } } }
             prefix = (prefix << 8) | (255u - 4u * (uint32_t)Ls - pick);
             need -= above;
+            THR8_STAMP(11 + level);
         }
         tau = prefix;
         keep = need;
@@ -887,6 +893,7 @@ __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_
     uint32_t c = 0;
 #pragma unroll
     for (int e = 0; e < 8; e++) c += ((valid >> e) & 1u) && keys[e] == tau;
+    THR8_STAMP(15);
     const uint32_t vinc = wave_scan_incl(c);
     if (lane == 63) wtot[wave] = vinc;
     __syncthreads();
@@ -900,6 +907,7 @@ __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_
         if (keys[e] == tau) { if (rank >= keep) q[e] = 0; rank++; }
         else q[e] = 0;
     }
+#undef THR8_STAMP
 }
 
 struct Ihtp8Args {
@@ -1097,7 +1105,8 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
             if (tid < 8 * IHTP8_HSTRIDE - 2048) hist[2048 + tid] = 0;
             __syncthreads();
         }
-        if (A.threshold && A.K < A.x_len) ihtp8_threshold(qx, xs, tid, A.x_len, A.K, hist, hsum, wtot);
+        if (A.threshold && A.K < A.x_len)
+            ihtp8_threshold(qx, xs, tid, A.x_len, A.K, hist, hsum, wtot, A.dbg && it < 16 ? A.dbg + ((size_t)g * 16 + it) * 32 : nullptr);
         IHTP_STAMP(8);
         if (tid < n / 8) {
             xw[0] = pack4_i8(qx);

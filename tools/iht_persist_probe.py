@@ -252,6 +252,12 @@ def stamps8(N, thr=1, seed=None):
     for k, nm in enumerate(names):
         print(f"  {nm:18s} mean {seg[:, :, k].mean():6.2f}  max {seg[:, :, k].max():6.2f}  min {seg[:, :, k].min():6.2f}")
     u = st[used]
+    if thr:
+        inner = u[:, 4:, :]
+        for nm, a, b in (("re-quant done .. keys", 7, 10), ("level 0 (atomics, 2 barriers, scan)", 10, 11), ("level 1", 11, 12), ("level 2", 12, 13), ("level 3", 13, 14),
+                         ("ties counted", 14, 15), ("rank + apply", 15, 8)):
+            dseg = (inner[:, :, b] - inner[:, :, a]) / 100.0
+            print(f"    threshold/{nm:36s} mean {dseg.mean():6.2f}  max {dseg.max():6.2f}")
     per_it = (u[:, 5:, 0] - u[:, 4:-1, 0]) / 100.0
     print(f"  iteration period (stamp 0 to stamp 0): mean {per_it.mean():6.2f}")
 
