@@ -839,7 +839,9 @@ __device__ __forceinline__ uint32_t pack4_i8(const int q[4]) { return ((uint32_t
 // wave that also adds the copies up and hands {bin, rest} over through LDS -- 16.2 against 15.9 us per iteration.  None of the three parts
 // of a level (atomics, barriers, scans) stands out; the kernel keeps the form below.  By the stamps: level 0 2.1 us -- mostly the wait for the
 // workgroup's slowest wave to come out of the gather --, levels 1-3 0.8 us each, ranks and apply 0.8.  Listing the keys that are left after
-// two levels (a dozen) and ranking them in one wave instead of levels 2 and 3: 1.4 against 1.6 us, not kept.)
+// two levels (a dozen) and ranking them in one wave instead of levels 2 and 3: 1.4 against 1.6 us, not kept; levels 1-3 on ONE copy of the bins
+// with one barrier each (no adding up): 0.63 against 0.79 us per level by the stamps, 13.4 against 13.4 us per iteration -- a level is
+// its ~100 instructions in each of 16 waves, whatever the barriers.)
 __device__ __forceinline__ void ihtp8_threshold(int q[8], float s, uint32_t tid_, uint32_t n, uint32_t k, uint32_t *hist, uint32_t *hsum, uint32_t *wtot,
                                                 u64 *dbg = nullptr)
 {
