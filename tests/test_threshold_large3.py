@@ -132,6 +132,24 @@ def test_three_launch_threshold_at_full_size(hip):
     os.environ.pop("CLV_THRESHOLD_THREE_LAUNCH", None)
 
 
+def test_three_launch_threshold_beyond_the_register_resident_range(hip):
+    """n = 2^29 - 5 inside a padding of 2^29: a workgroup of the persistent kernel owns more than 16 x 1024 blocks, so the candidate words
+    go through memory (k_th4_select_persist<false>) -- at the real size, not forced; the six-launch form's result bit for bit"""
+    lib = hip.lib
+    n_pad = 1 << 29
+    n = n_pad - 5
+    q, q2, s = hip.alloc(n_pad // 2), hip.alloc(n_pad // 2), hip.alloc(n_pad // 16)
+    hip.check(lib.clv_fill_random_scales(s.ptr, n_pad // 64, 18, 0, None))
+    for k in (n // 4, 4321):
+        for buf, three in ((q, "1"), (q2, "0")):
+            hip.check(lib.clv_fill_random_nibbles(buf.ptr, buf.nbytes, 17, 0, None))
+            os.environ["CLV_THRESHOLD_THREE_LAUNCH"] = three
+            hip.check(lib.clv4_threshold(buf.ptr, s.ptr, n, n_pad, k, None, None))
+        hip.sync()
+        assert np.array_equal(q.download(np.uint8, n_pad // 2), q2.download(np.uint8, n_pad // 2)), k
+    os.environ.pop("CLV_THRESHOLD_THREE_LAUNCH", None)
+
+
 def test_three_launch_threshold_on_two_streams_and_in_a_graph(hip, oracle):
     """the persistent kernel joins the chain of persistent launches (one at a time per device, iht_persist.hip): two host threads on two
     streams, every result right; and the three launches replay from a captured graph (the control block goes back zero after every call;
