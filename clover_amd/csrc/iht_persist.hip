@@ -651,7 +651,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht4_persist(const IhtpArgs A)
 #endif
 struct Ihtp8Layout {
     uint32_t GB1, GB2;            // groups of 4 blocks of Phi's / PhiT's rows
-    uint32_t offA1, offA2, offX, offT, offC1, offC2, offP1, offP2, offHist, offHsum, offWtot, offPub, offChain, total;
+    uint32_t offA1, offA2, offX, offT, offC1, offC2, offP1, offP2, offHist, offHsum, offWtot, offChain, total;
     uint32_t raw1_bytes, raw2_bytes, raw1_room, raw2_room;      // stochastic: the phases' raw draws and the regions they overlay
 };
 __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint32_t R1, uint32_t R2)
@@ -674,7 +674,6 @@ __host__ __device__ inline Ihtp8Layout ihtp8_layout(uint32_t m, uint32_t n, uint
     L.offP1 = o; o += L.GB1 * 16;                                       // f32(sA_b / 7)
     L.offP2 = o; o += L.GB2 * 16;
     L.offWtot = o; o += 64;
-    L.offPub = o; o += 64 * 4;
     L.offChain = o; o += (R1 > R2 ? R1 : R2) * 8 * 4;                    // the 8 chain sums of every local row, on their way to the row's tree
     L.total = o + 256;                                                  // the dot loop reads one group past an array's end
     L.raw1_bytes = ((m / 64 + 3) / 4) * 16 * 32;
@@ -951,7 +950,7 @@ __global__ __launch_bounds__(IHTP_THREADS) void k_iht8_persist(const Ihtp8Args A
     float *p1 = reinterpret_cast<float *>(smem + L.offP1), *p2 = reinterpret_cast<float *>(smem + L.offP2);
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + L.offHist), *hsum = reinterpret_cast<uint32_t *>(smem + L.offHsum);
     uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + L.offWtot);
-    float *pub = reinterpret_cast<float *>(smem + L.offPub), *chain = reinterpret_cast<float *>(smem + L.offChain);
+    float *chain = reinterpret_cast<float *>(smem + L.offChain);
 
     const uint32_t tid0 = threadIdx.x, g = blockIdx.x;
     const uint32_t m = A.m, n = A.n, NB1 = n / 64, NB2 = m / 64, XS1 = L.GB1 * 32, XS2 = L.GB2 * 32;      // words per nibble image
