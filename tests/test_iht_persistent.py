@@ -239,18 +239,25 @@ def test_persistent_calls_on_two_streams_are_chained(hip, oracle):
 
 
 def test_persistent_is_the_path_taken(hip, oracle):
-    """guard against a silent fall-back: at N = 8192 the persistent kernel is several times faster per call than the launch-per-step loop's
-    3 launches per iteration; 200 iterations must finish well inside the loop's time"""
+    """guard against a silent fall-back at the size the benchmarks quote (N = 8192): the library's own counter says that the calls ran as
+    ONE persistent launch each (4-bit and CloverVector8 vectors, both rounding modes), and -- informative, with a wide margin -- such a
+    call is well inside the time of the launch-per-step loop's 3 launches per iteration"""
     import time
     m, n = 4096, 8192
     P = Problem(hip, oracle, m, n, 9)
+    c0 = hip.lib.clv_iht_persistent_launches()
+    P.run(20, n // 4, 1e-3, 1, persistent=True)
+    P.run(20, n // 4, 1e-3, 1, persistent=True, seed=(7, 9))
+    P.run(20, 0, 1e-3, 0, persistent=True)
+    assert hip.lib.clv_iht_persistent_launches() == c0 + 3
     times = {}
     for persistent in (True, False):
         P.run(50, n // 4, 1e-3, 1, persistent=persistent)
         t0 = time.perf_counter()
         P.run(200, n // 4, 1e-3, 1, persistent=persistent)
         times[persistent] = time.perf_counter() - t0
-    assert times[True] < 0.8 * times[False], times
+    assert times[True] < 0.9 * times[False], times
+    os.environ.pop("CLV_IHT_PERSISTENT", None)
 
 
 def test_persistent_launch_counter(hip, oracle):
